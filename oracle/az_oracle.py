@@ -1,0 +1,320 @@
+"""ctypes binding + thin driver for the C oracle (oracle/az_oracle.c).
+
+TEST INFRASTRUCTURE: imported only by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  Nothing under alpha-zero_amd/ imports this module.
+
+The per-move self-play loop (`self_play`) restates <Game>.self_play
+(games/gomoku.py:123-164, games/connect4.py:117-151, games/tictactoe.py:99-133) in Python;
+everything inside a search runs in C.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+KIND = {"tictactoe": 0, "connect4": 1, "gomoku": 2}
+
+
+class _GameT(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("kind", "rows", "cols", "planes", "win_len", "action_dim", "state_dim")]
+
+
+class Counters(C.Structure):
+    _fields_ = [(n, C.c_longlong) for n in ("mcts_count", "matched", "evals", "edges_scanned", "trace_nodes",
+                                             "edges_created", "terminal_sims", "expansions")]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+EVAL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float))
+RANDINT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int)
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "libaz_oracle.so")
+    src = os.path.join(_HERE, "az_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "libaz_oracle.so"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.environ.get("AZ_ORACLE_SO") or build()
+        L = C.CDLL(so)
+        P = C.POINTER
+        L.azo_game_init.argtypes = [P(_GameT), C.c_int, C.c_int, C.c_int]
+        L.azo_get_valid_moves.argtypes = [P(_GameT), C.c_void_p, C.c_void_p]
+        L.azo_make_move.argtypes = [P(_GameT), C.c_void_p, C.c_int, C.c_int]
+        L.azo_undo_move.argtypes = [P(_GameT), C.c_void_p, C.c_int, C.c_int]
+        L.azo_check_winner.argtypes = [P(_GameT), C.c_void_p, C.c_int, C.c_int]
+        L.azo_canonical_board.argtypes = [P(_GameT), C.c_void_p, C.c_int, C.c_void_p]
+        L.azo_action_idx.argtypes = [P(_GameT), C.c_int]
+        L.azo_py_tuple2_hash.argtypes = [C.c_int, C.c_int]
+        L.azo_py_tuple2_hash.restype = C.c_uint64
+        L.azo_py_set_order.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.azo_exp_det.argtypes = [C.c_float]
+        L.azo_exp_det.restype = C.c_float
+        L.azo_exp_det64.argtypes = [C.c_double]
+        L.azo_exp_det64.restype = C.c_double
+        L.azo_pairwise_sum_f32.argtypes = [C.c_void_p, C.c_int]
+        L.azo_pairwise_sum_f32.restype = C.c_float
+        L.azo_softmax_det.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.azo_tree_new.argtypes = [C.c_int]
+        L.azo_tree_new.restype = C.c_void_p
+        L.azo_tree_free.argtypes = [C.c_void_p]
+        L.azo_tree_reset.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.azo_cache_new.argtypes = [C.c_int, C.c_int, C.c_int]
+        L.azo_cache_new.restype = C.c_void_p
+        L.azo_cache_free.argtypes = [C.c_void_p]
+        L.azo_cache_clear.argtypes = [C.c_void_p]
+        L.azo_cache_size.argtypes = [C.c_void_p]
+        L.azo_mcts.argtypes = [P(_GameT), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                               C.c_void_p, C.c_void_p, C.c_void_p, P(Counters)]
+        L.azo_tree_n_nodes.argtypes = [C.c_void_p]
+        L.azo_tree_root_visit.argtypes = [C.c_void_p]
+        L.azo_tree_root_visit.restype = C.c_longlong
+        L.azo_tree_root_value.argtypes = [C.c_void_p]
+        L.azo_tree_root_value.restype = C.c_double
+        L.azo_tree_root_children.argtypes = [C.c_void_p] + [C.c_void_p] * 4
+        L.azo_tree_export.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5
+        L.azo_root_pi.argtypes = [P(_GameT), C.c_void_p, C.c_void_p]
+        L.azo_root_max_visit_cell.argtypes = [C.c_void_p]
+        L.azo_sample_action.argtypes = [C.c_void_p, C.c_int, C.c_double]
+        L.azo_root_cell_for_action.argtypes = [P(_GameT), C.c_void_p, C.c_int]
+        _LIB = L
+    return _LIB
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class OracleGame:
+    """Static board-rule API of one game (games/game.py:4-38 + de-facto extras)."""
+
+    def __init__(self, name, size=None):
+        self.name = name
+        self.g = _GameT()
+        rows = cols = size or 0
+        if lib().azo_game_init(C.byref(self.g), KIND[name], rows, cols) != 0:
+            raise ValueError((name, size))
+        for n, _ in _GameT._fields_:
+            setattr(self, n, getattr(self.g, n))
+        self.feature_dim = self.planes
+
+    def new_board(self):
+        return np.zeros((self.planes, self.rows, self.cols), np.float32)
+
+    def cell(self, mv):
+        return mv[0] * self.cols + mv[1]
+
+    def rc(self, cell):
+        return (int(cell) // self.cols, int(cell) % self.cols)
+
+    def get_action_idx(self, mv):
+        return lib().azo_action_idx(C.byref(self.g), self.cell(mv))
+
+    def valid_cells(self, board):
+        out = np.empty(self.rows * self.cols, np.int32)
+        n = lib().azo_get_valid_moves(C.byref(self.g), _ptr(board), _ptr(out))
+        return out[:n].copy()
+
+    def get_valid_moves(self, board):
+        return [self.rc(c) for c in self.valid_cells(board)]
+
+    def make_move(self, board, player, mv):
+        return lib().azo_make_move(C.byref(self.g), _ptr(board), int(player), self.cell(mv))
+
+    def undo_move(self, board, current_player, mv):
+        lib().azo_undo_move(C.byref(self.g), _ptr(board), int(current_player), self.cell(mv))
+
+    def check_winner(self, board, player, mv):
+        return lib().azo_check_winner(C.byref(self.g), _ptr(board), int(player), self.cell(mv))
+
+    def get_canonical_board(self, board, player):
+        out = np.empty_like(board)
+        lib().azo_canonical_board(C.byref(self.g), _ptr(board), int(player), _ptr(out))
+        return out
+
+    def board_from_cells(self, cells, side_to_move=0):
+        b = self.new_board()
+        cells = np.asarray(cells).reshape(self.rows, self.cols)
+        b[0] = cells == 1
+        b[1] = cells == 2
+        if self.planes == 3:
+            b[2] = side_to_move
+        return b
+
+
+class OracleCache:
+    """MCTS.cache (ai/mcts.py:7)."""
+
+    def __init__(self, game):
+        self.h = lib().azo_cache_new(4 * game.planes * game.rows * game.cols, game.action_dim, 1 << 12)
+
+    def clear(self):
+        lib().azo_cache_clear(self.h)
+
+    def __len__(self):
+        return lib().azo_cache_size(self.h)
+
+    def __del__(self):
+        try:
+            lib().azo_cache_free(self.h)
+        except Exception:
+            pass
+
+
+class OracleTree:
+    def __init__(self, game, cap=4096):
+        self.game = game
+        self.h = lib().azo_tree_new(cap)
+
+    def __del__(self):
+        try:
+            lib().azo_tree_free(self.h)
+        except Exception:
+            pass
+
+    def reset(self, player, move_count):
+        lib().azo_tree_reset(self.h, int(player), int(move_count))
+
+    @property
+    def n_nodes(self):
+        return lib().azo_tree_n_nodes(self.h)
+
+    @property
+    def root_visit(self):
+        return lib().azo_tree_root_visit(self.h)
+
+    @property
+    def root_value(self):
+        return lib().azo_tree_root_value(self.h)
+
+    def root_children(self):
+        A = self.game.rows * self.game.cols
+        cells = np.empty(A, np.int32); visits = np.empty(A, np.int64)
+        values = np.empty(A, np.float64); priors = np.empty(A, np.float64)
+        n = lib().azo_tree_root_children(self.h, _ptr(cells), _ptr(visits), _ptr(values), _ptr(priors))
+        return dict(cell=cells[:n].copy(), visit=visits[:n].copy(), value=values[:n].copy(), prior=priors[:n].copy())
+
+    def export(self):
+        n = self.n_nodes
+        depth = np.empty(n, np.int32); cell = np.empty(n, np.int32); visit = np.empty(n, np.int64)
+        value = np.empty(n, np.float64); prior = np.empty(n, np.float64)
+        m = lib().azo_tree_export(self.h, n, _ptr(depth), _ptr(cell), _ptr(visit), _ptr(value), _ptr(prior))
+        assert m <= n
+        return dict(depth=depth[:m], cell=cell[:m], visit=visit[:m], value=value[:m], prior=prior[:m])
+
+    def pi(self):
+        out = np.empty(self.game.action_dim, np.float64)
+        lib().azo_root_pi(C.byref(self.game.g), self.h, _ptr(out))
+        return out
+
+    def max_visit_cell(self):
+        return lib().azo_root_max_visit_cell(self.h)
+
+    def cell_for_action(self, a):
+        return lib().azo_root_cell_for_action(C.byref(self.game.g), self.h, int(a))
+
+
+def sample_action(pi, u):
+    pi = np.ascontiguousarray(pi, np.float64)
+    return lib().azo_sample_action(_ptr(pi), len(pi), float(u))
+
+
+def softmax_det(logits):
+    logits = np.ascontiguousarray(logits, np.float32)
+    out = np.empty_like(logits)
+    lib().azo_softmax_det(_ptr(logits), len(logits), _ptr(out))
+    return out
+
+
+def mcts(game, tree, board, n_iter, evaluator=None, noise=None, cache=None, randint=None, counters=None):
+    """MCTS.mcts (ai/mcts.py:11).  evaluator(canonical f32[F,R,C]) -> (priors f32[A], value float)
+    (softmax already applied - with numpy's expression to check the oracle against the reference,
+    with softmax_det to check the HIP engine against the oracle); None = vanilla mode."""
+    shape = (game.planes, game.rows, game.cols)
+    err = []
+
+    def _eval(ctx, canon_p, pri_p, val_p):
+        try:
+            canon = np.ctypeslib.as_array(canon_p, shape=shape)
+            pri, v = evaluator(canon)
+            np.ctypeslib.as_array(pri_p, shape=(game.action_dim,))[:] = np.asarray(pri, np.float32)
+            val_p[0] = float(v)
+            return 0
+        except Exception as e:  # never raise across the C frame
+            err.append(e)
+            return -1
+
+    def _rand(ctx, n):
+        return int(randint(n))
+
+    ecb = EVAL_FN(_eval) if evaluator is not None else None
+    rcb = RANDINT_FN(_rand) if randint is not None else None
+    assert board.dtype == np.float32 and board.flags.c_contiguous
+    nz = None
+    if noise is not None:
+        nz = np.ascontiguousarray(noise, np.float64)
+    rc = lib().azo_mcts(C.byref(game.g), tree.h, _ptr(board), int(n_iter),
+                        C.cast(ecb, C.c_void_p) if ecb else None, None,
+                        _ptr(nz) if nz is not None else None,
+                        cache.h if cache is not None else None,
+                        C.cast(rcb, C.c_void_p) if rcb else None, None,
+                        C.byref(counters) if counters is not None else None)
+    if err:
+        raise err[0]
+    if rc != 0:
+        raise RuntimeError(f"azo_mcts failed: {rc}")
+
+
+def self_play(game, evaluator, n_sims, noise_fn=None, uniform_fn=None, cache=None, randint=None,
+              counters=None, max_moves=None):
+    """<Game>.self_play.  noise_fn(move_idx)->f64[A] supplies np.random.dirichlet's draw,
+    uniform_fn(move_idx)->float the uniform consumed by np.random.choice.  Returns a dict with
+    boards (raw, not canonical), cells played, pis, qs, winner."""
+    board = game.new_board()
+    tree = OracleTree(game)
+    player, mc = 0, 0
+    boards, cells, pis, qs = [], [], [], []
+    winner = None
+    while True:
+        tree.reset(player, mc)
+        noise = noise_fn(mc) if (evaluator is not None and noise_fn is not None) else None
+        mcts(game, tree, board, n_sims, evaluator, noise, cache, randint, counters)
+        pi = tree.pi()
+        pis.append(pi)
+        boards.append(board.copy())
+        qs.append(tree.root_value / tree.root_visit)
+        if evaluator is not None:
+            sample = (mc < 8) if game.name == "gomoku" else True        # gomoku.py:144 vs tictactoe.py:117
+        else:
+            sample = False
+        if sample:
+            a = sample_action(pi, uniform_fn(mc))
+            cell = tree.cell_for_action(a)
+            assert cell >= 0
+        else:
+            cell = tree.max_visit_cell()
+        mover = player
+        player = game.make_move(board, player, game.rc(cell))
+        mc += 1
+        cells.append(cell)
+        w = game.check_winner(board, mover, game.rc(cell))
+        if w != -1:
+            winner = w
+            break
+        if mc == game.state_dim:
+            winner = -1
+            break
+        if max_moves is not None and mc >= max_moves:
+            break
+    return dict(boards=boards, cells=np.array(cells, np.int32), pis=np.stack(pis), qs=np.array(qs), winner=winner)
