@@ -1,0 +1,84 @@
+"""MCTS.mcts with the reference's signature (ai/mcts.py:11), executed by the HIP engine.
+
+    MCTS.mcts(model, board, root, Game, mcts_iterations, dirichlet=True) -> None
+
+Results come back the way the reference returns them: by mutation of `root` (visit, value, children
+with visit / value / prior / prevAction); `board` is left exactly as passed.  `model` is any callable
+tensor[n,F,R,C] (CUDA, float32) -> (logits[n,A], value[n,1]).  The Dirichlet draw is taken from the global
+np.random stream at the same point the reference takes it (one np.random.dirichlet per search, utils.py:24),
+so a seeded caller sees the same noise.
+
+`MCTS.mcts_batch` is the batched form the self-play driver uses (many roots, one call).
+"""
+import numpy as np
+
+from .node import Node
+
+_ENGINES = {}
+
+
+def _engine(Game, n_games, n_sims):
+    import azk
+    key = (Game.engine_name, Game.rows, Game.cols, n_games)
+    eng = _ENGINES.get(key)
+    if eng is None or eng.max_sims < n_sims:
+        if eng is not None:
+            eng.close()
+        size = Game.rows if Game.engine_name == "gomoku" else None
+        eng = azk.Engine(Game.engine_name, n_games, max(n_sims, 64), size=size)
+        _ENGINES[key] = eng
+    return eng
+
+
+def _cells(board):
+    return (np.asarray(board[0]) == 1).astype(np.int8) + 2 * (np.asarray(board[1]) == 1).astype(np.int8)
+
+
+class MCTS:
+    # ai/mcts.py:7-9.  The engine has no eval cache yet (it is semantically transparent),
+    # so `matched` stays 0 and `cache` stays empty; mcts_count counts simulations as the reference does.
+    cache = {}
+    matched = 0
+    mcts_count = 0
+
+    @staticmethod
+    def mcts(model, board, root, Game, mcts_iterations, dirichlet=True):
+        if model is None:
+            raise NotImplementedError("vanilla (model=None) rollouts are not on the GPU path; "
+                                      "the network-guided search (model given) is")
+        MCTS.mcts_batch(model, [board], [root], Game, mcts_iterations, dirichlet)
+
+    @staticmethod
+    def mcts_batch(model, boards, roots, Game, mcts_iterations, dirichlet=True, noise=None):
+        import torch
+        G = len(boards)
+        eng = _engine(Game, G, mcts_iterations)
+        A = Game.action_dim
+        cells = np.stack([_cells(b).reshape(-1) for b in boards])
+        eng.set_positions(cells, [r.currentPlayer for r in roots], [r.move_count for r in roots])
+        nz = None
+        if dirichlet:
+            if noise is None:
+                noise = np.stack([np.random.dirichlet([0.03] * A) for _ in range(G)])     # utils.py:12,24
+            nz = torch.from_numpy(np.ascontiguousarray(noise, np.float64)).to(eng.device)
+
+        def evaluator(x):
+            logits, value = model(x)
+            return logits, value
+        eng.search(evaluator, mcts_iterations, nz)
+        eng.check_error()
+        MCTS.mcts_count += mcts_iterations * G
+        _, q, rv = eng.root_stats()
+        q, rv = q.cpu().numpy(), rv.cpu().numpy()
+        for g, root in enumerate(roots):
+            ch = eng.root_children(g)
+            root.visit = int(rv[g])
+            root.value = float(eng.export_tree(g, cap=1)["value"][0])      # W of the root, exact
+            f32_prior = not dirichlet
+            root.children = []
+            for cell, n, w, p in zip(ch["cell"], ch["visit"], ch["value"], ch["prior"]):
+                node = Node(root, (int(cell) // Game.cols, int(cell) % Game.cols), 1 - root.currentPlayer,
+                            root.move_count + 1, np.float32(p) if f32_prior else np.float64(p))
+                node.visit = int(n)
+                node.value = float(w)
+                root.children.append(node)

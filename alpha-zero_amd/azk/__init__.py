@@ -1,0 +1,365 @@
+"""azk - ctypes binding of libazk.so (include/azk.h), the MI355X-native self-play engine.
+
+Host orchestration stays Python (as in the reference); everything on the hot path is a HIP kernel
+behind the C ABI.  There is NO CPU fallback: if libazk.so is missing or no GPU is visible the
+functions here raise.  PyTorch is used for device memory and streams only.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(os.path.dirname(_HERE), "csrc")
+LIB_PATH = os.path.join(_HERE, "libazk.so")
+
+GAME_ID = {"tictactoe": 0, "connect4": 1, "gomoku": 2}
+LEAF_F32, LEAF_BF16 = 0, 1
+
+# every symbol include/azk.h declares (checked by tests/test_abi.py against the header text)
+SYMBOLS = [
+    "azk_abi_version", "azk_last_error", "azk_create", "azk_destroy", "azk_geometry", "azk_reset_games",
+    "azk_set_positions", "azk_begin_search", "azk_step_select", "azk_step_expand_backup", "azk_step",
+    "azk_root_stats", "azk_root_children", "azk_export_tree", "azk_advance", "azk_get_positions",
+    "azk_get_counters", "azk_reset_counters", "azk_check_device_error", "azk_gen_noise",
+    "azk_rules_legal_moves", "azk_rules_legal_mask", "azk_rules_apply_move", "azk_rules_undo_move",
+    "azk_rules_check_winner", "azk_rules_canonical", "azk_softmax_rows",
+]
+
+
+class AzkError(RuntimeError):
+    pass
+
+
+class Config(C.Structure):
+    _fields_ = [("game", C.c_int32), ("rows", C.c_int32), ("cols", C.c_int32), ("n_games", C.c_int32),
+                ("max_sims", C.c_int32), ("leaf_dtype", C.c_int32), ("device", C.c_int32),
+                ("arena_nodes", C.c_int32), ("reserved", C.c_int32 * 8)]
+
+
+class Counters(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ("sims", "edges_scanned", "trace_nodes", "edges_created",
+                                          "leaves_evaluated", "terminal_sims", "moves_played")] + [("reserved", C.c_int64 * 9)]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_[:7]}
+
+
+def build(force=False, verbose=False):
+    """Compile libazk.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith((".hip", ".h"))]
+    srcs.append(os.path.join(os.path.dirname(os.path.dirname(_HERE)), "include", "azk.h"))
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
+        return LIB_PATH
+    cmd = ["make", "-C", _CSRC] + (["-B"] if force else [])
+    r = subprocess.run(cmd, capture_output=not verbose, text=True)
+    if r.returncode != 0:
+        raise AzkError("building libazk.so failed:\n" + (r.stdout or "") + (r.stderr or ""))
+    return LIB_PATH
+
+
+_LIB = None
+
+
+def lib():
+    """Load libazk.so (no GPU needed to load; compute entry points need one)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise AzkError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(the HIP extension is required; there is no CPU fallback)")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64, u64, f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_double
+    L.azk_abi_version.restype = i32
+    L.azk_last_error.restype = C.c_char_p
+    L.azk_last_error.argtypes = [vp]
+    L.azk_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+    L.azk_destroy.argtypes = [vp]
+    L.azk_destroy.restype = None
+    L.azk_geometry.argtypes = [vp] + [C.POINTER(i32)] * 5
+    L.azk_reset_games.argtypes = [vp, i32, i32, vp]
+    L.azk_set_positions.argtypes = [vp, i32, i32, vp, vp, vp, vp]
+    L.azk_begin_search.argtypes = [vp, vp, vp]
+    L.azk_step_select.argtypes = [vp, vp, vp, vp]
+    L.azk_step_expand_backup.argtypes = [vp, vp, vp, vp]
+    L.azk_step.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.azk_root_stats.argtypes = [vp, vp, vp, vp, vp]
+    L.azk_root_children.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp]
+    L.azk_export_tree.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp]
+    L.azk_advance.argtypes = [vp, vp, i32, vp, vp, vp, vp]
+    L.azk_get_positions.argtypes = [vp, vp, vp, vp, vp]
+    L.azk_get_counters.argtypes = [vp, C.POINTER(Counters), vp]
+    L.azk_reset_counters.argtypes = [vp, vp]
+    L.azk_check_device_error.argtypes = [vp, vp]
+    L.azk_gen_noise.argtypes = [vp, u64, i64, i32, f64, vp, vp, vp]
+    for name in ("azk_rules_legal_moves",):
+        getattr(L, name).argtypes = [i32, i32, i32, vp, i32, vp, vp, vp]
+    L.azk_rules_legal_mask.argtypes = [i32, i32, i32, vp, i32, vp, vp]
+    L.azk_rules_apply_move.argtypes = [i32, i32, i32, vp, i32, vp, vp, vp, vp]
+    L.azk_rules_undo_move.argtypes = [i32, i32, i32, vp, i32, vp, vp, vp]
+    L.azk_rules_check_winner.argtypes = [i32, i32, i32, vp, i32, vp, vp, vp, vp]
+    L.azk_rules_canonical.argtypes = [i32, i32, i32, vp, i32, vp, vp, vp]
+    L.azk_softmax_rows.argtypes = [vp, i32, i32, vp, vp]
+    for name in SYMBOLS:
+        f = getattr(L, name)
+        if name not in ("azk_last_error", "azk_destroy"):
+            f.restype = i32
+    _LIB = L
+    return L
+
+
+def _torch():
+    import torch
+    if not torch.cuda.is_available():
+        raise AzkError("no GPU visible: the azk engine runs only on an MI355X (no CPU fallback)")
+    return torch
+
+
+def _stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _np(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class Engine:
+    """G concurrent games + their search trees resident on one GPU (one engine per process / GPU)."""
+
+    def __init__(self, game, n_games, max_sims, size=None, device=0, leaf_dtype="float32", arena_nodes=0):
+        torch = _torch()
+        self.torch = torch
+        self.L = lib()
+        self.game = game
+        cfg = Config()
+        cfg.game = GAME_ID[game]
+        cfg.rows = cfg.cols = int(size or 0)
+        cfg.n_games, cfg.max_sims, cfg.device, cfg.arena_nodes = int(n_games), int(max_sims), int(device), int(arena_nodes)
+        cfg.leaf_dtype = LEAF_BF16 if leaf_dtype in ("bfloat16", "bf16", torch.bfloat16) else LEAF_F32
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
+        h = C.c_void_p()
+        rc = self.L.azk_create(C.byref(cfg), C.byref(h))
+        if rc != 0:
+            raise AzkError(f"azk_create failed ({rc}): {self.L.azk_last_error(None).decode()}")
+        self.h = h
+        vals = [C.c_int32() for _ in range(5)]
+        self._chk(self.L.azk_geometry(self.h, *[C.byref(v) for v in vals]))
+        self.planes, self.rows, self.cols, self.action_dim, self.state_dim = [v.value for v in vals]
+        self.G, self.max_sims = int(n_games), int(max_sims)
+        tdt = torch.bfloat16 if cfg.leaf_dtype == LEAF_BF16 else torch.float32
+        dev = self.device
+        self.leaf_boards = torch.zeros((self.G, self.planes, self.rows, self.cols), dtype=tdt, device=dev)
+        self.n_leaf = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.pi = torch.zeros((self.G, self.action_dim), dtype=torch.float64, device=dev)
+        self.q = torch.zeros(self.G, dtype=torch.float64, device=dev)
+        self.root_visit = torch.zeros(self.G, dtype=torch.int32, device=dev)
+        self.chosen = torch.zeros(self.G, dtype=torch.int32, device=dev)
+        self.winner = torch.zeros(self.G, dtype=torch.int32, device=dev)
+        self.done = torch.zeros(self.G, dtype=torch.int32, device=dev)
+        self._noise = None
+
+    def _chk(self, rc):
+        if rc < 0:
+            raise AzkError(f"libazk error {rc}: {self.L.azk_last_error(self.h).decode()}")
+        return rc
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.azk_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- state ----------------------------------------------------------------------------------
+    def reset_games(self, first=0, count=None):
+        self._chk(self.L.azk_reset_games(self.h, first, self.G - first if count is None else count, _stream()))
+
+    def set_positions(self, cells, to_move, move_count, first=0):
+        cells = np.ascontiguousarray(cells, np.int8).reshape(-1, self.rows * self.cols)
+        tm = np.ascontiguousarray(to_move, np.int32)
+        mc = np.ascontiguousarray(move_count, np.int32)
+        self._chk(self.L.azk_set_positions(self.h, first, len(cells), _np(cells), _np(tm), _np(mc), _stream()))
+
+    def get_positions(self):
+        cells = np.empty((self.G, self.rows * self.cols), np.int8)
+        tm = np.empty(self.G, np.int32)
+        mc = np.empty(self.G, np.int32)
+        self._chk(self.L.azk_get_positions(self.h, _np(cells), _np(tm), _np(mc), _stream()))
+        return cells, tm, mc
+
+    # ---- search ---------------------------------------------------------------------------------
+    def begin_search(self, noise=None):
+        """noise: float64 CUDA tensor [G, A] (np.random.dirichlet draws) or None (dirichlet=False)."""
+        if noise is not None:
+            assert noise.dtype == self.torch.float64 and noise.is_cuda and noise.is_contiguous()
+            assert tuple(noise.shape) == (self.G, self.action_dim)
+        self._noise = noise     # keep alive for the whole search
+        self._chk(self.L.azk_begin_search(self.h, _p(noise), _stream()))
+
+    def step(self, logits=None, values=None):
+        """expand+backup the previous leaves (if logits given) and select the next; no host sync."""
+        self._chk(self.L.azk_step(self.h, _p(logits), _p(values), _p(self.leaf_boards), _p(self.n_leaf), _stream()))
+
+    def step_select(self):
+        self._chk(self.L.azk_step_select(self.h, _p(self.leaf_boards), _p(self.n_leaf), _stream()))
+
+    def step_expand_backup(self, logits, values):
+        self._chk(self.L.azk_step_expand_backup(self.h, _p(logits), _p(values), _stream()))
+
+    def search(self, evaluator, n_sims, noise=None):
+        """MCTS.mcts for all G games: n_sims simulations each, one in flight per game.
+        evaluator(boards[n,F,R,C]) -> (logits[n,A] float32, values[n] or [n,1] float32), on the GPU."""
+        assert n_sims <= self.max_sims
+        torch = self.torch
+        self.begin_search(noise)
+        logits = values = None
+        for _ in range(n_sims):
+            self.step(logits, values)
+            n = int(self.n_leaf.item())
+            if n > 0:
+                logits, values = evaluator(self.leaf_boards[:n])
+                logits = logits.to(torch.float32).contiguous()
+                values = values.to(torch.float32).reshape(-1).contiguous()
+                assert logits.shape == (n, self.action_dim) and values.shape[0] == n
+            else:
+                logits = values = None
+        if logits is not None:
+            self.step_expand_backup(logits, values)
+
+    def root_stats(self):
+        self._chk(self.L.azk_root_stats(self.h, _p(self.pi), _p(self.q), _p(self.root_visit), _stream()))
+        return self.pi, self.q, self.root_visit
+
+    def advance(self, uniforms=None, sample_until_move=0):
+        if uniforms is not None:
+            assert uniforms.dtype == self.torch.float64 and uniforms.is_cuda and uniforms.numel() == self.G
+        self._chk(self.L.azk_advance(self.h, _p(uniforms), int(sample_until_move), _p(self.chosen), _p(self.winner),
+                                     _p(self.done), _stream()))
+        return self.chosen, self.winner, self.done
+
+    def gen_noise(self, seed, first_global_game, move_index, alpha=0.03, want_noise=True, want_uniforms=True):
+        torch = self.torch
+        noise = torch.empty((self.G, self.action_dim), dtype=torch.float64, device=self.device) if want_noise else None
+        uni = torch.empty(self.G, dtype=torch.float64, device=self.device) if want_uniforms else None
+        self._chk(self.L.azk_gen_noise(self.h, int(seed), int(first_global_game), int(move_index), float(alpha),
+                                       _p(noise), _p(uni), _stream()))
+        return noise, uni
+
+    # ---- inspection -----------------------------------------------------------------------------
+    def root_children(self, game):
+        cap = self.rows * self.cols
+        cells = np.empty(cap, np.int32); visits = np.empty(cap, np.int32)
+        values = np.empty(cap, np.float64); priors = np.empty(cap, np.float64)
+        n = self._chk(self.L.azk_root_children(self.h, int(game), cap, _np(cells), _np(visits), _np(values), _np(priors), _stream()))
+        return dict(cell=cells[:n].copy(), visit=visits[:n].astype(np.int64), value=values[:n].copy(), prior=priors[:n].copy())
+
+    def export_tree(self, game, cap=None):
+        cap = cap or (1 + self.max_sims * self.rows * self.cols)
+        depth = np.empty(cap, np.int32); cell = np.empty(cap, np.int32); visit = np.empty(cap, np.int32)
+        value = np.empty(cap, np.float64); prior = np.empty(cap, np.float64)
+        n = self._chk(self.L.azk_export_tree(self.h, int(game), cap, _np(depth), _np(cell), _np(visit), _np(value), _np(prior), _stream()))
+        n = min(n, cap)
+        return dict(depth=depth[:n], cell=cell[:n], visit=visit[:n].astype(np.int64), value=value[:n], prior=prior[:n])
+
+    def counters(self):
+        c = Counters()
+        self._chk(self.L.azk_get_counters(self.h, C.byref(c), _stream()))
+        return c.as_dict()
+
+    def reset_counters(self):
+        self._chk(self.L.azk_reset_counters(self.h, _stream()))
+
+    def check_error(self):
+        rc = self.L.azk_check_device_error(self.h, _stream())
+        if rc != 0:
+            raise AzkError(f"device error {rc}: {self.L.azk_last_error(self.h).decode()}")
+
+
+# ---- stateless board-rule kernels (Game statics) over float32 boards [n, F, R, C] on the GPU ------------
+def _geom(game, size):
+    gid = GAME_ID[game]
+    s = int(size or 0)
+    return gid, s, s
+
+
+def _rules_chk(rc):
+    if rc != 0:
+        raise AzkError(f"libazk rules error {rc}: {lib().azk_last_error(None).decode()}")
+
+
+def rules_legal_moves(game, boards, size=None):
+    """boards: float32 CUDA tensor [n,F,R,C] -> (moves int16 [n, R*C] in the reference's list order, counts int32 [n])."""
+    torch = _torch()
+    assert boards.is_cuda and boards.dtype == torch.float32 and boards.is_contiguous()
+    n, rc = boards.shape[0], boards.shape[2] * boards.shape[3]
+    moves = torch.full((n, rc), -1, dtype=torch.int16, device=boards.device)
+    counts = torch.zeros(n, dtype=torch.int32, device=boards.device)
+    _rules_chk(lib().azk_rules_legal_moves(*_geom(game, size), _p(boards), n, _p(moves), _p(counts), _stream()))
+    return moves, counts
+
+
+def rules_legal_mask(game, boards, action_dim, size=None):
+    torch = _torch()
+    assert boards.is_cuda and boards.dtype == torch.float32 and boards.is_contiguous()
+    n = boards.shape[0]
+    mask = torch.zeros((n, action_dim), dtype=torch.uint8, device=boards.device)
+    _rules_chk(lib().azk_rules_legal_mask(*_geom(game, size), _p(boards), n, _p(mask), _stream()))
+    return mask
+
+
+def rules_apply_move(game, boards, players, cells, size=None):
+    """in-place make_move on each board; returns next player int32 [n]."""
+    torch = _torch()
+    assert boards.is_cuda and boards.dtype == torch.float32 and boards.is_contiguous()
+    n = boards.shape[0]
+    players = players.to(torch.int32).contiguous(); cells = cells.to(torch.int32).contiguous()
+    nxt = torch.zeros(n, dtype=torch.int32, device=boards.device)
+    _rules_chk(lib().azk_rules_apply_move(*_geom(game, size), _p(boards), n, _p(players), _p(cells), _p(nxt), _stream()))
+    return nxt
+
+
+def rules_undo_move(game, boards, current_players, cells, size=None):
+    torch = _torch()
+    assert boards.is_cuda and boards.dtype == torch.float32 and boards.is_contiguous()
+    n = boards.shape[0]
+    cp = current_players.to(torch.int32).contiguous(); cells = cells.to(torch.int32).contiguous()
+    _rules_chk(lib().azk_rules_undo_move(*_geom(game, size), _p(boards), n, _p(cp), _p(cells), _stream()))
+
+
+def rules_check_winner(game, boards, players, cells, size=None):
+    torch = _torch()
+    assert boards.is_cuda and boards.dtype == torch.float32 and boards.is_contiguous()
+    n = boards.shape[0]
+    players = players.to(torch.int32).contiguous(); cells = cells.to(torch.int32).contiguous()
+    out = torch.zeros(n, dtype=torch.int32, device=boards.device)
+    _rules_chk(lib().azk_rules_check_winner(*_geom(game, size), _p(boards), n, _p(players), _p(cells), _p(out), _stream()))
+    return out
+
+
+def rules_canonical(game, boards, players, size=None):
+    torch = _torch()
+    assert boards.is_cuda and boards.dtype == torch.float32 and boards.is_contiguous()
+    players = players.to(torch.int32).contiguous()
+    out = torch.empty_like(boards)
+    _rules_chk(lib().azk_rules_canonical(*_geom(game, size), _p(boards), boards.shape[0], _p(players), _p(out), _stream()))
+    return out
+
+
+def softmax_rows(logits):
+    torch = _torch()
+    logits = logits.to(torch.float32).contiguous()
+    out = torch.empty_like(logits)
+    _rules_chk(lib().azk_softmax_rows(_p(logits), logits.shape[0], logits.shape[1], _p(out), _stream()))
+    return out

@@ -1,0 +1,329 @@
+// azk_device.h - device-side building blocks shared by the engine and the stateless rule kernels.
+// gfx950 only: 64-lane wavefronts; one wavefront (= one 64-thread workgroup) owns one game/board.
+// Reference lines cited as file:line relative to the reference root.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define AZK_WAVE 64
+#define AZK_KIND_TTT 0
+#define AZK_KIND_C4 1
+#define AZK_KIND_GOMOKU 2
+
+// Cell codes held in LDS / HBM boards: bit0 = player-0 stone (plane0 == 1), bit1 = player-1 stone
+// (plane1 == 1), bit2 = "occupied by something that is not exactly 1.0" (only reachable through the
+// stateless float32 API).  Empty <=> code == 0 (the reference tests plane0 == 0 and plane1 == 0).
+struct GameDesc {
+    int kind, rows, cols, rc, planes, win_len, action_dim, state_dim;
+};
+
+__device__ __forceinline__ int azk_action_idx(const GameDesc &g, int cell) {
+    return g.kind == AZK_KIND_C4 ? cell % g.cols : cell;   // connect4.py:29 / gomoku.py:48 / tictactoe.py:34
+}
+
+__device__ __forceinline__ int azk_lane() { return threadIdx.x & 63; }
+
+__device__ __forceinline__ int uniform_i32(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// ---- wave reductions -------------------------------------------------------------------------
+// argmax with "first maximum wins" (Python max(), node.py:47,81): larger value, then lower index.
+template <typename T>
+__device__ __forceinline__ void wave_argmax_first(T &v, int &idx) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        T ov = __shfl_xor(v, off);
+        int oi = __shfl_xor(idx, off);
+        if (oi < 0x7fffffff && (idx == 0x7fffffff || ov > v || (ov == v && oi < idx))) { v = ov; idx = oi; }
+    }
+}
+
+__device__ __forceinline__ int wave_sum_i32(int v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+// ---- k-in-a-row through a cell: tictactoe.py:54-79, connect4.py:73-98, gomoku.py:66-91 ----------
+// 1 + run(+dir) + run(-dir) >= K for any of the four directions; the origin cell itself is NOT
+// tested (the reference's counter starts at 1).  Lanes 0..7 each walk one (direction, side).
+__device__ __forceinline__ int azk_check_winner(const uint8_t *b, const GameDesc &g, int player, int cell) {
+    int lane = azk_lane();
+    int cnt = 0;
+    if (lane < 8) {
+        int d = lane >> 1, sg = (lane & 1) ? -1 : 1;
+        int dr = (d > 0 ? 1 : 0) * sg;
+        int dc = (d == 0 ? 1 : (d == 1 ? 0 : (d == 2 ? 1 : -1))) * sg;
+        int r = cell / g.cols + dr, c = cell % g.cols + dc;
+        while (cnt < g.win_len - 1 && r >= 0 && r < g.rows && c >= 0 && c < g.cols &&
+               ((b[r * g.cols + c] >> player) & 1)) {
+            cnt++; r += dr; c += dc;
+        }
+    }
+    int other = __shfl_xor(cnt, 1);
+    bool win = lane < 8 && (1 + cnt + other >= g.win_len);
+    return __ballot(win) != 0ull ? player : -1;
+}
+
+// ---- CPython 3.10 tuple hash of (r, c) (Objects/tupleobject.c) -----------------------------------
+__device__ __forceinline__ unsigned long long py_tuple2_hash(int r, int c) {
+    const unsigned long long P1 = 11400714785074694791ULL, P2 = 14029467366897019727ULL, P5 = 2870177450012600261ULL;
+    unsigned long long acc = P5;
+    acc += (unsigned long long)r * P2; acc = (acc << 31) | (acc >> 33); acc *= P1;
+    acc += (unsigned long long)c * P2; acc = (acc << 31) | (acc >> 33); acc *= P1;
+    acc += 2ULL ^ (P5 ^ 3527539ULL);
+    if (acc == ~0ULL) return 1546275796ULL;
+    return acc;
+}
+
+// LDS scratch for move generation (pointers carved by the caller; all 16-byte aligned)
+struct MoveScratch {
+    uint32_t *bits;              // [ceil(rc*8/32)] first-adder key bitmap
+    uint16_t *pref;              // [ceil(rc*8/32)] exclusive popcount prefix
+    int16_t *ord;                // [rc] candidate cells in first-insertion order
+    unsigned long long *chash;   // [rc] tuple hash per cell
+    uint16_t *tabA, *tabB;       // [table_size] emulated set tables (cell+1, 0 = empty)
+    int table_size;
+};
+
+// set_insert_clean (Objects/setobject.c): first free slot along the probe sequence
+__device__ __forceinline__ void py_set_insert_clean(uint16_t *tab, unsigned mask, uint16_t key, unsigned long long h) {
+    unsigned long long perturb = h;
+    unsigned i = (unsigned)h & mask;
+    for (;;) {
+        if (tab[i] == 0) { tab[i] = key; return; }
+        if (i + 9 <= mask) {
+            for (unsigned j = 1; j <= 9; j++)
+                if (tab[i + j] == 0) { tab[i + j] = key; return; }
+        }
+        perturb >>= 5;
+        i = (unsigned)((unsigned long long)i * 5 + 1 + perturb) & mask;
+    }
+}
+
+// get_valid_moves in the reference's LIST ORDER; returns the count (wave-uniform); moves[] in LDS.
+//   TicTacToe  tictactoe.py:82-83   empty cells, row-major
+//   Connect4   connect4.py:44-53    per column with an empty top cell: (lowest empty row, col)
+//   Gomoku     gomoku.py:93-106     empty 8-neighbours of any stone as list(set(...)): CPython set
+//                                   iteration order; centre cell when there is no candidate.
+// All lanes must call this (it synchronises the single-wave workgroup).
+__device__ int azk_valid_moves(const uint8_t *b, const GameDesc &g, int16_t *moves, const MoveScratch &ms) {
+    const int lane = azk_lane();
+    int n = 0;
+    if (g.kind == AZK_KIND_TTT) {
+        for (int base = 0; base < g.rc; base += AZK_WAVE) {
+            int i = base + lane;
+            bool emp = i < g.rc && b[i] == 0;
+            unsigned long long m = __ballot(emp);
+            if (emp) moves[n + __popcll(m & ((1ull << lane) - 1ull))] = (int16_t)i;
+            n += __popcll(m);
+        }
+        __syncthreads();
+        return n;
+    }
+    if (g.kind == AZK_KIND_C4) {
+        int cell = -1;
+        if (lane < g.cols && b[lane] == 0) {
+            for (int row = g.rows - 1; row >= 0; row--)
+                if (b[row * g.cols + lane] == 0) { cell = row * g.cols + lane; break; }
+        }
+        unsigned long long m = __ballot(cell >= 0);
+        if (cell >= 0) moves[__popcll(m & ((1ull << lane) - 1ull))] = (int16_t)cell;
+        __syncthreads();
+        return __popcll(m);
+    }
+    // ---- Gomoku ----
+    const int R = g.rows, C = g.cols, rc = g.rc;
+    const int nwords = (rc * 8 + 31) >> 5;
+    for (int w = lane; w < nwords; w += AZK_WAVE) ms.bits[w] = 0u;
+    __syncthreads();
+    // 1. per empty cell: key = (row-major index of the first stone that adds it) * 8 + (its slot in that
+    //    stone's add order: (0,+1) (0,-1) (+1,0) (-1,0) (+1,+1) (-1,-1) (+1,-1) (-1,+1)), gomoku.py:97-102
+    for (int e = lane; e < rc; e += AZK_WAVE) {
+        if (b[e] != 0) continue;
+        int r = e / C, c = e % C;
+        unsigned key = 0xffffffffu;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            int d = j >> 1, sg = (j & 1) ? -1 : 1;
+            int dr = (d > 0 ? 1 : 0) * sg;
+            int dc = (d == 0 ? 1 : (d == 1 ? 0 : (d == 2 ? 1 : -1))) * sg;
+            int sr = r - dr, sc = c - dc;                       // the stone that would add e through slot j
+            if (sr >= 0 && sr < R && sc >= 0 && sc < C && (b[sr * C + sc] & 3)) {
+                unsigned k = (unsigned)(sr * C + sc) * 8u + (unsigned)j;
+                key = k < key ? k : key;
+            }
+        }
+        if (key != 0xffffffffu) {
+            atomicOr(&ms.bits[key >> 5], 1u << (key & 31));
+            ms.chash[e] = py_tuple2_hash(r, c);
+        }
+        // stash the key for pass 2 in the ord array's upper half? keys are recomputed instead (cheap, LDS-resident board)
+    }
+    __syncthreads();
+    // 2. exclusive popcount prefix over the key bitmap (<= 128 words)
+    int total = 0;
+    for (int base = 0; base < nwords; base += AZK_WAVE) {
+        int w = base + lane;
+        int p = w < nwords ? __popc(ms.bits[w]) : 0;
+        int incl = p;
+#pragma unroll
+        for (int off = 1; off < AZK_WAVE; off <<= 1) {
+            int t = __shfl_up(incl, off);
+            if (lane >= off) incl += t;
+        }
+        if (w < nwords) ms.pref[w] = (uint16_t)(total + incl - p);
+        total += __shfl(incl, AZK_WAVE - 1);
+    }
+    __syncthreads();
+    const int m = total;
+    if (m == 0) {                                                 // gomoku.py:103-104
+        if (lane == 0) moves[0] = (int16_t)((R / 2) * C + (C / 2));
+        __syncthreads();
+        return 1;
+    }
+    // 3. rank every candidate by its key -> first-insertion order
+    for (int e = lane; e < rc; e += AZK_WAVE) {
+        if (b[e] != 0) continue;
+        int r = e / C, c = e % C;
+        unsigned key = 0xffffffffu;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            int d = j >> 1, sg = (j & 1) ? -1 : 1;
+            int dr = (d > 0 ? 1 : 0) * sg;
+            int dc = (d == 0 ? 1 : (d == 1 ? 0 : (d == 2 ? 1 : -1))) * sg;
+            int sr = r - dr, sc = c - dc;
+            if (sr >= 0 && sr < R && sc >= 0 && sc < C && (b[sr * C + sc] & 3)) {
+                unsigned k = (unsigned)(sr * C + sc) * 8u + (unsigned)j;
+                key = k < key ? k : key;
+            }
+        }
+        if (key != 0xffffffffu) {
+            int rank = ms.pref[key >> 5] + __popc(ms.bits[key >> 5] & ((1u << (key & 31)) - 1u));
+            ms.ord[rank] = (int16_t)e;
+        }
+    }
+    for (int i = lane; i < ms.table_size; i += AZK_WAVE) ms.tabA[i] = 0;
+    __syncthreads();
+    // 4. replay the inserts into the emulated CPython set (set_add_entry + set_table_resize); serial by nature
+    uint16_t *tab = ms.tabA, *other = ms.tabB;
+    unsigned mask = 7;
+    if (lane == 0) {
+        int fill = 0;
+        for (int t = 0; t < m; t++) {
+            int cell = ms.ord[t];
+            unsigned long long h = ms.chash[cell];
+            py_set_insert_clean(tab, mask, (uint16_t)(cell + 1), h);   // keys are distinct: add == clean insert
+            fill++;
+            if ((unsigned)fill * 5u >= mask * 3u) {
+                unsigned newsize = 8, minused = (unsigned)fill * 4u;
+                while (newsize <= minused) newsize <<= 1;
+                for (unsigned i = 0; i < newsize; i++) other[i] = 0;
+                for (unsigned i = 0; i <= mask; i++) {
+                    uint16_t k = tab[i];
+                    if (k) py_set_insert_clean(other, newsize - 1, k, ms.chash[k - 1]);
+                }
+                uint16_t *tmp = tab; tab = other; other = tmp;
+                mask = newsize - 1;
+            }
+        }
+    }
+    __syncthreads();
+    mask = (unsigned)uniform_i32((int)mask);
+    bool useB = uniform_i32(tab == ms.tabB ? 1 : 0) != 0;
+    tab = useB ? ms.tabB : ms.tabA;
+    // 5. list(set): table order
+    for (unsigned base = 0; base <= mask; base += AZK_WAVE) {
+        unsigned i = base + lane;
+        uint16_t k = i <= mask ? tab[i] : (uint16_t)0;
+        unsigned long long bm = __ballot(k != 0);
+        if (k) moves[n + __popcll(bm & ((1ull << lane) - 1ull))] = (int16_t)(k - 1);
+        n += __popcll(bm);
+    }
+    __syncthreads();
+    return n;
+}
+
+// ---- deterministic float32 exp shared bit-for-bit with oracle/az_oracle.c (azo_exp_det) --------------
+__device__ __forceinline__ double azk_exp_det64(double x) {
+    const double LOG2E = 1.4426950408889634, LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
+    if (x > 700.0) return __builtin_huge_val();
+    if (x < -740.0) return 0.0;
+    double n = __builtin_rint(x * LOG2E);
+    double r = __builtin_fma(-n, LN2_HI, x);
+    r = __builtin_fma(-n, LN2_LO, r);
+    double p = 1.0 / 6227020800.0;
+    p = __builtin_fma(p, r, 1.0 / 479001600.0);
+    p = __builtin_fma(p, r, 1.0 / 39916800.0);
+    p = __builtin_fma(p, r, 1.0 / 3628800.0);
+    p = __builtin_fma(p, r, 1.0 / 362880.0);
+    p = __builtin_fma(p, r, 1.0 / 40320.0);
+    p = __builtin_fma(p, r, 1.0 / 5040.0);
+    p = __builtin_fma(p, r, 1.0 / 720.0);
+    p = __builtin_fma(p, r, 1.0 / 120.0);
+    p = __builtin_fma(p, r, 1.0 / 24.0);
+    p = __builtin_fma(p, r, 1.0 / 6.0);
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    int ni = (int)n, h = ni / 2;
+    double s1 = __longlong_as_double((long long)(1023 + h) << 52);
+    double s2 = __longlong_as_double((long long)(1023 + (ni - h)) << 52);
+    return p * s1 * s2;
+}
+
+__device__ __forceinline__ float azk_exp_det(float x) { return (float)azk_exp_det64((double)x); }
+
+// numpy's float32 pairwise summation (numpy/core/src/umath/loops_utils.h.src), n <= 512.
+// a[] in LDS, racc = 32 floats of LDS scratch.  All lanes call; returns the sum on every lane.
+// Recursion: n <= 128 -> one 8-accumulator block; else split at n2 = n/2 - (n/2)%8 and recurse.
+__device__ __forceinline__ float azk_pw_block(const float *p, int len, const float *r) {
+    // finish one leaf block on a single lane: r[0..7] are the strided accumulators
+    float s;
+    if (len < 8) {
+        s = 0.f;
+        for (int i = 0; i < len; i++) s += p[i];
+    } else {
+        s = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (int i = len - (len % 8); i < len; i++) s += p[i];
+    }
+    return s;
+}
+
+__device__ float azk_pairwise_sum(const float *a, int n, float *racc) {
+    const int lane = azk_lane();
+    // leaf blocks (start, len); a block with len 0 does not exist
+    int s0 = 0, l0 = n, s1 = 0, l1 = 0, s2 = 0, l2 = 0, s3 = 0, l3 = 0;
+    if (n > 128) {
+        int n2 = n / 2; n2 -= n2 % 8;
+        int ls = 0, ll = n2, rs = n2, rl = n - n2;               // left / right halves
+        s0 = ls; l0 = ll; s2 = rs; l2 = rl;
+        if (ll > 128) { int h = ll / 2; h -= h % 8; l0 = h; s1 = ls + h; l1 = ll - h; }
+        if (rl > 128) { int h = rl / 2; h -= h % 8; l2 = h; s3 = rs + h; l3 = rl - h; }
+    }
+    int q = lane >> 3, j = lane & 7;
+    int ms = q == 0 ? s0 : (q == 1 ? s1 : (q == 2 ? s2 : s3));
+    int ml = q == 0 ? l0 : (q == 1 ? l1 : (q == 2 ? l2 : (q == 3 ? l3 : 0)));
+    if (ml >= 8) {
+        const float *p = a + ms;
+        float r = p[j];
+        int lim = ml - (ml % 8);
+        for (int i = 8; i < lim; i += 8) r += p[i + j];
+        racc[lane] = r;
+    }
+    __syncthreads();
+    if (lane == 0) {
+        float left = azk_pw_block(a + s0, l0, racc);
+        if (l1 > 0) left = left + azk_pw_block(a + s1, l1, racc + 8);
+        float res = left;
+        if (l2 > 0) {
+            float right = azk_pw_block(a + s2, l2, racc + 16);
+            if (l3 > 0) right = right + azk_pw_block(a + s3, l3, racc + 24);
+            res = left + right;
+        }
+        racc[0] = res;
+    }
+    __syncthreads();
+    float res = racc[0];
+    __syncthreads();
+    return res;
+}

@@ -1,0 +1,989 @@
+// azk_engine.hip - batched self-play engine for MI355X (gfx950): tree + board-rule kernels and the C ABI
+// declared in include/azk.h.  One 64-lane wavefront (one 64-thread workgroup) owns one game; the tree is
+// a structure-of-arrays arena in HBM whose child blocks are contiguous, so a PUCT scan is a coalesced read
+// of the N / W / P columns; per-wave scratch (board, path, move list, emulated CPython set) lives in LDS.
+// Built with -ffp-contract=off: every float result is the same sequence of IEEE operations the oracle runs.
+// Reference lines cited as file:line relative to the reference root.
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "azk.h"
+#include "azk_device.h"
+
+namespace {
+
+enum { CNT_SIMS = 0, CNT_SCANNED, CNT_TRACE, CNT_CREATED, CNT_LEAVES, CNT_TERMINAL, CNT_MOVES, CNT_N };
+
+struct Dev {               // device view of the engine, passed to kernels by value
+    GameDesc g;
+    int G, cap, path_cap, rc_pad, leaf_dtype, table_size, lds_bytes;
+    // game state
+    uint8_t *cells;        // [G][rc_pad]  cell codes (1 = player 0, 2 = player 1)
+    int *to_move, *move_count, *done, *winner;   // [G]
+    // tree arena, [G][cap] each (ai/node.py:21-40 as columns)
+    int *N;                // Node.visit
+    double *W;             // Node.value (running sum)
+    float *P;              // Node.prior (float32 softmax entries)
+    int16_t *cell;         // Node.prevAction as r*cols+c
+    int *first_child;      // index of children[0] in this game's arena, -1 = not expanded
+    int16_t *n_children;
+    double *rootP;         // [G][rc] float64 root priors after Dirichlet mixing (utils.py:24-25), by child position
+    int *root_f64;         // [G] root children use rootP (float64 UCB) instead of P (float32 UCB)
+    int *arena_top;        // [G] bump allocator
+    // pending leaf of the current simulation
+    int *leaf_node, *leaf_depth, *leaf_nmoves, *leaf_slot;   // [G]
+    int *path;             // [G][path_cap]
+    uint8_t *leaf_cells;   // [G][rc_pad] board at the leaf
+    int16_t *leaf_moves;   // [G][rc] valid moves at the leaf, reference list order
+    uint8_t *leaf_flag;    // [G] 1 = this game contributes a leaf to the evaluator batch this step
+    const double *noise;   // [G][A] or nullptr
+    long long *counters;   // [CNT_N][G]
+    int *err;              // sticky error word
+};
+
+struct LdsView {
+    uint8_t *board;
+    int *path;
+    int16_t *moves;
+    float *e;
+    float *racc;
+    int *cnt;
+    double *cdf;
+    MoveScratch ms;
+};
+
+__host__ __device__ inline int up16(int x) { return (x + 15) & ~15; }
+
+__host__ __device__ inline int lds_layout(const GameDesc &g, int path_cap, int table_size, int *off) {
+    // offsets (bytes) of: board, path, moves, e, racc, cnt, cdf, bits, pref, ord, chash, tabA, tabB
+    int o = 0;
+    off[0] = o; o += up16(g.rc);
+    off[1] = o; o += up16(path_cap * 4);
+    off[2] = o; o += up16(g.rc * 2);
+    int ea = g.action_dim > g.rc ? g.action_dim : g.rc;
+    off[3] = o; o += up16(ea * 4);
+    off[4] = o; o += 128;
+    off[5] = o; o += up16(ea * 4);
+    off[6] = o; o += up16(ea * 8);
+    int nwords = (g.rc * 8 + 31) >> 5;
+    off[7] = o; o += up16(nwords * 4);
+    off[8] = o; o += up16(nwords * 2);
+    off[9] = o; o += up16(g.rc * 2);
+    off[10] = o; o += up16(g.rc * 8);
+    off[11] = o; o += up16(table_size * 2);
+    off[12] = o; o += up16(table_size * 2);
+    return o;
+}
+
+extern __shared__ __attribute__((aligned(16))) unsigned char azk_smem[];
+
+__device__ __forceinline__ LdsView carve(const GameDesc &g, int path_cap, int table_size) {
+    int off[13];
+    lds_layout(g, path_cap, table_size, off);
+    LdsView L;
+    L.board = azk_smem + off[0];
+    L.path = (int *)(azk_smem + off[1]);
+    L.moves = (int16_t *)(azk_smem + off[2]);
+    L.e = (float *)(azk_smem + off[3]);
+    L.racc = (float *)(azk_smem + off[4]);
+    L.cnt = (int *)(azk_smem + off[5]);
+    L.cdf = (double *)(azk_smem + off[6]);
+    L.ms.bits = (uint32_t *)(azk_smem + off[7]);
+    L.ms.pref = (uint16_t *)(azk_smem + off[8]);
+    L.ms.ord = (int16_t *)(azk_smem + off[9]);
+    L.ms.chash = (unsigned long long *)(azk_smem + off[10]);
+    L.ms.tabA = (uint16_t *)(azk_smem + off[11]);
+    L.ms.tabB = (uint16_t *)(azk_smem + off[12]);
+    L.ms.table_size = table_size;
+    return L;
+}
+
+// Node.backup (node.py:62-74): the node at trace index i gets value * (-1)^(depth - i); lanes take one node each.
+__device__ __forceinline__ void backup_path(const Dev &d, size_t base, const int *path, int depth, double value) {
+    for (int i = azk_lane(); i <= depth; i += AZK_WAVE) {
+        int nd = path[i];
+        double sv = ((depth - i) & 1) ? -value : value;
+        d.N[base + nd] += 1;
+        d.W[base + nd] += sv;
+    }
+}
+
+// ================================================================================================
+// k_tree<EXPAND, SELECT>: one simulation step for every game.
+//   EXPAND: mcts.py:46-60 for the leaf selected by the previous step (softmax, noise, expand, backup)
+//   SELECT: mcts.py:18-37 (PUCT walk, terminal test + backup, valid moves, leaf hand-off)
+// ================================================================================================
+template <bool EXPAND, bool SELECT>
+__global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev d, const float *__restrict__ logits, const float *__restrict__ values) {
+    const int g = blockIdx.x;
+    const int lane = azk_lane();
+    const GameDesc &gd = d.g;
+    const int A = gd.action_dim, rc = gd.rc;
+    const size_t base = (size_t)g * (size_t)d.cap;
+    LdsView L = carve(gd, d.path_cap, d.table_size);
+
+    if (EXPAND) {
+        const int node = uniform_i32(d.leaf_node[g]);
+        if (node >= 0) {
+            const int slot = uniform_i32(d.leaf_slot[g]);
+            const int depth = uniform_i32(d.leaf_depth[g]);
+            const int nv = uniform_i32(d.leaf_nmoves[g]);
+            const float *lg = logits + (size_t)slot * A;
+            // float32 softmax, no max subtraction (mcts.py:48-49)
+            for (int i = lane; i < A; i += AZK_WAVE) L.e[i] = azk_exp_det(lg[i]);
+            __syncthreads();
+            const float s = azk_pairwise_sum(L.e, A, L.racc);
+            const int fc = uniform_i32(d.arena_top[g]);
+            const bool fits = fc + nv <= d.cap;
+            const bool mix = depth == 0 && d.noise != nullptr;        // mcts.py:42-43,52-53
+            if (fits) {
+                for (int i = lane; i < nv; i += AZK_WAVE) {           // Node.expand (node.py:50-59)
+                    const int cell = d.leaf_moves[(size_t)g * rc + i];
+                    const int a = azk_action_idx(gd, cell);
+                    const float p = L.e[a] / s;
+                    const size_t idx = base + fc + i;
+                    d.N[idx] = 0; d.W[idx] = 0.0; d.P[idx] = p; d.cell[idx] = (int16_t)cell;
+                    d.first_child[idx] = -1; d.n_children[idx] = 0;
+                    if (mix) d.rootP[(size_t)g * rc + i] = (double)(0.75f * p) + 0.25 * d.noise[(size_t)g * A + a];  // utils.py:24-25
+                }
+                if (lane == 0) {
+                    d.first_child[base + node] = fc; d.n_children[base + node] = (int16_t)nv;
+                    d.arena_top[g] = fc + nv;
+                    if (depth == 0) d.root_f64[g] = mix ? 1 : 0;
+                    d.counters[(size_t)CNT_CREATED * d.G + g] += nv;
+                }
+            } else if (lane == 0) {
+                atomicExch(d.err, AZK_ERR_ARENA_FULL);
+            }
+            const double v = -(double)values[slot];                  // mcts.py:56
+            backup_path(d, base, d.path + (size_t)g * d.path_cap, depth, v);
+            if (lane == 0) {
+                d.leaf_node[g] = -1;
+                d.counters[(size_t)CNT_TRACE * d.G + g] += depth + 1;
+            }
+        }
+        __syncthreads();   // this wave's tree writes are visible to its own SELECT reads below
+    }
+
+    if (SELECT) {
+        const bool active = uniform_i32(d.done[g]) == 0;
+        if (!active) {
+            if (lane == 0) d.leaf_flag[g] = 0;
+            return;
+        }
+        for (int i = lane; i < rc; i += AZK_WAVE) L.board[i] = d.cells[(size_t)g * d.rc_pad + i];
+        const int root_player = uniform_i32(d.to_move[g]);
+        const int root_mc = uniform_i32(d.move_count[g]);
+        if (lane == 0) L.path[0] = 0;
+        __syncthreads();
+        int node = 0, depth = 0, scanned = 0;
+        for (;;) {                                                    // mcts.py:20-23
+            const int nch = uniform_i32((int)d.n_children[base + node]);
+            if (nch <= 0) break;
+            const int fc = uniform_i32(d.first_child[base + node]);
+            const int Np = uniform_i32(d.N[base + node]);
+            const bool f64 = node == 0 && uniform_i32(d.root_f64[g]) != 0;
+            int best = 0x7fffffff;
+            if (f64) {                                                // float64 priors => float64 UCB
+                const double s = sqrt((double)Np);
+                double bu = 0.0;
+                for (int i = lane; i < nch; i += AZK_WAVE) {
+                    const int Nc = d.N[base + fc + i];
+                    const double Wc = d.W[base + fc + i];
+                    const double Pc = d.rootP[(size_t)g * rc + i];
+                    double u = Pc * s / (double)(Nc + 1);
+                    if (Nc != 0) u = Wc / (double)Nc + u;
+                    if (best == 0x7fffffff || u > bu) { bu = u; best = i; }
+                }
+                wave_argmax_first<double>(bu, best);
+            } else {                                                  // float32 priors => float32 UCB (numpy>=2)
+                const float s = (float)sqrt((double)Np);
+                float bu = 0.f;
+                for (int i = lane; i < nch; i += AZK_WAVE) {
+                    const int Nc = d.N[base + fc + i];
+                    const double Wc = d.W[base + fc + i];
+                    const float Pc = d.P[base + fc + i];
+                    float u = (Pc * s) / (float)(Nc + 1);
+                    if (Nc != 0) u = (float)(Wc / (double)Nc) + u;
+                    if (best == 0x7fffffff || u > bu) { bu = u; best = i; }
+                }
+                wave_argmax_first<float>(bu, best);
+            }
+            best = uniform_i32(best);
+            scanned += nch;
+            const int child = fc + best;
+            const int cellc = uniform_i32((int)d.cell[base + child]);
+            const int mover = (root_player + depth) & 1;
+            depth++;
+            node = child;
+            if (lane == 0) {
+                L.path[depth] = node;
+                // make_move (gomoku.py:51-58 / tictactoe.py:37-45 test emptiness; connect4.py:56-63 does not)
+                if (gd.kind == AZK_KIND_C4) L.board[cellc] |= (uint8_t)(1 << mover);
+                else if (L.board[cellc] == 0) L.board[cellc] = (uint8_t)(1 << mover);
+            }
+            if (depth + 1 >= d.path_cap) break;
+        }
+        __syncthreads();
+        const int node_player = (root_player + depth) & 1;
+        const int node_mc = root_mc + depth;
+        int term = -1;
+        if (depth > 0) {                                              // mcts.py:25-32 (root is never tested)
+            const int cellc = uniform_i32((int)d.cell[base + node]);
+            const int w = azk_check_winner(L.board, gd, 1 - node_player, cellc);
+            if (w != -1) term = 1;
+            else if (node_mc == gd.state_dim) term = 0;
+        }
+        if (lane == 0) {
+            d.counters[(size_t)CNT_SIMS * d.G + g] += 1;
+            d.counters[(size_t)CNT_SCANNED * d.G + g] += scanned;
+        }
+        if (term >= 0) {
+            backup_path(d, base, L.path, depth, (double)term);
+            if (lane == 0) {
+                d.leaf_flag[g] = 0;
+                d.counters[(size_t)CNT_TERMINAL * d.G + g] += 1;
+                d.counters[(size_t)CNT_TRACE * d.G + g] += depth + 1;
+            }
+            return;
+        }
+        const int nv = azk_valid_moves(L.board, gd, L.moves, L.ms);  // mcts.py:34
+        for (int i = lane; i < nv; i += AZK_WAVE) d.leaf_moves[(size_t)g * rc + i] = L.moves[i];
+        for (int i = lane; i < rc; i += AZK_WAVE) d.leaf_cells[(size_t)g * d.rc_pad + i] = L.board[i];
+        for (int i = lane; i <= depth; i += AZK_WAVE) d.path[(size_t)g * d.path_cap + i] = L.path[i];
+        if (lane == 0) {
+            d.leaf_node[g] = node; d.leaf_depth[g] = depth; d.leaf_nmoves[g] = nv;
+            d.leaf_flag[g] = 1;
+            d.counters[(size_t)CNT_LEAVES * d.G + g] += 1;
+        }
+    }
+}
+
+// Leaf compaction: slot = number of leaf games with a lower index (deterministic order); writes the
+// canonical board (gomoku.py:34-40; 3-plane: mcts.py:126-137) of each leaf into the evaluator batch.
+__global__ __launch_bounds__(AZK_WAVE) void k_gather(Dev d, void *__restrict__ leaf_boards, int *__restrict__ n_leaf_out) {
+    const int g = blockIdx.x, lane = azk_lane();
+    // prefix over byte flags, 8 flags per lane per load (leaf_flag is padded to a multiple of 512 bytes)
+    int before = 0, total = 0;
+    const unsigned long long *fw = (const unsigned long long *)d.leaf_flag;
+    const int nw = (d.G + 7) >> 3;
+    const bool last = g == d.G - 1;
+    const int limit_words = last ? nw : ((g + 8) >> 3);
+    for (int w0 = 0; w0 < limit_words; w0 += AZK_WAVE) {
+        int w = w0 + lane;
+        unsigned long long x = w < nw ? fw[w] : 0ull;
+        total += __popcll(x);
+        // flags strictly before game g
+        int lo = w * 8;
+        if (lo + 8 <= g) before += __popcll(x);
+        else if (lo < g) before += __popcll(x & ((1ull << ((g - lo) * 8)) - 1ull));
+    }
+    before = wave_sum_i32(before);
+    if (last) {
+        total = wave_sum_i32(total);
+        if (lane == 0) *n_leaf_out = total;
+    }
+    if (!d.leaf_flag[g]) return;
+    const int slot = before;
+    if (lane == 0) d.leaf_slot[g] = slot;
+    const int rc = d.g.rc, F = d.g.planes;
+    const int player = (d.to_move[g] + d.leaf_depth[g]) & 1;          // node.currentPlayer
+    const uint8_t *b = d.leaf_cells + (size_t)g * d.rc_pad;
+    const size_t o = (size_t)slot * F * rc;
+    for (int i = lane; i < F * rc; i += AZK_WAVE) {
+        const int plane = i / rc, c = i - plane * rc;
+        float v;
+        if (plane == 2) v = (float)player;                            // side-to-move plane (tictactoe.py:41)
+        else v = (float)((b[c] >> (plane ^ player)) & 1);             // own stones first for player 1
+        if (d.leaf_dtype == AZK_LEAF_BF16) ((__hip_bfloat16 *)leaf_boards)[o + i] = __float2bfloat16(v);
+        else ((float *)leaf_boards)[o + i] = v;
+    }
+}
+
+// Node(None, None, current_player, move_count) for every game (gomoku.py:134)
+__global__ void k_begin_search(Dev d) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= d.G) return;
+    const size_t base = (size_t)g * d.cap;
+    d.N[base] = 0; d.W[base] = 0.0; d.P[base] = 0.f; d.cell[base] = -1;
+    d.first_child[base] = -1; d.n_children[base] = 0;
+    d.arena_top[g] = 1; d.leaf_node[g] = -1; d.root_f64[g] = 0; d.leaf_flag[g] = 0;
+}
+
+__global__ void k_reset_games(Dev d, int first, int count) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count * d.rc_pad) return;
+    const int g = first + t / d.rc_pad, i = t % d.rc_pad;
+    d.cells[(size_t)g * d.rc_pad + i] = 0;
+    if (i == 0) { d.to_move[g] = 0; d.move_count[g] = 0; d.done[g] = 0; d.winner[g] = -2; d.leaf_node[g] = -1; d.leaf_flag[g] = 0; }
+}
+
+// utils.get_probablity_distribution_of_children (utils.py:46-55), root.value / root.visit (gomoku.py:140)
+__global__ __launch_bounds__(AZK_WAVE) void k_root_stats(Dev d, double *pi, double *q, int *root_visit) {
+    const int g = blockIdx.x, lane = azk_lane();
+    const size_t base = (size_t)g * d.cap;
+    const int A = d.g.action_dim;
+    LdsView L = carve(d.g, d.path_cap, d.table_size);
+    const int fc = d.first_child[base], nch = d.n_children[base];
+    for (int a = lane; a < A; a += AZK_WAVE) L.cnt[a] = 0;
+    __syncthreads();
+    int sum = 0;
+    for (int i = lane; i < nch; i += AZK_WAVE) {
+        const int n = d.N[base + fc + i];
+        L.cnt[azk_action_idx(d.g, d.cell[base + fc + i])] = n;
+        sum += n;
+    }
+    sum = wave_sum_i32(sum);
+    __syncthreads();
+    if (pi) for (int a = lane; a < A; a += AZK_WAVE) pi[(size_t)g * A + a] = (double)L.cnt[a] / (double)sum;
+    if (lane == 0) {
+        if (q) q[g] = d.W[base] / (double)d.N[base];
+        if (root_visit) root_visit[g] = d.N[base];
+    }
+}
+
+// gomoku.py:143-162: choose (sample ~ visits | first max-visit child), make_move, check_winner, draw
+__global__ __launch_bounds__(AZK_WAVE) void k_advance(Dev d, const double *uniforms, int sample_until,
+                                                       int *chosen, int *winner_out, int *done_out) {
+    const int g = blockIdx.x, lane = azk_lane();
+    const GameDesc &gd = d.g;
+    const size_t base = (size_t)g * d.cap;
+    const int A = gd.action_dim, rc = gd.rc;
+    LdsView L = carve(gd, d.path_cap, d.table_size);
+    if (uniform_i32(d.done[g]) != 0) {
+        if (lane == 0) {
+            if (chosen) chosen[g] = -1;
+            if (winner_out) winner_out[g] = d.winner[g];
+            if (done_out) done_out[g] = 1;
+        }
+        return;
+    }
+    const int fc = uniform_i32(d.first_child[base]), nch = uniform_i32((int)d.n_children[base]);
+    const int mc = uniform_i32(d.move_count[g]), mover = uniform_i32(d.to_move[g]);
+    for (int i = lane; i < rc; i += AZK_WAVE) L.board[i] = d.cells[(size_t)g * d.rc_pad + i];
+    for (int a = lane; a < A; a += AZK_WAVE) L.cnt[a] = 0;
+    __syncthreads();
+    int sum = 0;
+    for (int i = lane; i < nch; i += AZK_WAVE) {
+        const int n = d.N[base + fc + i];
+        L.cnt[azk_action_idx(gd, d.cell[base + fc + i])] = n;
+        sum += n;
+    }
+    sum = wave_sum_i32(sum);
+    __syncthreads();
+    int cellc = -1;
+    if (nch <= 0 || sum <= 0) {
+        if (lane == 0) atomicExch(d.err, AZK_ERR_STATE);
+        return;
+    }
+    if (uniforms != nullptr && mc < sample_until) {
+        // Node.sample_child (node.py:83-93) -> legacy np.random.choice(p=pi): cdf = cumsum(pi); cdf /= cdf[-1];
+        // index = searchsorted(cdf, u, side='right').  cumsum is sequential in float64.
+        if (lane == 0) {
+            double acc = 0.0;
+            for (int a = 0; a < A; a++) { acc += (double)L.cnt[a] / (double)sum; L.cdf[a] = acc; }
+            const double lastv = L.cdf[A - 1], u = uniforms[g];
+            int lo = 0, hi = A;
+            while (lo < hi) { int mid = (lo + hi) >> 1; if (u < L.cdf[mid] / lastv) hi = mid; else lo = mid + 1; }
+            L.cnt[0] = lo < A ? lo : A - 1;                          // action drawn
+        }
+        __syncthreads();
+        const int act = L.cnt[0];
+        int found = 0x7fffffff;
+        for (int i = lane; i < nch; i += AZK_WAVE)
+            if (azk_action_idx(gd, d.cell[base + fc + i]) == act && i < found) found = i;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { int o = __shfl_xor(found, off); found = o < found ? o : found; }
+        cellc = found != 0x7fffffff ? (int)d.cell[base + fc + found] : -1;
+    } else {
+        // Node.max_visit_child (node.py:76-81): first child with the most visits
+        int best = 0x7fffffff, bn = 0;
+        for (int i = lane; i < nch; i += AZK_WAVE) {
+            const int n = d.N[base + fc + i];
+            if (best == 0x7fffffff || n > bn) { bn = n; best = i; }
+        }
+        wave_argmax_first<int>(bn, best);
+        cellc = (int)d.cell[base + fc + uniform_i32(best)];
+    }
+    cellc = uniform_i32(cellc);
+    if (cellc < 0) {
+        if (lane == 0) atomicExch(d.err, AZK_ERR_STATE);
+        return;
+    }
+    if (lane == 0) {
+        if (gd.kind == AZK_KIND_C4) L.board[cellc] |= (uint8_t)(1 << mover);
+        else if (L.board[cellc] == 0) L.board[cellc] = (uint8_t)(1 << mover);
+    }
+    __syncthreads();
+    const int w = azk_check_winner(L.board, gd, mover, cellc);      // gomoku.py:150
+    if (lane == 0) {
+        d.cells[(size_t)g * d.rc_pad + cellc] = L.board[cellc];
+        d.to_move[g] = 1 - mover;
+        d.move_count[g] = mc + 1;
+        int win = -2, dn = 0;
+        if (w != -1) { win = w; dn = 1; }
+        else if (mc + 1 == gd.state_dim) { win = -1; dn = 1; }
+        d.winner[g] = win; d.done[g] = dn;
+        if (chosen) chosen[g] = cellc;
+        if (winner_out) winner_out[g] = win;
+        if (done_out) done_out[g] = dn;
+        d.counters[(size_t)CNT_MOVES * d.G + g] += 1;
+    }
+}
+
+__global__ void k_sum_counters(const long long *counters, int G, long long *out) {
+    // one block per counter
+    __shared__ long long sm[256];
+    long long s = 0;
+    for (int i = threadIdx.x; i < G; i += blockDim.x) s += counters[(size_t)blockIdx.x * G + i];
+    sm[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) out[blockIdx.x] = sm[0];
+}
+
+// ------------------------------------------------------------------------------------------------
+// Counter-based RNG for the product path: Philox4x32-10 keyed by (seed), counter = (game, move, lane idx, draw).
+// Dirichlet(alpha) via Gamma(alpha) = Gamma(alpha + 1) * U^(1/alpha) (Marsaglia-Tsang for the shape > 1 part).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c[0];
+        const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c[2];
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+
+__device__ __forceinline__ double u53(uint32_t hi, uint32_t lo) {     // uniform in (0, 1)
+    const unsigned long long x = (((unsigned long long)hi << 32) | lo) >> 11;
+    return ((double)x + 0.5) * (1.0 / 9007199254740992.0);
+}
+
+__global__ __launch_bounds__(AZK_WAVE) void k_gen_noise(int A, unsigned long long seed, long long first_game, int move,
+                                                         double alpha, double *noise, double *uniforms) {
+    const int g = blockIdx.x, lane = azk_lane();
+    const unsigned long long gg = (unsigned long long)(first_game + g);
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    __shared__ double red[AZK_WAVE];
+    if (uniforms && lane == 0) {
+        uint32_t c[4] = {(uint32_t)gg, (uint32_t)(gg >> 32), (uint32_t)move, 0xFFFFFFFFu};
+        philox4x32_10(c, k0, k1);
+        double u = (double)((((unsigned long long)c[0] << 32) | c[1]) >> 11) * (1.0 / 9007199254740992.0);   // [0,1)
+        uniforms[g] = u;
+    }
+    if (!noise) return;
+    double part = 0.0;
+    for (int a = lane; a < A; a += AZK_WAVE) {
+        const double d = alpha + 1.0 - 1.0 / 3.0, cc = 1.0 / sqrt(9.0 * d);
+        double gam = 0.0;
+        for (uint32_t it = 0; it < 64; it++) {
+            uint32_t c[4] = {(uint32_t)gg, (uint32_t)(gg >> 32) ^ ((uint32_t)a << 8), (uint32_t)move, it};
+            philox4x32_10(c, k0, k1);
+            uint32_t c2[4] = {(uint32_t)gg, (uint32_t)(gg >> 32) ^ ((uint32_t)a << 8), (uint32_t)move, it | 0x40000000u};
+            philox4x32_10(c2, k0, k1);
+            const double u1 = u53(c[0], c[1]), u2 = u53(c[2], c[3]), u3 = u53(c2[0], c2[1]), u4 = u53(c2[2], c2[3]);
+            const double x = sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
+            const double t = 1.0 + cc * x;
+            if (t <= 0.0) continue;
+            const double v = t * t * t;
+            if (log(u3) < 0.5 * x * x + d - d * v + d * log(v)) { gam = d * v * pow(u4, 1.0 / alpha); break; }
+        }
+        noise[(size_t)g * A + a] = gam;
+        part += gam;
+    }
+    red[lane] = part;
+    __syncthreads();
+    for (int o = 32; o > 0; o >>= 1) { if (lane < o) red[lane] += red[lane + o]; __syncthreads(); }
+    const double tot = red[0];
+    for (int a = lane; a < A; a += AZK_WAVE) {
+        const size_t i = (size_t)g * A + a;
+        noise[i] = tot > 0.0 ? noise[i] / tot : 1.0 / (double)A;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// stateless rule kernels over float32 boards [n][F][R][C] (the reference's own board layout)
+// ------------------------------------------------------------------------------------------------
+enum { RULE_MOVES = 0, RULE_MASK, RULE_APPLY, RULE_UNDO, RULE_WINNER, RULE_CANON };
+
+struct RuleArgs {
+    GameDesc g;
+    int mode, n, table_size;
+    const float *boards_in; float *boards;
+    const int *players; const int *cells;
+    int16_t *moves; int *counts; uint8_t *mask; int *out_i; float *out_f;
+};
+
+__device__ __forceinline__ uint8_t code_of(float p0, float p1) {
+    uint8_t c = (p0 == 1.0f ? 1 : 0) | (p1 == 1.0f ? 2 : 0);
+    if ((p0 != 0.0f && p0 != 1.0f) || (p1 != 0.0f && p1 != 1.0f)) c |= 4;
+    return c;
+}
+
+__global__ __launch_bounds__(AZK_WAVE) void k_rules(RuleArgs a) {
+    const int b = blockIdx.x, lane = azk_lane();
+    const GameDesc &g = a.g;
+    const int rc = g.rc, F = g.planes;
+    LdsView L = carve(g, 4, a.table_size);
+    const float *src = (a.boards_in ? a.boards_in : a.boards) + (size_t)b * F * rc;
+    for (int i = lane; i < rc; i += AZK_WAVE) L.board[i] = code_of(src[i], src[rc + i]);
+    __syncthreads();
+    if (a.mode == RULE_MOVES || a.mode == RULE_MASK) {
+        const int n = azk_valid_moves(L.board, g, L.moves, L.ms);
+        if (a.mode == RULE_MOVES) {
+            for (int i = lane; i < n; i += AZK_WAVE) a.moves[(size_t)b * rc + i] = L.moves[i];
+            if (lane == 0) a.counts[b] = n;
+        } else {
+            for (int i = lane; i < g.action_dim; i += AZK_WAVE) a.mask[(size_t)b * g.action_dim + i] = 0;
+            __syncthreads();
+            for (int i = lane; i < n; i += AZK_WAVE) a.mask[(size_t)b * g.action_dim + azk_action_idx(g, L.moves[i])] = 1;
+        }
+    } else if (a.mode == RULE_APPLY) {
+        const int player = a.players[b], cell = a.cells[b];
+        float *dst = a.boards + (size_t)b * F * rc;
+        int next = player;
+        if (g.kind == AZK_KIND_C4 || L.board[cell] == 0) {
+            next = 1 - player;
+            if (lane == 0) dst[(size_t)player * rc + cell] = 1.0f;
+            if (F == 3) for (int i = lane; i < rc; i += AZK_WAVE) dst[2 * rc + i] = (float)(1 - player);
+        }
+        if (lane == 0) a.out_i[b] = next;
+    } else if (a.mode == RULE_UNDO) {
+        const int cur = a.players[b], cell = a.cells[b];
+        float *dst = a.boards + (size_t)b * F * rc;
+        if (lane == 0) dst[(size_t)(1 - cur) * rc + cell] = 0.0f;
+        if (F == 3) for (int i = lane; i < rc; i += AZK_WAVE) dst[2 * rc + i] = (float)(1 - cur);
+    } else if (a.mode == RULE_WINNER) {
+        const int w = azk_check_winner(L.board, g, a.players[b], a.cells[b]);
+        if (lane == 0) a.out_i[b] = w;
+    } else if (a.mode == RULE_CANON) {
+        const int player = a.players[b];
+        float *dst = a.out_f + (size_t)b * F * rc;
+        for (int i = lane; i < F * rc; i += AZK_WAVE) {
+            const int plane = i / rc, c = i - plane * rc;
+            const int sp = plane < 2 ? (plane ^ player) : plane;
+            dst[i] = src[(size_t)sp * rc + c];
+        }
+    }
+}
+
+__global__ __launch_bounds__(AZK_WAVE) void k_softmax_rows(const float *logits, int A, float *out) {
+    const int b = blockIdx.x, lane = azk_lane();
+    float *e = (float *)azk_smem;
+    float *racc = e + ((A + 31) & ~31);
+    for (int i = lane; i < A; i += AZK_WAVE) e[i] = azk_exp_det(logits[(size_t)b * A + i]);
+    __syncthreads();
+    const float s = azk_pairwise_sum(e, A, racc);
+    for (int i = lane; i < A; i += AZK_WAVE) out[(size_t)b * A + i] = e[i] / s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+thread_local std::string g_create_error;
+
+bool make_game(int kind, int rows, int cols, GameDesc *g, std::string *err) {
+    memset(g, 0, sizeof *g);
+    g->kind = kind;
+    if (kind == AZK_TICTACTOE) { rows = 3; cols = 3; g->planes = 3; g->win_len = 3; g->action_dim = 9; }
+    else if (kind == AZK_CONNECT4) { rows = 6; cols = 7; g->planes = 3; g->win_len = 4; g->action_dim = 7; }
+    else if (kind == AZK_GOMOKU) {
+        if (rows < 1 || cols < 1 || rows * cols > 400) { *err = "gomoku board must have 1..400 cells"; return false; }
+        g->planes = 2; g->win_len = 5; g->action_dim = rows * cols;
+    } else { *err = "unknown game id"; return false; }
+    g->rows = rows; g->cols = cols; g->rc = rows * cols; g->state_dim = rows * cols;
+    return true;
+}
+
+int table_size_for(const GameDesc &g) { return g.rc < 307 ? 512 : 2048; }   // CPython set growth: 8 -> 32 -> 128 -> 512 -> 2048
+
+}  // namespace
+
+struct azk_engine {
+    Dev d;
+    azk_config cfg;
+    std::string err;
+    std::vector<void *> allocs;
+    long long *counter_sums = nullptr;   // device [CNT_N]
+    int *n_leaf_scratch = nullptr;
+    void *leaf_scratch = nullptr;        // used when the caller passes no leaf buffer
+};
+
+#define HIPCHK(e, call)                                                                 \
+    do {                                                                                \
+        hipError_t _s = (call);                                                         \
+        if (_s != hipSuccess) {                                                         \
+            (e)->err = std::string(#call) + ": " + hipGetErrorString(_s);              \
+            return AZK_ERR_HIP;                                                         \
+        }                                                                               \
+    } while (0)
+
+template <typename T>
+static hipError_t dalloc(azk_engine *e, T **p, size_t count) {
+    void *q = nullptr;
+    hipError_t s = hipMalloc(&q, count * sizeof(T) + 64);
+    if (s != hipSuccess) return s;
+    e->allocs.push_back(q);
+    *p = (T *)q;
+    return hipSuccess;
+}
+
+extern "C" {
+
+int32_t azk_abi_version(void) { return AZK_ABI_VERSION; }
+
+const char *azk_last_error(const azk_engine *e) { return e ? e->err.c_str() : g_create_error.c_str(); }
+
+int32_t azk_create(const azk_config *cfg, azk_engine **out) {
+    if (!cfg || !out) { g_create_error = "null argument"; return AZK_ERR_ARG; }
+    *out = nullptr;
+    azk_engine *e = new azk_engine();
+    e->cfg = *cfg;
+    Dev &d = e->d;
+    memset(&d, 0, sizeof d);
+    auto fail = [&](int code, const std::string &msg) { g_create_error = msg; azk_destroy(e); return code; };
+    std::string gerr;
+    if (!make_game(cfg->game, cfg->rows, cfg->cols, &d.g, &gerr)) return fail(AZK_ERR_ARG, gerr);
+    if (cfg->n_games < 1 || cfg->max_sims < 1) return fail(AZK_ERR_ARG, "n_games and max_sims must be >= 1");
+    if (cfg->leaf_dtype != AZK_LEAF_F32 && cfg->leaf_dtype != AZK_LEAF_BF16) return fail(AZK_ERR_ARG, "bad leaf_dtype");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(AZK_ERR_HIP, "no HIP device visible: libazk needs an MI355X (there is no CPU fallback)");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(AZK_ERR_ARG, "bad device ordinal");
+    if (hipSetDevice(cfg->device) != hipSuccess) return fail(AZK_ERR_HIP, "hipSetDevice failed");
+    const GameDesc &g = d.g;
+    const int maxch = g.kind == AZK_CONNECT4 ? g.cols : g.rc;
+    long long cap = cfg->arena_nodes > 0 ? cfg->arena_nodes : 1 + (long long)cfg->max_sims * maxch;
+    if (cap > 0x7ffffff0LL) return fail(AZK_ERR_ARG, "arena too large");
+    d.G = cfg->n_games; d.cap = (int)cap; d.path_cap = g.state_dim + 2; d.rc_pad = up16(g.rc);
+    d.leaf_dtype = cfg->leaf_dtype; d.table_size = table_size_for(g);
+    int off[13];
+    d.lds_bytes = lds_layout(g, d.path_cap, d.table_size, off);
+    const size_t G = d.G, nodes = G * (size_t)d.cap;
+    hipError_t s = hipSuccess;
+#define DA(ptr, count) if (s == hipSuccess) s = dalloc(e, &ptr, (count))
+    DA(d.cells, G * d.rc_pad); DA(d.to_move, G); DA(d.move_count, G); DA(d.done, G); DA(d.winner, G);
+    DA(d.N, nodes); DA(d.W, nodes); DA(d.P, nodes); DA(d.cell, nodes); DA(d.first_child, nodes); DA(d.n_children, nodes);
+    DA(d.rootP, G * g.rc); DA(d.root_f64, G); DA(d.arena_top, G);
+    DA(d.leaf_node, G); DA(d.leaf_depth, G); DA(d.leaf_nmoves, G); DA(d.leaf_slot, G);
+    DA(d.path, G * d.path_cap); DA(d.leaf_cells, G * d.rc_pad); DA(d.leaf_moves, G * g.rc);
+    DA(d.leaf_flag, ((G + 511) / 512) * 512 + 512);
+    DA(d.counters, (size_t)CNT_N * G); DA(d.err, 1); DA(e->counter_sums, CNT_N); DA(e->n_leaf_scratch, 1);
+    if (s == hipSuccess) { uint8_t *ls = nullptr; s = dalloc(e, &ls, G * g.planes * g.rc * 4); e->leaf_scratch = ls; }
+#undef DA
+    if (s != hipSuccess) return fail(AZK_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(s));
+    (void)hipMemset(d.leaf_flag, 0, ((G + 511) / 512) * 512 + 512);
+    (void)hipMemset(d.counters, 0, sizeof(long long) * CNT_N * G);
+    (void)hipMemset(d.err, 0, sizeof(int));
+    (void)hipMemset(d.leaf_node, 0xff, sizeof(int) * G);
+    k_reset_games<<<(unsigned)((G * d.rc_pad + 255) / 256), 256>>>(d, 0, d.G);
+    k_begin_search<<<(unsigned)((G + 255) / 256), 256>>>(d);
+    s = hipDeviceSynchronize();
+    if (s != hipSuccess) return fail(AZK_ERR_HIP, std::string("init kernels: ") + hipGetErrorString(s));
+    *out = e;
+    return AZK_OK;
+}
+
+void azk_destroy(azk_engine *e) {
+    if (!e) return;
+    for (void *p : e->allocs) (void)hipFree(p);
+    delete e;
+}
+
+int32_t azk_geometry(const azk_engine *e, int32_t *planes, int32_t *rows, int32_t *cols, int32_t *action_dim, int32_t *state_dim) {
+    if (!e) return AZK_ERR_ARG;
+    if (planes) *planes = e->d.g.planes;
+    if (rows) *rows = e->d.g.rows;
+    if (cols) *cols = e->d.g.cols;
+    if (action_dim) *action_dim = e->d.g.action_dim;
+    if (state_dim) *state_dim = e->d.g.state_dim;
+    return AZK_OK;
+}
+
+int32_t azk_reset_games(azk_engine *e, int32_t first, int32_t count, void *stream) {
+    if (!e || first < 0 || count < 0 || first + count > e->d.G) { if (e) e->err = "azk_reset_games: bad range"; return AZK_ERR_ARG; }
+    if (count == 0) return AZK_OK;
+    k_reset_games<<<(unsigned)(((size_t)count * e->d.rc_pad + 255) / 256), 256, 0, (hipStream_t)stream>>>(e->d, first, count);
+    HIPCHK(e, hipGetLastError());
+    return AZK_OK;
+}
+
+int32_t azk_set_positions(azk_engine *e, int32_t first, int32_t count, const int8_t *cells_host,
+                          const int32_t *to_move_host, const int32_t *move_count_host, void *stream) {
+    if (!e || first < 0 || count < 1 || first + count > e->d.G || !cells_host || !to_move_host || !move_count_host) {
+        if (e) e->err = "azk_set_positions: bad argument";
+        return AZK_ERR_ARG;
+    }
+    const Dev &d = e->d;
+    hipStream_t st = (hipStream_t)stream;
+    std::vector<uint8_t> padded((size_t)count * d.rc_pad, 0);
+    std::vector<int> zeros(count, 0), win(count, -2);
+    for (int i = 0; i < count; i++)
+        for (int c = 0; c < d.g.rc; c++) {
+            int8_t v = cells_host[(size_t)i * d.g.rc + c];
+            if (v < 0 || v > 2) { e->err = "azk_set_positions: cell codes must be 0, 1 or 2"; return AZK_ERR_ARG; }
+            padded[(size_t)i * d.rc_pad + c] = (uint8_t)v;
+        }
+    HIPCHK(e, hipMemcpyAsync(d.cells + (size_t)first * d.rc_pad, padded.data(), padded.size(), hipMemcpyHostToDevice, st));
+    HIPCHK(e, hipMemcpyAsync(d.to_move + first, to_move_host, sizeof(int) * count, hipMemcpyHostToDevice, st));
+    HIPCHK(e, hipMemcpyAsync(d.move_count + first, move_count_host, sizeof(int) * count, hipMemcpyHostToDevice, st));
+    HIPCHK(e, hipMemcpyAsync(d.done + first, zeros.data(), sizeof(int) * count, hipMemcpyHostToDevice, st));
+    HIPCHK(e, hipMemcpyAsync(d.winner + first, win.data(), sizeof(int) * count, hipMemcpyHostToDevice, st));
+    HIPCHK(e, hipStreamSynchronize(st));   // host staging buffers go out of scope
+    return AZK_OK;
+}
+
+int32_t azk_begin_search(azk_engine *e, const double *noise_dev, void *stream) {
+    if (!e) return AZK_ERR_ARG;
+    e->d.noise = noise_dev;
+    k_begin_search<<<(unsigned)((e->d.G + 255) / 256), 256, 0, (hipStream_t)stream>>>(e->d);
+    HIPCHK(e, hipGetLastError());
+    return AZK_OK;
+}
+
+static int32_t launch_tree(azk_engine *e, bool expand, bool select, const float *logits, const float *values,
+                           void *leaf_boards, int32_t *n_leaf, hipStream_t st) {
+    const Dev &d = e->d;
+    if (expand && (!logits || !values)) { e->err = "expand needs logits_dev and values_dev"; return AZK_ERR_ARG; }
+    if (select && (!leaf_boards || !n_leaf)) { e->err = "select needs leaf_boards_dev and n_leaf_dev"; return AZK_ERR_ARG; }
+    if (expand && select) k_tree<true, true><<<d.G, AZK_WAVE, d.lds_bytes, st>>>(d, logits, values);
+    else if (expand) k_tree<true, false><<<d.G, AZK_WAVE, d.lds_bytes, st>>>(d, logits, values);
+    else k_tree<false, true><<<d.G, AZK_WAVE, d.lds_bytes, st>>>(d, logits, values);
+    HIPCHK(e, hipGetLastError());
+    if (select) {
+        k_gather<<<d.G, AZK_WAVE, 0, st>>>(d, leaf_boards, n_leaf);
+        HIPCHK(e, hipGetLastError());
+    }
+    return AZK_OK;
+}
+
+int32_t azk_step_select(azk_engine *e, void *leaf_boards_dev, int32_t *n_leaf_dev, void *stream) {
+    if (!e) return AZK_ERR_ARG;
+    return launch_tree(e, false, true, nullptr, nullptr, leaf_boards_dev, n_leaf_dev, (hipStream_t)stream);
+}
+
+int32_t azk_step_expand_backup(azk_engine *e, const float *logits_dev, const float *values_dev, void *stream) {
+    if (!e) return AZK_ERR_ARG;
+    return launch_tree(e, true, false, logits_dev, values_dev, nullptr, nullptr, (hipStream_t)stream);
+}
+
+int32_t azk_step(azk_engine *e, const float *logits_dev, const float *values_dev, void *leaf_boards_dev,
+                 int32_t *n_leaf_dev, void *stream) {
+    if (!e) return AZK_ERR_ARG;
+    return launch_tree(e, logits_dev != nullptr, true, logits_dev, values_dev, leaf_boards_dev, n_leaf_dev, (hipStream_t)stream);
+}
+
+int32_t azk_root_stats(azk_engine *e, double *pi_dev, double *q_dev, int32_t *root_visit_dev, void *stream) {
+    if (!e) return AZK_ERR_ARG;
+    k_root_stats<<<e->d.G, AZK_WAVE, e->d.lds_bytes, (hipStream_t)stream>>>(e->d, pi_dev, q_dev, root_visit_dev);
+    HIPCHK(e, hipGetLastError());
+    return AZK_OK;
+}
+
+int32_t azk_advance(azk_engine *e, const double *uniforms_dev, int32_t sample_until_move, int32_t *chosen_cell_dev,
+                    int32_t *winner_dev, int32_t *done_dev, void *stream) {
+    if (!e) return AZK_ERR_ARG;
+    k_advance<<<e->d.G, AZK_WAVE, e->d.lds_bytes, (hipStream_t)stream>>>(e->d, uniforms_dev, sample_until_move,
+                                                                         chosen_cell_dev, winner_dev, done_dev);
+    HIPCHK(e, hipGetLastError());
+    return AZK_OK;
+}
+
+// copy one game's used arena to the host
+struct HostTree {
+    std::vector<int> N, first_child;
+    std::vector<double> W, rootP;
+    std::vector<float> P;
+    std::vector<int16_t> cell, nch;
+    int top = 0, root_f64 = 0;
+};
+
+static int32_t fetch_tree(azk_engine *e, int game, HostTree *t, hipStream_t st) {
+    const Dev &d = e->d;
+    if (game < 0 || game >= d.G) { e->err = "bad game index"; return AZK_ERR_ARG; }
+    HIPCHK(e, hipMemcpyAsync(&t->top, d.arena_top + game, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(e, hipMemcpyAsync(&t->root_f64, d.root_f64 + game, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(e, hipStreamSynchronize(st));
+    const size_t n = (size_t)t->top, base = (size_t)game * d.cap;
+    t->N.resize(n); t->first_child.resize(n); t->W.resize(n); t->P.resize(n); t->cell.resize(n); t->nch.resize(n);
+    t->rootP.resize(d.g.rc);
+    HIPCHK(e, hipMemcpyAsync(t->N.data(), d.N + base, n * sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(e, hipMemcpyAsync(t->first_child.data(), d.first_child + base, n * sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(e, hipMemcpyAsync(t->W.data(), d.W + base, n * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHK(e, hipMemcpyAsync(t->P.data(), d.P + base, n * sizeof(float), hipMemcpyDeviceToHost, st));
+    HIPCHK(e, hipMemcpyAsync(t->cell.data(), d.cell + base, n * sizeof(int16_t), hipMemcpyDeviceToHost, st));
+    HIPCHK(e, hipMemcpyAsync(t->nch.data(), d.n_children + base, n * sizeof(int16_t), hipMemcpyDeviceToHost, st));
+    HIPCHK(e, hipMemcpyAsync(t->rootP.data(), d.rootP + (size_t)game * d.g.rc, d.g.rc * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHK(e, hipStreamSynchronize(st));
+    return AZK_OK;
+}
+
+int32_t azk_root_children(azk_engine *e, int32_t game, int32_t cap, int32_t *cells_host, int32_t *visits_host,
+                          double *values_host, double *priors_host, void *stream) {
+    if (!e) return AZK_ERR_ARG;
+    HostTree t;
+    int32_t rc = fetch_tree(e, game, &t, (hipStream_t)stream);
+    if (rc != AZK_OK) return rc;
+    const int fc = t.first_child[0], n = t.nch[0];
+    for (int i = 0; i < n && i < cap; i++) {
+        if (cells_host) cells_host[i] = t.cell[fc + i];
+        if (visits_host) visits_host[i] = t.N[fc + i];
+        if (values_host) values_host[i] = t.W[fc + i];
+        if (priors_host) priors_host[i] = t.root_f64 ? t.rootP[i] : (double)t.P[fc + i];
+    }
+    return n;
+}
+
+int32_t azk_export_tree(azk_engine *e, int32_t game, int32_t cap, int32_t *depth_host, int32_t *cell_host,
+                        int32_t *visit_host, double *value_host, double *prior_host, void *stream) {
+    if (!e) return AZK_ERR_ARG;
+    HostTree t;
+    int32_t rc = fetch_tree(e, game, &t, (hipStream_t)stream);
+    if (rc != AZK_OK) return rc;
+    std::vector<std::pair<int, int>> stack;
+    stack.push_back({0, 0});
+    int m = 0;
+    const int rfc = t.first_child[0];
+    while (!stack.empty()) {
+        auto [node, dep] = stack.back();
+        stack.pop_back();
+        if (m < cap) {
+            if (depth_host) depth_host[m] = dep;
+            if (cell_host) cell_host[m] = t.cell[node];
+            if (visit_host) visit_host[m] = t.N[node];
+            if (value_host) value_host[m] = t.W[node];
+            if (prior_host) {
+                const bool root_child = dep == 1 && t.root_f64;
+                prior_host[m] = root_child ? t.rootP[node - rfc] : (double)t.P[node];
+            }
+        }
+        m++;
+        for (int i = t.nch[node] - 1; i >= 0; i--) stack.push_back({t.first_child[node] + i, dep + 1});
+    }
+    return m;
+}
+
+int32_t azk_get_positions(azk_engine *e, int8_t *cells_host, int32_t *to_move_host, int32_t *move_count_host, void *stream) {
+    if (!e) return AZK_ERR_ARG;
+    const Dev &d = e->d;
+    hipStream_t st = (hipStream_t)stream;
+    std::vector<uint8_t> padded((size_t)d.G * d.rc_pad);
+    HIPCHK(e, hipMemcpyAsync(padded.data(), d.cells, padded.size(), hipMemcpyDeviceToHost, st));
+    if (to_move_host) HIPCHK(e, hipMemcpyAsync(to_move_host, d.to_move, sizeof(int) * d.G, hipMemcpyDeviceToHost, st));
+    if (move_count_host) HIPCHK(e, hipMemcpyAsync(move_count_host, d.move_count, sizeof(int) * d.G, hipMemcpyDeviceToHost, st));
+    HIPCHK(e, hipStreamSynchronize(st));
+    if (cells_host)
+        for (int g = 0; g < d.G; g++) memcpy(cells_host + (size_t)g * d.g.rc, padded.data() + (size_t)g * d.rc_pad, d.g.rc);
+    return AZK_OK;
+}
+
+int32_t azk_get_counters(azk_engine *e, azk_counters *out, void *stream) {
+    if (!e || !out) return AZK_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    k_sum_counters<<<CNT_N, 256, 0, st>>>(e->d.counters, e->d.G, e->counter_sums);
+    HIPCHK(e, hipGetLastError());
+    long long h[CNT_N];
+    HIPCHK(e, hipMemcpyAsync(h, e->counter_sums, sizeof h, hipMemcpyDeviceToHost, st));
+    HIPCHK(e, hipStreamSynchronize(st));
+    memset(out, 0, sizeof *out);
+    out->sims = h[CNT_SIMS]; out->edges_scanned = h[CNT_SCANNED]; out->trace_nodes = h[CNT_TRACE];
+    out->edges_created = h[CNT_CREATED]; out->leaves_evaluated = h[CNT_LEAVES]; out->terminal_sims = h[CNT_TERMINAL];
+    out->moves_played = h[CNT_MOVES];
+    return AZK_OK;
+}
+
+int32_t azk_reset_counters(azk_engine *e, void *stream) {
+    if (!e) return AZK_ERR_ARG;
+    HIPCHK(e, hipMemsetAsync(e->d.counters, 0, sizeof(long long) * CNT_N * e->d.G, (hipStream_t)stream));
+    return AZK_OK;
+}
+
+int32_t azk_check_device_error(azk_engine *e, void *stream) {
+    if (!e) return AZK_ERR_ARG;
+    int h = 0;
+    HIPCHK(e, hipMemcpyAsync(&h, e->d.err, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIPCHK(e, hipStreamSynchronize((hipStream_t)stream));
+    if (h == AZK_ERR_ARENA_FULL) e->err = "tree arena full: raise azk_config.max_sims / arena_nodes";
+    else if (h != 0) e->err = "device-side state error (search advanced without visits?)";
+    return h;
+}
+
+int32_t azk_gen_noise(azk_engine *e, uint64_t seed, int64_t first_global_game, int32_t move_index, double alpha,
+                      double *noise_dev, double *uniforms_dev, void *stream) {
+    if (!e || alpha <= 0.0) return AZK_ERR_ARG;
+    k_gen_noise<<<e->d.G, AZK_WAVE, 0, (hipStream_t)stream>>>(e->d.g.action_dim, seed, first_global_game, move_index, alpha,
+                                                            noise_dev, uniforms_dev);
+    HIPCHK(e, hipGetLastError());
+    return AZK_OK;
+}
+
+// ---- stateless rule kernels ---------------------------------------------------------------------
+static int32_t run_rules(int mode, int32_t game, int32_t rows, int32_t cols, const float *in, float *inout, int32_t n,
+                         const int32_t *players, const int32_t *cells, int16_t *moves, int32_t *counts, uint8_t *mask,
+                         int32_t *out_i, float *out_f, void *stream) {
+    RuleArgs a;
+    memset(&a, 0, sizeof a);
+    std::string err;
+    if (!make_game(game, rows, cols, &a.g, &err)) { g_create_error = err; return AZK_ERR_ARG; }
+    if (n < 0) { g_create_error = "negative batch"; return AZK_ERR_ARG; }
+    if (n == 0) return AZK_OK;
+    a.mode = mode; a.n = n; a.table_size = table_size_for(a.g);
+    a.boards_in = in; a.boards = inout; a.players = players; a.cells = cells;
+    a.moves = moves; a.counts = counts; a.mask = mask; a.out_i = out_i; a.out_f = out_f;
+    int off[13];
+    const int lds = lds_layout(a.g, 4, a.table_size, off);
+    k_rules<<<n, AZK_WAVE, lds, (hipStream_t)stream>>>(a);
+    hipError_t s = hipGetLastError();
+    if (s != hipSuccess) { g_create_error = std::string("k_rules: ") + hipGetErrorString(s); return AZK_ERR_HIP; }
+    return AZK_OK;
+}
+
+int32_t azk_rules_legal_moves(int32_t game, int32_t rows, int32_t cols, const float *boards_dev, int32_t n,
+                              int16_t *moves_dev, int32_t *counts_dev, void *stream) {
+    if (!boards_dev || !moves_dev || !counts_dev) return AZK_ERR_ARG;
+    return run_rules(RULE_MOVES, game, rows, cols, boards_dev, nullptr, n, nullptr, nullptr, moves_dev, counts_dev, nullptr, nullptr, nullptr, stream);
+}
+int32_t azk_rules_legal_mask(int32_t game, int32_t rows, int32_t cols, const float *boards_dev, int32_t n,
+                             uint8_t *mask_dev, void *stream) {
+    if (!boards_dev || !mask_dev) return AZK_ERR_ARG;
+    return run_rules(RULE_MASK, game, rows, cols, boards_dev, nullptr, n, nullptr, nullptr, nullptr, nullptr, mask_dev, nullptr, nullptr, stream);
+}
+int32_t azk_rules_apply_move(int32_t game, int32_t rows, int32_t cols, float *boards_dev, int32_t n,
+                             const int32_t *players_dev, const int32_t *cells_dev, int32_t *next_player_dev, void *stream) {
+    if (!boards_dev || !players_dev || !cells_dev || !next_player_dev) return AZK_ERR_ARG;
+    return run_rules(RULE_APPLY, game, rows, cols, nullptr, boards_dev, n, players_dev, cells_dev, nullptr, nullptr, nullptr, next_player_dev, nullptr, stream);
+}
+int32_t azk_rules_undo_move(int32_t game, int32_t rows, int32_t cols, float *boards_dev, int32_t n,
+                            const int32_t *current_players_dev, const int32_t *cells_dev, void *stream) {
+    if (!boards_dev || !current_players_dev || !cells_dev) return AZK_ERR_ARG;
+    return run_rules(RULE_UNDO, game, rows, cols, nullptr, boards_dev, n, current_players_dev, cells_dev, nullptr, nullptr, nullptr, nullptr, nullptr, stream);
+}
+int32_t azk_rules_check_winner(int32_t game, int32_t rows, int32_t cols, const float *boards_dev, int32_t n,
+                               const int32_t *players_dev, const int32_t *cells_dev, int32_t *winners_dev, void *stream) {
+    if (!boards_dev || !players_dev || !cells_dev || !winners_dev) return AZK_ERR_ARG;
+    return run_rules(RULE_WINNER, game, rows, cols, boards_dev, nullptr, n, players_dev, cells_dev, nullptr, nullptr, nullptr, winners_dev, nullptr, stream);
+}
+int32_t azk_rules_canonical(int32_t game, int32_t rows, int32_t cols, const float *boards_dev, int32_t n,
+                            const int32_t *players_dev, float *out_dev, void *stream) {
+    if (!boards_dev || !players_dev || !out_dev) return AZK_ERR_ARG;
+    return run_rules(RULE_CANON, game, rows, cols, boards_dev, nullptr, n, players_dev, nullptr, nullptr, nullptr, nullptr, nullptr, out_dev, stream);
+}
+
+int32_t azk_softmax_rows(const float *logits_dev, int32_t n, int32_t action_dim, float *out_dev, void *stream) {
+    if (!logits_dev || !out_dev || n < 0 || action_dim < 1 || action_dim > 512) return AZK_ERR_ARG;
+    if (n == 0) return AZK_OK;
+    const int lds = (((action_dim + 31) & ~31) + 32) * 4;
+    k_softmax_rows<<<n, AZK_WAVE, lds, (hipStream_t)stream>>>(logits_dev, action_dim, out_dev);
+    return hipGetLastError() == hipSuccess ? AZK_OK : AZK_ERR_HIP;
+}
+
+}  // extern "C"

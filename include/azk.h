@@ -1,0 +1,182 @@
+/*
+ * azk.h - C ABI of libazk.so: the MI355X-native batched self-play engine (HIP, gfx950).
+ *
+ * This is the drop-in boundary for the reference's self-play hot path
+ *     train.collect_data -> <Game>.self_play -> ai.mcts.MCTS.mcts -> Game statics + model
+ * (reference files cited per entry point as file:line, relative to the reference root).
+ * The reference has no native layer: everything below replaces interpreted Python.  The ABI is
+ * plain C: no C++ / torch types, raw pointers + sizes, int32 status returns (0 = OK, <0 = error,
+ * text via azk_last_error).  Pointers named *_dev are device (HBM) pointers - e.g. a torch
+ * tensor's data_ptr() - valid until the stream reaches the call; *_host are host pointers.
+ * `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream); every
+ * kernel is enqueued on it and nothing here synchronises unless stated, so calls are capturable
+ * in a hipGraph.  One host thread drives one engine; one engine per GPU / process.
+ *
+ * Data model (DESIGN.md "HBM layout"): G concurrent games; per game a structure-of-arrays tree
+ * arena (the reference's Node fields, ai/node.py:21-40, one row per child edge): N int32, W float64,
+ * P float32 (+ a float64 root-prior row after Dirichlet mixing), cell int16, first_child int32,
+ * n_children int16.  One 64-lane wavefront owns one game; child blocks are contiguous, so a PUCT
+ * scan is a coalesced read of the N/W/P columns.
+ */
+#ifndef AZK_H
+#define AZK_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AZK_ABI_VERSION 1
+
+/* games (games/tictactoe.py, games/connect4.py, games/gomoku.py) */
+#define AZK_TICTACTOE 0
+#define AZK_CONNECT4 1
+#define AZK_GOMOKU 2
+
+/* leaf batch element type handed to the evaluator */
+#define AZK_LEAF_F32 0
+#define AZK_LEAF_BF16 1
+
+/* status codes */
+#define AZK_OK 0
+#define AZK_ERR_ARG (-1)
+#define AZK_ERR_HIP (-2)
+#define AZK_ERR_ARENA_FULL (-3)
+#define AZK_ERR_STATE (-4)
+
+typedef struct azk_engine azk_engine;
+
+typedef struct {
+    int32_t game;          /* AZK_* */
+    int32_t rows, cols;    /* Gomoku only (reference ships 7x7, gomoku.py:10; 15x15 by attribute override) */
+    int32_t n_games;       /* G: games resident on this GPU */
+    int32_t max_sims;      /* largest mcts_iterations a search will run (arena sizing) */
+    int32_t leaf_dtype;    /* AZK_LEAF_F32 | AZK_LEAF_BF16 */
+    int32_t device;        /* HIP device ordinal */
+    int32_t arena_nodes;   /* nodes per game; 0 = worst case 1 + max_sims * max_children */
+    int32_t reserved[8];
+} azk_config;
+
+/* device-side work counters; sums over all games since the last azk_reset_counters */
+typedef struct {
+    int64_t sims;             /* iterations of ai/mcts.py:16 */
+    int64_t edges_scanned;    /* children read by PUCT scans (utils.py:29-44) */
+    int64_t trace_nodes;      /* nodes updated by backups (node.py:62-74) */
+    int64_t edges_created;    /* children appended by expansions (node.py:50-59) */
+    int64_t leaves_evaluated; /* leaf boards handed to the evaluator (mcts.py:46) */
+    int64_t terminal_sims;    /* simulations that ended in mcts.py:25-32 */
+    int64_t moves_played;
+    int64_t reserved[9];
+} azk_counters;
+
+int32_t azk_abi_version(void);
+/* e may be NULL: returns the message of the last failed azk_create on this thread */
+const char *azk_last_error(const azk_engine *e);
+
+/* ---- engine life cycle ---------------------------------------------------------------------- */
+int32_t azk_create(const azk_config *cfg, azk_engine **out);
+void azk_destroy(azk_engine *e);
+/* geometry the caller needs to size buffers: planes F, rows, cols, action_dim A, state_dim */
+int32_t azk_geometry(const azk_engine *e, int32_t *planes, int32_t *rows, int32_t *cols,
+                     int32_t *action_dim, int32_t *state_dim);
+
+/* Game(): empty boards, player 0 to move, move_count 0 (gomoku.py:16-17,125-126) for games [first, first+count) */
+int32_t azk_reset_games(azk_engine *e, int32_t first, int32_t count, void *stream);
+/* load caller positions: cells int8 [count][rows*cols] (0 empty, 1 player-0, 2 player-1), side to move, plies played.
+ * This is how MCTS.mcts(model, board, root, ...) (ai/mcts.py:11) receives the caller's board and root. */
+int32_t azk_set_positions(azk_engine *e, int32_t first, int32_t count, const int8_t *cells_host,
+                          const int32_t *to_move_host, const int32_t *move_count_host, void *stream);
+
+/* ---- one search = Node(None, None, player, move_count) + MCTS.mcts(...) (gomoku.py:134-136) ---- */
+/* Fresh root for every game.  noise_dev: float64 [G][A] Dirichlet draws (utils.py:24) or NULL for
+ * dirichlet=False.  The pointer is read by later steps: keep it alive until the search ends. */
+int32_t azk_begin_search(azk_engine *e, const double *noise_dev, void *stream);
+
+/* One simulation per active game (ai/mcts.py:16-60), split around the evaluator:
+ *   azk_step_select   - mcts.py:18-37: PUCT walk (node.py:42-47, utils.py:29-44), make_move along the
+ *                       path, terminal test + immediate backup, get_valid_moves, canonical board.
+ *                       Non-terminal leaves are compacted (ascending game index) into
+ *                       leaf_boards_dev [n_leaf][F][R][C]; *n_leaf_dev (int32) gets the count.
+ *   azk_step_expand_backup - mcts.py:46-60: float32 softmax without max subtraction, root noise
+ *                       mixing (utils.py:12-27), Node.expand (node.py:50-59), Node.backup (node.py:62-74)
+ *                       with value = -v.  logits_dev float32 [n_leaf][A], values_dev float32 [n_leaf],
+ *                       rows in the slot order azk_step_select produced.
+ * azk_step fuses "expand+backup of the previous step's leaves" with "select of the next" in one launch
+ * (pass logits_dev = NULL on the first step of a search). */
+int32_t azk_step_select(azk_engine *e, void *leaf_boards_dev, int32_t *n_leaf_dev, void *stream);
+int32_t azk_step_expand_backup(azk_engine *e, const float *logits_dev, const float *values_dev, void *stream);
+int32_t azk_step(azk_engine *e, const float *logits_dev, const float *values_dev,
+                 void *leaf_boards_dev, int32_t *n_leaf_dev, void *stream);
+
+/* Root statistics after a search, for all G games (device outputs, any may be NULL):
+ *   pi_dev float64 [G][A]   utils.get_probablity_distribution_of_children (utils.py:46-55)
+ *   q_dev  float64 [G]      root.value / root.visit (gomoku.py:140)
+ *   root_visit_dev int32 [G] */
+int32_t azk_root_stats(azk_engine *e, double *pi_dev, double *q_dev, int32_t *root_visit_dev, void *stream);
+
+/* Root children of ONE game, in the reference's list order (what callers read from root.children:
+ * child.prevAction / visit / value / prior, test.py:46-47, node.py:76-97).  Host outputs of
+ * capacity `cap` each; returns the child count (>= 0) or an error.  Synchronises the stream. */
+int32_t azk_root_children(azk_engine *e, int32_t game, int32_t cap, int32_t *cells_host,
+                          int32_t *visits_host, double *values_host, double *priors_host, void *stream);
+/* Whole tree of one game, DFS pre-order with children in list order (for digests / Node views).
+ * Returns the node count (may exceed cap: only the first cap rows are written).  Synchronises. */
+int32_t azk_export_tree(azk_engine *e, int32_t game, int32_t cap, int32_t *depth_host, int32_t *cell_host,
+                        int32_t *visit_host, double *value_host, double *prior_host, void *stream);
+
+/* Move selection + state advance for all active games (gomoku.py:143-162):
+ *   game g samples ~ visits when move_count[g] < sample_until_move (Node.sample_child, node.py:83-93:
+ *   legacy np.random.choice == searchsorted(cumsum(pi)/sum, u, 'right') with u = uniforms_dev[g]),
+ *   else takes the first child with the most visits (Node.max_visit_child, node.py:76-81);
+ *   then make_move, check_winner for the mover, draw when move_count == state_dim.
+ * Outputs (device, may be NULL): chosen_cell_dev int32 [G] (r*cols+c, -1 for finished games),
+ * winner_dev int32 [G] (-2 still running, -1 draw, 0/1 winner), done_dev int32 [G]. */
+int32_t azk_advance(azk_engine *e, const double *uniforms_dev, int32_t sample_until_move,
+                    int32_t *chosen_cell_dev, int32_t *winner_dev, int32_t *done_dev, void *stream);
+
+/* current boards as int8 cells [G][rows*cols], side to move [G], plies [G] (host outputs; synchronises) */
+int32_t azk_get_positions(azk_engine *e, int8_t *cells_host, int32_t *to_move_host, int32_t *move_count_host, void *stream);
+
+int32_t azk_get_counters(azk_engine *e, azk_counters *out, void *stream);   /* synchronises */
+int32_t azk_reset_counters(azk_engine *e, void *stream);
+/* sticky device-side error word (arena overflow etc.); synchronises; returns AZK_OK or the error */
+int32_t azk_check_device_error(azk_engine *e, void *stream);
+
+/* Dirichlet(alpha) rows and uniforms from a counter-based generator keyed by
+ * (seed, global game index, move index) - results do not depend on how games are sharded over GPUs.
+ * noise_dev float64 [count][A]; uniforms_dev float64 [count] (either may be NULL). */
+int32_t azk_gen_noise(azk_engine *e, uint64_t seed, int64_t first_global_game, int32_t move_index, double alpha,
+                      double *noise_dev, double *uniforms_dev, void *stream);
+
+/* ---- stateless board-rule kernels over caller boards (float32 [n][F][R][C], the reference's layout) ----
+ * game/rows/cols as in azk_config.  These replace the Game statics (games/game.py:4-38):
+ *   azk_rules_legal_moves : get_valid_moves - cells in the reference's LIST ORDER (tictactoe.py:82-83,
+ *                           connect4.py:44-53, gomoku.py:93-106 incl. CPython set order), moves_dev int16 [n][R*C],
+ *                           counts_dev int32 [n]
+ *   azk_rules_legal_mask  : same set as a uint8 mask over ACTIONS [n][A]
+ *   azk_rules_apply_move  : make_move (returns next player; occupied cell => unchanged player, tictactoe.py:37-45,
+ *                           gomoku.py:51-58; connect4.py:56-63 never checks)
+ *   azk_rules_undo_move   : undo_move (tictactoe.py:48-51, connect4.py:67-70, gomoku.py:61-63)
+ *   azk_rules_check_winner: check_winner (k-in-a-row through the cell; player or -1)
+ *   azk_rules_canonical   : get_canonical_board (gomoku.py:34-40; 3-plane: mcts.py:126-137) */
+int32_t azk_rules_legal_moves(int32_t game, int32_t rows, int32_t cols, const float *boards_dev, int32_t n,
+                              int16_t *moves_dev, int32_t *counts_dev, void *stream);
+int32_t azk_rules_legal_mask(int32_t game, int32_t rows, int32_t cols, const float *boards_dev, int32_t n,
+                             uint8_t *mask_dev, void *stream);
+int32_t azk_rules_apply_move(int32_t game, int32_t rows, int32_t cols, float *boards_dev, int32_t n,
+                             const int32_t *players_dev, const int32_t *cells_dev, int32_t *next_player_dev, void *stream);
+int32_t azk_rules_undo_move(int32_t game, int32_t rows, int32_t cols, float *boards_dev, int32_t n,
+                            const int32_t *current_players_dev, const int32_t *cells_dev, void *stream);
+int32_t azk_rules_check_winner(int32_t game, int32_t rows, int32_t cols, const float *boards_dev, int32_t n,
+                               const int32_t *players_dev, const int32_t *cells_dev, int32_t *winners_dev, void *stream);
+int32_t azk_rules_canonical(int32_t game, int32_t rows, int32_t cols, const float *boards_dev, int32_t n,
+                            const int32_t *players_dev, float *out_dev, void *stream);
+
+/* float32 softmax exactly as the engine applies it to logits (test hook; [n][A] -> [n][A]) */
+int32_t azk_softmax_rows(const float *logits_dev, int32_t n, int32_t action_dim, float *out_dev, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AZK_H */
