@@ -25,6 +25,7 @@ SYMBOLS = [
     "azk_get_counters", "azk_reset_counters", "azk_check_device_error", "azk_gen_noise",
     "azk_rules_legal_moves", "azk_rules_legal_mask", "azk_rules_apply_move", "azk_rules_undo_move",
     "azk_rules_check_winner", "azk_rules_canonical", "azk_softmax_rows",
+    "azk_step_tree", "azk_step_gather", "azk_recycle_finished",
 ]
 
 
@@ -70,6 +71,9 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise AzkError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                        "(the HIP extension is required; there is no CPU fallback)")
+    # PyTorch ships its own HIP runtime (libamdhip64.so.7 + libhsa-runtime64); it must be the process's only
+    # one, so torch is imported before libazk.so is mapped and the soname resolves to the copy already loaded.
+    import torch  # noqa: F401
     L = C.CDLL(LIB_PATH)
     vp, i32, i64, u64, f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_double
     L.azk_abi_version.restype = i32
@@ -102,6 +106,9 @@ def lib():
     L.azk_rules_check_winner.argtypes = [i32, i32, i32, vp, i32, vp, vp, vp, vp]
     L.azk_rules_canonical.argtypes = [i32, i32, i32, vp, i32, vp, vp, vp]
     L.azk_softmax_rows.argtypes = [vp, i32, i32, vp, vp]
+    L.azk_step_tree.argtypes = [vp, vp, vp, vp]
+    L.azk_step_gather.argtypes = [vp, vp, vp, vp]
+    L.azk_recycle_finished.argtypes = [vp, vp, vp]
     for name in SYMBOLS:
         f = getattr(L, name)
         if name not in ("azk_last_error", "azk_destroy"):
@@ -211,6 +218,17 @@ class Engine:
     def step(self, logits=None, values=None):
         """expand+backup the previous leaves (if logits given) and select the next; no host sync."""
         self._chk(self.L.azk_step(self.h, _p(logits), _p(values), _p(self.leaf_boards), _p(self.n_leaf), _stream()))
+
+    def step_tree(self, logits=None, values=None):
+        self._chk(self.L.azk_step_tree(self.h, _p(logits), _p(values), _stream()))
+
+    def step_gather(self):
+        self._chk(self.L.azk_step_gather(self.h, _p(self.leaf_boards), _p(self.n_leaf), _stream()))
+
+    def recycle_finished(self, stats):
+        """stats: int64 CUDA tensor [8] accumulating (games, plies, wins0, wins1, draws)."""
+        assert stats.dtype == self.torch.int64 and stats.is_cuda and stats.numel() >= 8
+        self._chk(self.L.azk_recycle_finished(self.h, _p(stats), _stream()))
 
     def step_select(self):
         self._chk(self.L.azk_step_select(self.h, _p(self.leaf_boards), _p(self.n_leaf), _stream()))

@@ -323,6 +323,19 @@ __global__ void k_reset_games(Dev d, int first, int count) {
     if (i == 0) { d.to_move[g] = 0; d.move_count[g] = 0; d.done[g] = 0; d.winner[g] = -2; d.leaf_node[g] = -1; d.leaf_flag[g] = 0; }
 }
 
+// Continuous self-play: every finished game's slot restarts from Game() (empty board, player 0).
+// stats[0] += games recycled, stats[1] += plies those games lasted, stats[2..4] += wins of player 0 / player 1 / draws.
+__global__ void k_recycle(Dev d, long long *stats) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= d.G || !d.done[g]) return;
+    atomicAdd((unsigned long long *)&stats[0], 1ull);
+    atomicAdd((unsigned long long *)&stats[1], (unsigned long long)d.move_count[g]);
+    const int w = d.winner[g];
+    atomicAdd((unsigned long long *)&stats[w == 0 ? 2 : (w == 1 ? 3 : 4)], 1ull);
+    for (int i = 0; i < d.rc_pad; i++) d.cells[(size_t)g * d.rc_pad + i] = 0;
+    d.to_move[g] = 0; d.move_count[g] = 0; d.done[g] = 0; d.winner[g] = -2; d.leaf_node[g] = -1; d.leaf_flag[g] = 0;
+}
+
 // utils.get_probablity_distribution_of_children (utils.py:46-55), root.value / root.visit (gomoku.py:140)
 __global__ __launch_bounds__(AZK_WAVE) void k_root_stats(Dev d, double *pi, double *q, int *root_visit) {
     const int g = blockIdx.x, lane = azk_lane();
@@ -780,6 +793,31 @@ int32_t azk_step(azk_engine *e, const float *logits_dev, const float *values_dev
                  int32_t *n_leaf_dev, void *stream) {
     if (!e) return AZK_ERR_ARG;
     return launch_tree(e, logits_dev != nullptr, true, logits_dev, values_dev, leaf_boards_dev, n_leaf_dev, (hipStream_t)stream);
+}
+
+int32_t azk_step_tree(azk_engine *e, const float *logits_dev, const float *values_dev, void *stream) {
+    if (!e) return AZK_ERR_ARG;
+    const Dev &d = e->d;
+    hipStream_t st = (hipStream_t)stream;
+    if (logits_dev && !values_dev) { e->err = "values_dev missing"; return AZK_ERR_ARG; }
+    if (logits_dev) k_tree<true, true><<<d.G, AZK_WAVE, d.lds_bytes, st>>>(d, logits_dev, values_dev);
+    else k_tree<false, true><<<d.G, AZK_WAVE, d.lds_bytes, st>>>(d, nullptr, nullptr);
+    HIPCHK(e, hipGetLastError());
+    return AZK_OK;
+}
+
+int32_t azk_step_gather(azk_engine *e, void *leaf_boards_dev, int32_t *n_leaf_dev, void *stream) {
+    if (!e || !leaf_boards_dev || !n_leaf_dev) return AZK_ERR_ARG;
+    k_gather<<<e->d.G, AZK_WAVE, 0, (hipStream_t)stream>>>(e->d, leaf_boards_dev, n_leaf_dev);
+    HIPCHK(e, hipGetLastError());
+    return AZK_OK;
+}
+
+int32_t azk_recycle_finished(azk_engine *e, int64_t *stats_dev, void *stream) {
+    if (!e || !stats_dev) return AZK_ERR_ARG;
+    k_recycle<<<(unsigned)((e->d.G + 255) / 256), 256, 0, (hipStream_t)stream>>>(e->d, (long long *)stats_dev);
+    HIPCHK(e, hipGetLastError());
+    return AZK_OK;
 }
 
 int32_t azk_root_stats(azk_engine *e, double *pi_dev, double *q_dev, int32_t *root_visit_dev, void *stream) {

@@ -1,0 +1,199 @@
+"""Policy-value evaluator for the self-play engine: the reference's ViT (ai/nn.py:5-84) as a
+functional forward over a flat weight table keyed by the reference's own state_dict names, so
+checkpoints written by utils.save_model (utils.py:57-61) load unchanged.
+
+    embedding.cls_token [1,1,D]            embedding.pos_embedding [1,T,D]
+    embedding.patch_embed.patch_embed.{weight [D,C,k,k], bias}
+    blocks.i.{norm1,norm2}.{weight,bias}   blocks.i.attn.{in_proj_weight [3D,D], in_proj_bias, out_proj.weight, out_proj.bias}
+    blocks.i.mlp.{0,3}.{weight,bias}       norm.{weight,bias}   policy_head.{weight [A,D],bias}   value_head.{weight [1,D],bias}
+
+Evaluation paths (all compute the SAME function: logits [n,A], value [n] in (-1,1)):
+  "full"  every token through every block (what nn.Module.forward does; 1.538 GFLOP/board at the
+          15x15 / D=512 / depth 1 config)
+  "cls"   the last block only produces what is consumed: K,V for all tokens, Q / out-proj / MLP for the
+          cls row alone (x[:,0] is the only row the heads read, nn.py:80-83).  0.254 GFLOP/board.
+Rectangular boards (Connect4 6x7) get rows*cols+1 tokens; the reference's Net is square-only
+(nn.py:26-28), so that case has no reference numerics ("parity unpinned - build-defined").
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+class NetConfig:
+    def __init__(self, rows, cols, channels, action_dim, patch_size=5, embed_dim=512, num_heads=8, depth=1):
+        self.rows, self.cols, self.channels, self.action_dim = rows, cols, channels, action_dim
+        self.patch_size, self.embed_dim, self.num_heads, self.depth = patch_size, embed_dim, num_heads, depth
+
+    @property
+    def tokens(self):
+        return self.rows * self.cols + 1
+
+    def flops_full(self):
+        """multiply-add = 2 flops; matches SURVEY 3.2 (1.538 GFLOP at the training config)."""
+        T, D, A, C, k = self.tokens, self.embed_dim, self.action_dim, self.channels, self.patch_size
+        conv = 2 * (T - 1) * D * C * k * k
+        blk = 2 * T * D * 3 * D + 2 * 2 * T * T * D + 2 * T * D * D + 2 * 2 * T * D * 4 * D
+        return conv + self.depth * blk + 2 * D * (A + 1)
+
+    def flops_cls(self):
+        T, D, A, C, k = self.tokens, self.embed_dim, self.action_dim, self.channels, self.patch_size
+        conv = 2 * (T - 1) * D * C * k * k
+        blk = 2 * T * D * 3 * D + 2 * 2 * T * T * D + 2 * T * D * D + 2 * 2 * T * D * 4 * D
+        last = 2 * T * D * 2 * D + 2 * D * D + 2 * 2 * T * D + 2 * D * D + 2 * 2 * D * 4 * D
+        return conv + (self.depth - 1) * blk + last + 2 * D * (A + 1)
+
+
+def reference_key_shapes(cfg):
+    D, T, C, k, A = cfg.embed_dim, cfg.tokens, cfg.channels, cfg.patch_size, cfg.action_dim
+    s = {"embedding.cls_token": (1, 1, D), "embedding.pos_embedding": (1, T, D),
+         "embedding.patch_embed.patch_embed.weight": (D, C, k, k), "embedding.patch_embed.patch_embed.bias": (D,)}
+    for i in range(cfg.depth):
+        b = f"blocks.{i}."
+        s.update({b + "norm1.weight": (D,), b + "norm1.bias": (D,), b + "attn.in_proj_weight": (3 * D, D),
+                  b + "attn.in_proj_bias": (3 * D,), b + "attn.out_proj.weight": (D, D), b + "attn.out_proj.bias": (D,),
+                  b + "norm2.weight": (D,), b + "norm2.bias": (D,), b + "mlp.0.weight": (4 * D, D), b + "mlp.0.bias": (4 * D,),
+                  b + "mlp.3.weight": (D, 4 * D), b + "mlp.3.bias": (D,)})
+    s.update({"norm.weight": (D,), "norm.bias": (D,), "policy_head.weight": (A, D), "policy_head.bias": (A,),
+              "value_head.weight": (1, D), "value_head.bias": (1,)})
+    return s
+
+
+def init_weights(cfg, seed=0):
+    """Random initialisation with torch's default initialisers, drawn in module-construction order
+    (conv, cls, pos, per block: attention out-proj then in-proj, MLP linears; final heads) so that
+    torch.manual_seed(seed) yields the very tensors `Net(...)` would hold under the same seed."""
+    D, C, k, A, T = cfg.embed_dim, cfg.channels, cfg.patch_size, cfg.action_dim, cfg.tokens
+    torch.manual_seed(seed)
+    w = {}
+    conv = torch.nn.Conv2d(C, D, kernel_size=k, stride=1, padding=k // 2)
+    w["embedding.patch_embed.patch_embed.weight"], w["embedding.patch_embed.patch_embed.bias"] = conv.weight.data, conv.bias.data
+    w["embedding.cls_token"] = torch.randn(1, 1, D)
+    w["embedding.pos_embedding"] = torch.randn(1, T, D)
+    for i in range(cfg.depth):
+        b = f"blocks.{i}."
+        att = torch.nn.MultiheadAttention(D, cfg.num_heads, batch_first=True)
+        l1, l2 = torch.nn.Linear(D, 4 * D), torch.nn.Linear(4 * D, D)
+        for nm in ("norm1", "norm2"):
+            w[b + nm + ".weight"], w[b + nm + ".bias"] = torch.ones(D), torch.zeros(D)
+        w[b + "attn.in_proj_weight"], w[b + "attn.in_proj_bias"] = att.in_proj_weight.data, att.in_proj_bias.data
+        w[b + "attn.out_proj.weight"], w[b + "attn.out_proj.bias"] = att.out_proj.weight.data, att.out_proj.bias.data
+        w[b + "mlp.0.weight"], w[b + "mlp.0.bias"] = l1.weight.data, l1.bias.data
+        w[b + "mlp.3.weight"], w[b + "mlp.3.bias"] = l2.weight.data, l2.bias.data
+    w["norm.weight"], w["norm.bias"] = torch.ones(D), torch.zeros(D)
+    ph, vh = torch.nn.Linear(D, A), torch.nn.Linear(D, 1)
+    w["policy_head.weight"], w["policy_head.bias"] = ph.weight.data, ph.bias.data
+    w["value_head.weight"], w["value_head.bias"] = vh.weight.data, vh.bias.data
+    return {k_: v.clone() for k_, v in w.items()}
+
+
+class PolicyValueNet:
+    """Callable evaluator: net(boards[n,C,R,Cc]) -> (logits [n,A] float32, value [n,1] float32)."""
+
+    def __init__(self, cfg, weights=None, seed=0, device="cpu", dtype=torch.float32, path="cls"):
+        self.cfg = cfg
+        w = weights if weights is not None else init_weights(cfg, seed)
+        want = reference_key_shapes(cfg)
+        if set(w) != set(want):
+            raise KeyError(f"state_dict keys differ: missing {sorted(set(want) - set(w))}, unexpected {sorted(set(w) - set(want))}")
+        for k_, shp in want.items():
+            if tuple(w[k_].shape) != tuple(shp):
+                raise ValueError(f"{k_}: shape {tuple(w[k_].shape)} != {shp}")
+        self.master = {k_: torch.as_tensor(v).detach().to(torch.float32).cpu().clone() for k_, v in w.items()}
+        self.path = path
+        self.to(device, dtype)
+
+    # ---- state_dict compatibility with utils.save_model / load_model (utils.py:57-69) ----------------
+    def state_dict(self):
+        return {k_: v.clone() for k_, v in self.master.items()}
+
+    @classmethod
+    def from_state_dict(cls, cfg, sd, **kw):
+        return cls(cfg, weights=sd, **kw)
+
+    def to(self, device, dtype=None):
+        self.device = torch.device(device)
+        self.dtype = dtype or self.dtype
+        self.w = {k_: v.to(self.device, self.dtype) for k_, v in self.master.items()}
+        D, H = self.cfg.embed_dim, self.cfg.num_heads
+        self.scale = 1.0 / math.sqrt(D // H)
+        return self
+
+    def eval(self):
+        return self
+
+    def __bool__(self):
+        return True
+
+    # ---- pieces ------------------------------------------------------------------------------------------
+    def embed(self, x):
+        """nn.py:13-19,30-36: stride-1 'same' conv as im2col + GEMM, + bias, cls token, + positional embedding.
+        (MIOpen's bf16 conv for C=2 falls back to per-image im2col / naive kernels: 16k launches per call.)"""
+        w, cfg = self.w, self.cfg
+        n, k = x.shape[0], cfg.patch_size
+        cols = F.unfold(x.to(self.dtype), kernel_size=k, padding=k // 2)        # [n, C*k*k, R*C]
+        wmat = w["embedding.patch_embed.patch_embed.weight"].reshape(cfg.embed_dim, -1)
+        t = torch.matmul(cols.transpose(1, 2), wmat.t()) + w["embedding.patch_embed.patch_embed.bias"]
+        t = torch.cat([w["embedding.cls_token"].expand(n, -1, -1), t], dim=1)  # nn.py:33-34
+        return t + w["embedding.pos_embedding"]                                # nn.py:35
+
+    def _ln(self, x, name):
+        return F.layer_norm(x, (self.cfg.embed_dim,), self.w[name + ".weight"], self.w[name + ".bias"], 1e-5)
+
+    def block_full(self, x, i):
+        w, cfg = self.w, self.cfg
+        b = f"blocks.{i}."
+        n, T, D = x.shape
+        H = cfg.num_heads
+        h = self._ln(x, b + "norm1")
+        qkv = F.linear(h, w[b + "attn.in_proj_weight"], w[b + "attn.in_proj_bias"])
+        q, k, v = qkv.view(n, T, 3, H, D // H).permute(2, 0, 3, 1, 4)
+        a = F.scaled_dot_product_attention(q, k, v)                            # softmax(q k^T / sqrt(d)) v
+        a = a.transpose(1, 2).reshape(n, T, D)
+        x = x + F.linear(a, w[b + "attn.out_proj.weight"], w[b + "attn.out_proj.bias"])   # nn.py:54-56
+        h = self._ln(x, b + "norm2")
+        h = F.linear(F.gelu(F.linear(h, w[b + "mlp.0.weight"], w[b + "mlp.0.bias"])), w[b + "mlp.3.weight"], w[b + "mlp.3.bias"])
+        return x + h                                                           # nn.py:59-60
+
+    def block_cls(self, x, i):
+        """Last block restricted to the cls row: exact, because only x[:,0] is read afterwards (nn.py:80)."""
+        w, cfg = self.w, self.cfg
+        b = f"blocks.{i}."
+        n, T, D = x.shape
+        H, dh = cfg.num_heads, D // cfg.num_heads
+        h = self._ln(x, b + "norm1")
+        Wi, bi = w[b + "attn.in_proj_weight"], w[b + "attn.in_proj_bias"]
+        q = F.linear(h[:, 0], Wi[:D], bi[:D]).view(n, H, 1, dh)
+        kv = F.linear(h, Wi[D:], bi[D:]).view(n, T, 2, H, dh)
+        k, v = kv[:, :, 0].transpose(1, 2), kv[:, :, 1].transpose(1, 2)        # [n,H,T,dh]
+        a = F.scaled_dot_product_attention(q, k, v).reshape(n, D)
+        x0 = x[:, 0] + F.linear(a, w[b + "attn.out_proj.weight"], w[b + "attn.out_proj.bias"])
+        h = self._ln(x0, b + "norm2")
+        h = F.linear(F.gelu(F.linear(h, w[b + "mlp.0.weight"], w[b + "mlp.0.bias"])), w[b + "mlp.3.weight"], w[b + "mlp.3.bias"])
+        return x0 + h                                                          # [n, D]
+
+    def heads(self, x0):
+        x0 = self._ln(x0, "norm")
+        logits = F.linear(x0, self.w["policy_head.weight"], self.w["policy_head.bias"])
+        value = torch.tanh(F.linear(x0, self.w["value_head.weight"], self.w["value_head.bias"]))   # nn.py:82-83
+        return logits.float(), value.float()
+
+    @torch.no_grad()
+    def forward(self, x, path=None):
+        path = path or self.path
+        x = self.embed(x.to(self.device))
+        depth = self.cfg.depth
+        if path == "full":
+            for i in range(depth):
+                x = self.block_full(x, i)
+            x0 = x[:, 0]
+        elif path == "cls":
+            for i in range(depth - 1):
+                x = self.block_full(x, i)
+            x0 = self.block_cls(x, depth - 1)
+        else:
+            raise ValueError(path)
+        return self.heads(x0)
+
+    __call__ = forward

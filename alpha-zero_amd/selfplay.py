@@ -92,3 +92,115 @@ def self_play_batch(game, evaluator, n_games, n_sims, size=None, seed=0, first_g
         stats.update(eng.counters())
         stats["moves"] = move
     return results
+
+
+class SelfPlayRunner:
+    """Continuous self-play: G slots advance one move per `play_move()`; a slot whose game ends restarts
+    from an empty board in the same call (azk_recycle_finished), so every move does G searches.
+    Per move the records the reference's self_play keeps (raw board, pi, q, action; gomoku.py:138-146)
+    are copied to pinned host buffers; `on_records` (optional) receives them.
+
+    RNG key = (seed, first_global_game + slot, move counter): results do not depend on the sharding.
+    """
+
+    def __init__(self, game, evaluator, n_games, n_sims, size=None, seed=0, first_global_game=0, dirichlet=True,
+                 alpha=0.03, device=0, leaf_dtype="float32", recycle=True, on_records=None, kernel_timer=None):
+        import torch
+        self.torch = torch
+        self.eng = Engine(game, n_games, n_sims, size=size, device=device, leaf_dtype=leaf_dtype)
+        self.evaluator, self.n_sims, self.seed, self.first = evaluator, n_sims, seed, first_global_game
+        self.dirichlet, self.alpha, self.recycle, self.on_records = dirichlet, alpha, recycle, on_records
+        self.sample_until = SAMPLE_UNTIL[game]
+        self.kernel_timer = kernel_timer
+        e = self.eng
+        self.stats = torch.zeros(8, dtype=torch.int64, device=e.device)
+        self.cells_dev = torch.zeros((e.G, e.rows * e.cols), dtype=torch.int8, device=e.device)
+        pin = dict(pin_memory=True)
+        self.h_pi = torch.zeros((e.G, e.action_dim), dtype=torch.float64, **pin)
+        self.h_q = torch.zeros(e.G, dtype=torch.float64, **pin)
+        self.h_chosen = torch.zeros(e.G, dtype=torch.int32, **pin)
+        self.h_winner = torch.zeros(e.G, dtype=torch.int32, **pin)
+        self.h_done = torch.zeros(e.G, dtype=torch.int32, **pin)
+        self.h_stats = torch.zeros(8, dtype=torch.int64, **pin)
+        self.move_idx = 0
+        self.plies_played = 0
+        e.reset_games()
+
+    def play_move(self):
+        e = self.eng
+        noise, uni = e.gen_noise(self.seed, self.first, self.move_idx, self.alpha, want_noise=self.dirichlet)
+        self.search(noise)
+        pi, q, _ = e.root_stats()
+        self.h_pi.copy_(pi, non_blocking=True)
+        self.h_q.copy_(q, non_blocking=True)
+        chosen, winner, done = e.advance(uni, self.sample_until)
+        self.h_chosen.copy_(chosen, non_blocking=True)
+        self.h_winner.copy_(winner, non_blocking=True)
+        self.h_done.copy_(done, non_blocking=True)
+        if self.recycle:
+            e.recycle_finished(self.stats)
+        self.h_stats.copy_(self.stats, non_blocking=True)
+        self.torch.cuda.current_stream().synchronize()
+        self.plies_played += int((self.h_chosen >= 0).sum())
+        if self.on_records is not None:
+            self.on_records(self.move_idx, self.h_pi, self.h_q, self.h_chosen, self.h_winner, self.h_done)
+        self.move_idx += 1
+
+    def search(self, noise):
+        """Engine.search with optional per-kernel event timing of k_tree (sampled steps)."""
+        e, torch, kt = self.eng, self.torch, self.kernel_timer
+        e.begin_search(noise)
+        logits = values = None
+        for s in range(self.n_sims):
+            if kt is not None and kt.want(s):
+                kt.start()
+                e.step_tree(logits, values)
+                kt.stop()
+                e.step_gather()
+            else:
+                e.step(logits, values)
+            n = int(e.n_leaf.item())
+            if n > 0:
+                logits, values = self.evaluator(e.leaf_boards[:n])
+                logits = logits.to(torch.float32).contiguous()
+                values = values.to(torch.float32).reshape(-1).contiguous()
+            else:
+                logits = values = None
+        if logits is not None:
+            e.step_expand_backup(logits, values)
+
+    @property
+    def games_finished(self):
+        return int(self.h_stats[0])
+
+    @property
+    def finished_plies(self):
+        return int(self.h_stats[1])
+
+
+class KernelTimer:
+    """HIP-event timing of one kernel on the stream it is launched on (torch's current stream)."""
+
+    def __init__(self, stride=16, max_samples=4096):
+        import torch
+        self.torch, self.stride, self.max = torch, stride, max_samples
+        self.pairs = []
+        self.enabled = False
+
+    def want(self, step):
+        return self.enabled and step % self.stride == 0 and len(self.pairs) < self.max
+
+    def start(self):
+        self._a = self.torch.cuda.Event(enable_timing=True)
+        self._a.record()
+
+    def stop(self):
+        b = self.torch.cuda.Event(enable_timing=True)
+        b.record()
+        self.pairs.append((self._a, b))
+
+    def mean_ms(self):
+        self.torch.cuda.synchronize()
+        if not self.pairs:
+            return None
+        return sum(a.elapsed_time(b) for a, b in self.pairs) / len(self.pairs)

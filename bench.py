@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""bench.py - self-play data generation throughput on MI355X (BASELINE.json metric).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]            (N > 1: launched by torch.distributed.run)
+
+Workload (BASELINE.json configs[2]): Gomoku 15x15, 800 simulations per move, 2048 concurrent self-play
+games per GPU, policy-value net = the reference's training config (ai/nn.py Net(15, patch 5, embed 512,
+225 actions, 8 heads, depth 1, 2 channels), random init, seed 0), synthetic start (empty boards).
+
+A STEP is one move of the whole resident batch: 2048 searches x 800 simulations (tree kernels + leaf
+compaction + network evaluation + expansion/backup), move selection, state advance, the per-move records
+(board, pi, q, action) copied to the host, and finished games restarted (continuous self-play).
+value = self-play games/sec = plies played in the timed region / mean plies per finished game / seconds
+(the steady-state completion rate; raw completions inside the window are reported next to it).
+
+One JSON line on rank 0.  Extra objects:
+  roofline      k_tree (PUCT scan + expand + backup), HBM-bound: algorithmic bytes per launch from the engine's
+                device counters / mean launch duration from HIP events on the launch stream
+  cpu_baseline  the oracle (CPU restatement of the reference algorithm, batch-1 fp32 net, eval cache) timed on
+                this box's host cores on a bounded sample of the same workload
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "alpha-zero_amd"), os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+BF16_PEAK_TFLOPS = 2500.0      # dense bf16 MFMA
+
+
+def algorithmic_bytes(c, action_dim):
+    """k_tree traffic model (DESIGN.md 'k_tree roofline'): per scanned child N,W,P = 4+8+4 B; per backed-up
+    node a read-modify-write of N and W = 2*(4+8) B; per created child N,W,P,cell,first_child,n_children =
+    4+8+4+2+4+2 B plus its move-list entry written then read (2+2 B); per evaluated leaf the logits row (4*A B),
+    the leaf board written (R*C B) and the path written then read (8 B per node, folded into the trace term)."""
+    return (16 * c["edges_scanned"] + 24 * c["trace_nodes"] + 28 * c["edges_created"]
+            + c["leaves_evaluated"] * (4 * action_dim + action_dim) + 8 * c["trace_nodes"])
+
+
+def cpu_baseline(n_sims, budget_s, mean_plies):
+    """The oracle (kind 'port'): sequential search in C, batch-1 float32 ViT through PyTorch CPU, eval cache on,
+    numpy softmax - the reference's algorithm and evaluator shape.  Bounded by wall-clock."""
+    import numpy as np
+    import torch
+    from oracle import az_oracle as ao
+    from pvnet import NetConfig, PolicyValueNet
+    cfg = NetConfig(15, 15, 2, 225, 5, 512, 8, 1)
+    net = PolicyValueNet(cfg, seed=0, device="cpu", dtype=torch.float32, path="full")
+    game = ao.OracleGame("gomoku", 15)
+    cache = ao.OracleCache(game)
+    cnt = ao.Counters()
+    rng = np.random.RandomState(0)
+
+    def ev(canon):
+        logits, v = net(torch.from_numpy(np.ascontiguousarray(canon))[None])
+        l = logits[0].numpy()
+        return np.exp(l) / np.sum(np.exp(l)), float(v[0, 0])
+    t0 = time.time()
+    out = ao.self_play(game, ev, n_sims, noise_fn=lambda mc: rng.dirichlet([0.03] * 225),
+                       uniform_fn=lambda mc: rng.random_sample(), cache=cache, counters=cnt, time_budget=budget_s)
+    dt = time.time() - t0
+    sims_per_s = cnt.mcts_count / dt
+    games_per_s = sims_per_s / (n_sims * mean_plies)
+    return {"value": games_per_s, "unit": "games/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sims_per_sec": sims_per_s, "host_cpus": os.cpu_count(),
+            "sample": f"first {len(out['cells'])} moves of one Gomoku 15x15 game, {n_sims} sims/move: {cnt.mcts_count} sims "
+                      f"({cnt.evals} net evals, {cnt.matched} cache hits) in {dt:.1f} s; games/s = sims/s / ({n_sims} x {mean_plies:.1f} plies)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--games", type=int, default=2048, help="concurrent games per GPU")
+    ap.add_argument("--sims", type=int, default=800)
+    ap.add_argument("--size", type=int, default=15)
+    ap.add_argument("--nn-path", default="cls", choices=["cls", "full"])
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="wall-clock budget of the CPU baseline leg (0 = skip)")
+    ap.add_argument("--seed", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+
+    from pvnet import NetConfig, PolicyValueNet
+    from selfplay import KernelTimer, SelfPlayRunner
+    A = args.size * args.size
+    cfg = NetConfig(args.size, args.size, 2, A, 5, 512, 8, 1)
+    net = PolicyValueNet(cfg, seed=0, device=f"cuda:{local_rank}", dtype=torch.bfloat16, path=args.nn_path)
+    kt = KernelTimer(stride=16)
+    runner = SelfPlayRunner("gomoku", net, args.games, args.sims, size=args.size, seed=args.seed,
+                            first_global_game=rank * args.games, device=local_rank, leaf_dtype="bfloat16",
+                            recycle=True, kernel_timer=kt)
+    eng = runner.eng
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        runner.play_move()
+    eng.reset_counters()
+    plies0, fin0, finp0 = runner.plies_played, runner.games_finished, runner.finished_plies
+    kt.enabled = True
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        runner.play_move()
+    sync_all()
+    dt = time.perf_counter() - t0
+    kt.enabled = False
+    eng.check_error()
+    c = eng.counters()
+    plies = runner.plies_played - plies0
+    fin, finp = runner.games_finished, runner.finished_plies
+
+    # max time / summed work over ranks
+    tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    work = torch.tensor([plies, fin - fin0, fin, finp, c["sims"], c["leaves_evaluated"]], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dist.all_reduce(work, op=dist.ReduceOp.SUM)
+    dt_max = float(tt[0])
+    plies_all, fin_window, fin_all, finp_all, sims_all, leaves_all = [float(x) for x in work]
+
+    if rank == 0:
+        if fin_all > 0:
+            mean_plies, src = finp_all / fin_all, f"{int(fin_all)} games finished in this run"
+        else:
+            mean_plies, src = 30.0, "no game finished in this run: assumed 30 plies"
+        games_per_s = plies_all / mean_plies / dt_max
+        tree_ms = kt.mean_ms()
+        launches = args.steps * args.sims
+        alg_bytes = algorithmic_bytes(c, A) / launches
+        roof = None
+        if tree_ms:
+            gbs = alg_bytes / (tree_ms * 1e-3) / 1e9
+            roof = {"kernel": "k_tree<expand,select>", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": gbs / HBM_PEAK_GBS, "traffic": None, "avg_launch_us": tree_ms * 1e3,
+                    "algorithmic_bytes_per_launch": alg_bytes, "event_samples": len(kt.pairs)}
+        flops = cfg.flops_cls() if args.nn_path == "cls" else cfg.flops_full()
+        out = {
+            "metric": "selfplay_games_per_sec", "value": games_per_s, "unit": "games/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt_max / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"Gomoku {args.size}x{args.size}, {args.sims} sims/move, {args.games} concurrent self-play games per GPU "
+                                   f"(BASELINE.json configs[2]), continuous self-play", "games_per_gpu": args.games,
+                       "sims_per_move": args.sims, "net": f"ViT patch5 embed512 heads8 depth1 (ai/nn.py), random init seed 0, path={args.nn_path}",
+                       "parallelism": f"games sharded over {world} GPU(s), no collectives on the generation path"},
+            "sims_per_sec": sims_all / dt_max, "leaf_evals_per_sec": leaves_all / dt_max,
+            "nn_tflops_algorithmic": leaves_all * flops / dt_max / 1e12, "nn_flops_per_leaf": flops,
+            "mean_plies_per_game": mean_plies, "game_length_source": src, "games_finished_in_window": fin_window,
+            "plies_in_window": plies_all, "counters_rank0": c, "roofline": roof,
+        }
+        if args.cpu_seconds > 0 and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args.sims, args.cpu_seconds, mean_plies)
+            out["gpu_over_cpu"] = games_per_s / out["cpu_baseline"]["value"]
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -109,6 +109,17 @@ int32_t azk_step_expand_backup(azk_engine *e, const float *logits_dev, const flo
 int32_t azk_step(azk_engine *e, const float *logits_dev, const float *values_dev,
                  void *leaf_boards_dev, int32_t *n_leaf_dev, void *stream);
 
+/* The two launches azk_step is made of, separately (per-kernel timing; also lets the caller overlap):
+ *   azk_step_tree   - k_tree: expand+backup of the pending leaves (logits_dev != NULL) then PUCT select
+ *   azk_step_gather - k_gather: leaf compaction + canonical boards into the evaluator batch */
+int32_t azk_step_tree(azk_engine *e, const float *logits_dev, const float *values_dev, void *stream);
+int32_t azk_step_gather(azk_engine *e, void *leaf_boards_dev, int32_t *n_leaf_dev, void *stream);
+
+/* Continuous self-play (the batched form of train.collect_data's `for iter in range(iterations): game = Game()`,
+ * train.py:63-65): every finished game's slot restarts from an empty board.  stats_dev int64[8] accumulates
+ * [0] games finished, [1] their total plies, [2] wins of player 0, [3] wins of player 1, [4] draws. */
+int32_t azk_recycle_finished(azk_engine *e, int64_t *stats_dev, void *stream);
+
 /* Root statistics after a search, for all G games (device outputs, any may be NULL):
  *   pi_dev float64 [G][A]   utils.get_probablity_distribution_of_children (utils.py:46-55)
  *   q_dev  float64 [G]      root.value / root.visit (gomoku.py:140)

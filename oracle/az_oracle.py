@@ -277,7 +277,7 @@ def mcts(game, tree, board, n_iter, evaluator=None, noise=None, cache=None, rand
 
 
 def self_play(game, evaluator, n_sims, noise_fn=None, uniform_fn=None, cache=None, randint=None,
-              counters=None, max_moves=None):
+              counters=None, max_moves=None, time_budget=None):
     """<Game>.self_play.  noise_fn(move_idx)->f64[A] supplies np.random.dirichlet's draw,
     uniform_fn(move_idx)->float the uniform consumed by np.random.choice.  Returns a dict with
     boards (raw, not canonical), cells played, pis, qs, winner."""
@@ -285,6 +285,8 @@ def self_play(game, evaluator, n_sims, noise_fn=None, uniform_fn=None, cache=Non
     tree = OracleTree(game)
     player, mc = 0, 0
     boards, cells, pis, qs = [], [], [], []
+    import time as _time
+    t_start = _time.time()
     winner = None
     while True:
         tree.reset(player, mc)
@@ -316,5 +318,7 @@ def self_play(game, evaluator, n_sims, noise_fn=None, uniform_fn=None, cache=Non
             winner = -1
             break
         if max_moves is not None and mc >= max_moves:
+            break
+        if time_budget is not None and _time.time() - t_start >= time_budget:
             break
     return dict(boards=boards, cells=np.array(cells, np.int32), pis=np.stack(pis), qs=np.array(qs), winner=winner)

@@ -119,9 +119,9 @@ def test_rules_playouts(azk, ao, name, size, file):
             assert moves[j, :counts[j]].tolist() == want, (name, live[j], t)
         players = torch.full((len(live),), t & 1, dtype=torch.int32, device=dev())
         cellt = torch.from_numpy(z["actions"][ply].astype(np.int32)).to(dev())
-        nxt = azk.rules_apply_move(name, sub, players, cellt)
+        nxt = azk.rules_apply_move(name, sub, players, cellt, size)
         assert torch.equal(nxt, 1 - players)
-        w = azk.rules_check_winner(name, sub, players, cellt).cpu().numpy()
+        w = azk.rules_check_winner(name, sub, players, cellt, size).cpu().numpy()
         assert w.tolist() == z["winners"][ply].astype(np.int32).tolist()
         boards[torch.from_numpy(live).to(dev())] = sub
     final = (boards[:, 0] + 2 * boards[:, 1]).to(torch.int8).reshape(n_games, -1).cpu().numpy()
@@ -353,9 +353,11 @@ def test_engine_noise_generator_properties(azk):
     assert (n1 >= 0).all() and (u1 >= 0).all() and (u1 < 1).all()
     n3, _ = e1.gen_noise(8, 100, 3)
     assert not torch.equal(n1, n3)
-    # alpha = 0.03 concentrates mass: the largest entry of a row is typically > 0.5
-    big, _ = azk.Engine("gomoku", 512, 4, size=15).gen_noise(1, 0, 0)
-    assert 0.5 < big.max(1).values.mean().item() < 1.0
+    # alpha = 0.03 concentrates mass.  numpy's Dirichlet([0.03]*225) has E[max] = 0.255 and on average
+    # 28.65 entries above 1e-3 (4096 draws); the engine's generator must land on the same statistics.
+    big, _ = azk.Engine("gomoku", 2048, 4, size=15).gen_noise(1, 0, 0)
+    assert 0.235 < big.max(1).values.mean().item() < 0.275
+    assert 27.0 < (big > 1e-3).sum(1).double().mean().item() < 30.3
     # Dirichlet marginal mean = 1/A
     assert abs(big.mean().item() - 1 / 225) < 1e-9
     assert abs(big[:, 0].mean().item() - 1 / 225) < 0.01

@@ -1,0 +1,57 @@
+"""The functional ViT evaluator against the reference's Net (ai/nn.py) outputs recorded in
+tests/golden/nn_small.npz (weights committed as data), and the seed-0 full training config.  CPU, float32."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from pvnet import NetConfig, PolicyValueNet, init_weights, reference_key_shapes
+
+Z = load_golden("nn_small.npz")
+
+
+@pytest.mark.parametrize("ni", [0, 1])
+def test_small_nets_match_reference_outputs(ni):
+    k = f"n{ni}_"
+    c = json.loads(bytes(Z[k + "cfg_json"]).decode())
+    cfg = NetConfig(c["img_size"], c["img_size"], c["channels"], c["action_dim"], c["patch_size"], c["embed_dim"],
+                    c["num_heads"], c["depth"])
+    sd = {key[len(k) + 3:]: torch.from_numpy(Z[key]) for key in Z.files if key.startswith(k + "sd_")}
+    assert set(sd) == set(reference_key_shapes(cfg))
+    x = torch.from_numpy(Z[k + "x"])
+    for path in ("full", "cls"):
+        net = PolicyValueNet.from_state_dict(cfg, sd, path=path)
+        logits, v = net(x)
+        np.testing.assert_allclose(logits.numpy(), Z[k + "logits"], rtol=0, atol=2e-5)   # float32: 1e-5-level
+        np.testing.assert_allclose(v.numpy(), Z[k + "value"], rtol=0, atol=2e-5)
+    # round trip through state_dict
+    net2 = PolicyValueNet.from_state_dict(cfg, net.state_dict(), path="full")
+    assert torch.equal(net2(x)[0], PolicyValueNet.from_state_dict(cfg, sd, path="full")(x)[0])
+
+
+def test_full_training_config_seed0():
+    """main.py:134 shape at 15x15: same keys/shapes as the reference's state_dict, the same tensors from
+    torch.manual_seed(0), and the same outputs on four boards."""
+    cfg = NetConfig(15, 15, 2, 225, patch_size=5, embed_dim=512, num_heads=8, depth=1)
+    want = json.loads(bytes(Z["full_keys_json"]).decode())
+    assert {k: list(v) for k, v in reference_key_shapes(cfg).items()} == want
+    w = init_weights(cfg, 0)
+    sums = np.array([float(w[k].double().sum()) for k in want], np.float64)
+    np.testing.assert_array_equal(sums, Z["full_param_sums"])
+    assert sum(v.numel() for v in w.values()) == 3411682
+    x = torch.from_numpy(Z["full_x"])
+    for path in ("full", "cls"):
+        logits, v = PolicyValueNet(cfg, w, path=path)(x)
+        np.testing.assert_allclose(logits.numpy(), Z["full_logits"], rtol=0, atol=5e-5)
+        np.testing.assert_allclose(v.numpy(), Z["full_value"], rtol=0, atol=2e-5)
+    assert abs(cfg.flops_full() / 1e9 - 1.538) < 0.01 and abs(cfg.flops_cls() / 1e9 - 0.254) < 0.01
+
+
+def test_bad_state_dict_is_rejected():
+    cfg = NetConfig(7, 7, 2, 49, 5, 32, 4, 1)
+    w = init_weights(cfg, 0)
+    w.pop("norm.bias")
+    with pytest.raises(KeyError):
+        PolicyValueNet(cfg, w)
