@@ -25,7 +25,7 @@ SYMBOLS = [
     "azk_get_counters", "azk_reset_counters", "azk_check_device_error", "azk_gen_noise",
     "azk_rules_legal_moves", "azk_rules_legal_mask", "azk_rules_apply_move", "azk_rules_undo_move",
     "azk_rules_check_winner", "azk_rules_canonical", "azk_softmax_rows",
-    "azk_step_tree", "azk_step_gather", "azk_recycle_finished",
+    "azk_step_tree", "azk_step_gather", "azk_recycle_finished", "azk_nn_patch_embed",
 ]
 
 
@@ -109,6 +109,7 @@ def lib():
     L.azk_step_tree.argtypes = [vp, vp, vp, vp]
     L.azk_step_gather.argtypes = [vp, vp, vp, vp]
     L.azk_recycle_finished.argtypes = [vp, vp, vp]
+    L.azk_nn_patch_embed.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, C.c_float, vp]
     for name in SYMBOLS:
         f = getattr(L, name)
         if name not in ("azk_last_error", "azk_destroy"):
@@ -381,3 +382,19 @@ def softmax_rows(logits):
     out = torch.empty_like(logits)
     _rules_chk(lib().azk_softmax_rows(_p(logits), logits.shape[0], logits.shape[1], _p(out), _stream()))
     return out
+
+
+def nn_patch_embed(boards, wt, cpos, ln_w, ln_b, rows, cols, ksize, embed_dim, want_x=True, want_xhat=False, eps=1e-5):
+    """Token embedding on the matrix cores (azk_nn_patch_embed).  boards [n,C,R,Cc] bf16|f32 CUDA;
+    wt [D,kp] bf16; cpos [T,D] f32.  Returns (x, xhat) bf16 [n,T,D] (None where not requested)."""
+    torch = _torch()
+    assert boards.is_cuda and boards.is_contiguous() and boards.dtype in (torch.bfloat16, torch.float32)
+    n, C = boards.shape[0], boards.shape[1]
+    T = rows * cols + 1
+    x = torch.empty((n, T, embed_dim), dtype=torch.bfloat16, device=boards.device) if want_x else None
+    xh = torch.empty((n, T, embed_dim), dtype=torch.bfloat16, device=boards.device) if want_xhat else None
+    rc = lib().azk_nn_patch_embed(_p(boards), 1 if boards.dtype == torch.float32 else 0, _p(wt), _p(cpos), _p(ln_w), _p(ln_b),
+                                  _p(x), _p(xh), n, C, rows, cols, ksize, wt.shape[1], embed_dim, float(eps), _stream())
+    if rc != 0:
+        raise AzkError(f"azk_nn_patch_embed failed ({rc})")
+    return x, xh

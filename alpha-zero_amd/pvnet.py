@@ -118,7 +118,29 @@ class PolicyValueNet:
         self.w = {k_: v.to(self.device, self.dtype) for k_, v in self.master.items()}
         D, H = self.cfg.embed_dim, self.cfg.num_heads
         self.scale = 1.0 / math.sqrt(D // H)
+        self._hip = None
+        if self.device.type == "cuda" and self.dtype == torch.bfloat16:
+            self._prepare_hip_embed()
         return self
+
+    def _prepare_hip_embed(self):
+        """Operands of azk_nn_patch_embed: conv weight [D, kp] bf16 (k padded to a multiple of 16) and the
+        per-token additive term cpos [T, D] fp32 (row 0 = cls + pos[0]; row 1+j = conv bias + pos[1+j])."""
+        cfg, m = self.cfg, self.master
+        D, kreal = cfg.embed_dim, cfg.channels * cfg.patch_size ** 2
+        kp = (kreal + 15) // 16 * 16
+        if D not in (128, 256, 512) or kp // 16 not in (1, 2, 4, 5):
+            return
+        wt = torch.zeros(D, kp)
+        wt[:, :kreal] = m["embedding.patch_embed.patch_embed.weight"].reshape(D, kreal)
+        pos = m["embedding.pos_embedding"][0]
+        cpos = pos.clone()
+        cpos[0] += m["embedding.cls_token"][0, 0]
+        cpos[1:] += m["embedding.patch_embed.patch_embed.bias"]
+        dev = self.device
+        self._hip = dict(wt=wt.to(dev, torch.bfloat16).contiguous(), cpos=cpos.to(dev, torch.float32).contiguous(),
+                         ln_w=m["blocks.0.norm1.weight"].to(dev, torch.float32).contiguous(),
+                         ln_b=m["blocks.0.norm1.bias"].to(dev, torch.float32).contiguous())
 
     def eval(self):
         return self
@@ -132,11 +154,22 @@ class PolicyValueNet:
         (MIOpen's bf16 conv for C=2 falls back to per-image im2col / naive kernels: 16k launches per call.)"""
         w, cfg = self.w, self.cfg
         n, k = x.shape[0], cfg.patch_size
+        if self._hip is not None and x.is_cuda:
+            return self.embed_hip(x, want_x=True, want_xhat=False)[0]
         cols = F.unfold(x.to(self.dtype), kernel_size=k, padding=k // 2)        # [n, C*k*k, R*C]
         wmat = w["embedding.patch_embed.patch_embed.weight"].reshape(cfg.embed_dim, -1)
         t = torch.matmul(cols.transpose(1, 2), wmat.t()) + w["embedding.patch_embed.patch_embed.bias"]
         t = torch.cat([w["embedding.cls_token"].expand(n, -1, -1), t], dim=1)  # nn.py:33-34
         return t + w["embedding.pos_embedding"]                                # nn.py:35
+
+    def embed_hip(self, x, want_x, want_xhat):
+        """(tokens, LayerNorm_block0(tokens)) from the hand-written im2col + MFMA kernel (csrc/azk_nn.hip)."""
+        import azk
+        h, cfg = self._hip, self.cfg
+        if x.dtype not in (torch.bfloat16, torch.float32):
+            x = x.float()
+        return azk.nn_patch_embed(x.contiguous(), h["wt"], h["cpos"], h["ln_w"], h["ln_b"], cfg.rows, cfg.cols,
+                                  cfg.patch_size, cfg.embed_dim, want_x=want_x, want_xhat=want_xhat)
 
     def _ln(self, x, name):
         return F.layer_norm(x, (self.cfg.embed_dim,), self.w[name + ".weight"], self.w[name + ".bias"], 1e-5)
@@ -156,19 +189,22 @@ class PolicyValueNet:
         h = F.linear(F.gelu(F.linear(h, w[b + "mlp.0.weight"], w[b + "mlp.0.bias"])), w[b + "mlp.3.weight"], w[b + "mlp.3.bias"])
         return x + h                                                           # nn.py:59-60
 
-    def block_cls(self, x, i):
-        """Last block restricted to the cls row: exact, because only x[:,0] is read afterwards (nn.py:80)."""
+    def block_cls(self, x, i, h=None, x0=None):
+        """Last block restricted to the cls row: exact, because only x[:,0] is read afterwards (nn.py:80).
+        h = LayerNorm1(x) may be supplied (fused into the embedding kernel); then only x0 = x[:,0] is needed."""
         w, cfg = self.w, self.cfg
         b = f"blocks.{i}."
-        n, T, D = x.shape
+        if h is None:
+            h = self._ln(x, b + "norm1")
+            x0 = x[:, 0]
+        n, T, D = h.shape
         H, dh = cfg.num_heads, D // cfg.num_heads
-        h = self._ln(x, b + "norm1")
         Wi, bi = w[b + "attn.in_proj_weight"], w[b + "attn.in_proj_bias"]
         q = F.linear(h[:, 0], Wi[:D], bi[:D]).view(n, H, 1, dh)
         kv = F.linear(h, Wi[D:], bi[D:]).view(n, T, 2, H, dh)
         k, v = kv[:, :, 0].transpose(1, 2), kv[:, :, 1].transpose(1, 2)        # [n,H,T,dh]
         a = F.scaled_dot_product_attention(q, k, v).reshape(n, D)
-        x0 = x[:, 0] + F.linear(a, w[b + "attn.out_proj.weight"], w[b + "attn.out_proj.bias"])
+        x0 = x0 + F.linear(a, w[b + "attn.out_proj.weight"], w[b + "attn.out_proj.bias"])
         h = self._ln(x0, b + "norm2")
         h = F.linear(F.gelu(F.linear(h, w[b + "mlp.0.weight"], w[b + "mlp.0.bias"])), w[b + "mlp.3.weight"], w[b + "mlp.3.bias"])
         return x0 + h                                                          # [n, D]
@@ -182,8 +218,15 @@ class PolicyValueNet:
     @torch.no_grad()
     def forward(self, x, path=None):
         path = path or self.path
-        x = self.embed(x.to(self.device))
+        x = x.to(self.device)
         depth = self.cfg.depth
+        if path == "cls" and depth == 1 and self._hip is not None:
+            # tokens are never materialised: the embedding kernel emits LayerNorm1(tokens) and the cls residual
+            # row is the constant cls + pos[0]
+            _, xhat = self.embed_hip(x, want_x=False, want_xhat=True)
+            x0 = self._hip["cpos"][0].to(self.dtype).expand(x.shape[0], -1)
+            return self.heads(self.block_cls(None, 0, h=xhat, x0=x0))
+        x = self.embed(x)
         if path == "full":
             for i in range(depth):
                 x = self.block_full(x, i)

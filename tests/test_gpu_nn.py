@@ -1,0 +1,65 @@
+"""GPU tests of the hand-written embedding kernel (csrc/azk_nn.hip) and the bf16 evaluator paths.
+Numerics reference = the same op in plain PyTorch fp32 (tolerances are bf16-level and stated per test)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden
+from pvnet import NetConfig, PolicyValueNet
+
+pytestmark = pytest.mark.gpu
+
+
+def random_boards(n, C, R, Cc, seed):
+    rng = np.random.RandomState(seed)
+    x = np.zeros((n, C, R, Cc), np.float32)
+    for b in range(n):
+        dens = rng.uniform(0, 0.9)
+        u = rng.rand(R, Cc)
+        x[b, 0] = u < dens / 2
+        x[b, 1] = (u >= dens / 2) & (u < dens)
+        if C == 3:
+            x[b, 2] = rng.randint(2)
+    return torch.from_numpy(x)
+
+
+@pytest.mark.parametrize("R,Cc,C,k,D,heads", [(15, 15, 2, 5, 512, 8), (7, 7, 2, 5, 256, 8), (6, 7, 3, 5, 128, 4),
+                                              (3, 3, 3, 3, 128, 4), (15, 15, 2, 3, 256, 4)])
+def test_patch_embed_kernel_vs_torch_fp32(R, Cc, C, k, D, heads):
+    cfg = NetConfig(R, Cc, C, R * Cc if C == 2 else (7 if R == 6 else 9), k, D, heads, 1)
+    net32 = PolicyValueNet(cfg, seed=3, device="cuda", dtype=torch.float32, path="full")
+    net16 = PolicyValueNet(cfg, weights=net32.state_dict(), device="cuda", dtype=torch.bfloat16, path="full")
+    assert net16._hip is not None
+    n = 37
+    xb = random_boards(n, C, R, Cc, 1).cuda()
+    ref = net32.embed(xb)                                        # unfold + fp32 GEMM
+    ref_hat = F.layer_norm(ref, (D,), net32.w["blocks.0.norm1.weight"], net32.w["blocks.0.norm1.bias"], 1e-5)
+    for inp in (xb, xb.to(torch.bfloat16)):
+        x, xhat = net16.embed_hip(inp, want_x=True, want_xhat=True)
+        # operands are bf16 (weights rounded to 8 bits), accumulation fp32, output rounded to bf16:
+        # |err| <= ~2^-8 * (|x| + sum|w|) ; tokens are O(1..4)
+        torch.testing.assert_close(x.float(), ref, rtol=2e-2, atol=3e-2)
+        torch.testing.assert_close(xhat.float(), ref_hat, rtol=2e-2, atol=3e-2)
+    # cls row is exactly cls + pos[0] rounded once
+    want0 = (net32.w["embedding.cls_token"][0, 0] + net32.w["embedding.pos_embedding"][0, 0]).to(torch.bfloat16)
+    assert torch.equal(x[:, 0], want0.expand(n, -1))
+
+
+def test_evaluator_paths_agree_and_match_reference_kat():
+    """bf16 evaluator (hand-written embed + torch GEMMs) vs the reference's fp32 outputs for the seed-0 training
+    config (tests/golden/nn_small.npz 'full_*'): logits within 3e-2 absolute (bf16 ~ 2e-2)."""
+    z = load_golden("nn_small.npz")
+    cfg = NetConfig(15, 15, 2, 225, 5, 512, 8, 1)
+    x = torch.from_numpy(z["full_x"]).cuda()
+    outs = {}
+    for path in ("full", "cls"):
+        net = PolicyValueNet(cfg, seed=0, device="cuda", dtype=torch.bfloat16, path=path)
+        logits, v = net(x.to(torch.bfloat16))
+        outs[path] = logits
+        np.testing.assert_allclose(logits.cpu().numpy(), z["full_logits"], rtol=0, atol=4e-2)
+        np.testing.assert_allclose(v.cpu().numpy(), z["full_value"], rtol=0, atol=2e-2)
+    torch.testing.assert_close(outs["full"], outs["cls"], rtol=0, atol=3e-2)
+    net32 = PolicyValueNet(cfg, seed=0, device="cuda", dtype=torch.float32, path="cls")
+    l32, v32 = net32(x)
+    np.testing.assert_allclose(l32.cpu().numpy(), z["full_logits"], rtol=0, atol=1e-4)
