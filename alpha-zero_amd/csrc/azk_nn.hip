@@ -1,209 +1,219 @@
 // azk_nn.hip - hand-written CDNA4 kernels for the policy-value network's token embedding (ai/nn.py:5-36):
 //   tokens[n, 0, :]   = cls_token + pos_embedding[0]
 //   tokens[n, 1+j, :] = Conv2d(C -> D, k x k, stride 1, 'same')(board)[:, r, c] + pos_embedding[1+j]      j = r*cols + c
-// lowered to an im2col GEMM on the matrix cores: per board A[T x KP] (0/1 patches gathered from the LDS-resident
-// board, KP = C*k*k rounded up to 16) times B[KP x D] (the conv weight, held in registers for the kernel's
-// lifetime) with v_mfma_f32_32x32x16_bf16, fp32 accumulate.  The epilogue adds bias + positional embedding,
-// optionally applies the first block's LayerNorm (nn.py:53) in fp32 and stores whole 1 KiB rows (16 B per lane).
+// lowered to an im2col GEMM on the matrix cores (v_mfma_f32_16x16x32_bf16, fp32 accumulate).
+//
+// Structure (one wavefront = one 16-token x D output tile, no workgroup barriers in the main loop):
+//   * the conv weight [D][KP] is staged ONCE per workgroup into LDS in MFMA-fragment order, so every B-fragment
+//     read is a conflict-free, lane-linear ds_read_b128;
+//   * the board is a bit string held across the wave's lanes (one ballot per 64 cells); each lane assembles the
+//     k*k*C-bit patch of its token with funnel shifts and expands its 8 k-values to a bf16 A fragment - the
+//     im2col matrix never exists in memory;
+//   * bias + positional embedding enter as the accumulator's initial value (coalesced fp32 loads);
+//   * the column -> accumulator map is permuted so each lane ends up with 8 consecutive columns per group:
+//     LayerNorm statistics need only a 16-lane butterfly, and stores are 16 B per lane, 256 B contiguous.
 // The kernel is bound by its HBM writes (T*D*2 bytes per board per output), not by MFMA.
 #include <hip/hip_runtime.h>
 #include <hip/hip_bf16.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "azk.h"
 
 namespace {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 struct EmbedArgs {
-    const void *boards;        // [n][C][R][Cc] bf16 or f32
+    const void *boards;        // [n][C][R][Cc] bf16 or f32, values 0/1
     int boards_f32;
     const __hip_bfloat16 *wt;  // [D][KP] conv weight, k index = ch*k*k + ky*k + kx, zero padded
     const float *cpos;         // [T][D]: row 0 = cls + pos[0]; row 1+j = conv bias + pos[1+j]
     const float *ln_w, *ln_b;  // [D] LayerNorm affine (used when xhat != nullptr)
     __hip_bfloat16 *x;         // [n][T][D] tokens (may be null)
     __hip_bfloat16 *xhat;      // [n][T][D] LayerNorm(tokens) (may be null)
-    int n, C, R, Cc, ksz, KP, T;
+    int n, C, R, Cc, ksz, T;
     float eps;
+    int ablate;                // debug only (AZK_EMBED_ABLATE): 1 no cpos loads, 2 no stores, 4 no MFMA, 8 no patch build
 };
 
-__device__ __forceinline__ float bf16_bits_to_f32(unsigned short u) { return __uint_as_float((unsigned)u << 16); }
+typedef __attribute__((ext_vector_type(8))) float f32x8;
 
-// XOR swizzle of the 16-byte chunk index inside an A-tile row (conflict-free ds_read_b128 of the fragments);
-// only the leading power-of-two group of chunks is permuted so every index stays inside the row.
-template <int KS>
-__device__ __forceinline__ int swz(int chunk, int row) {
-    constexpr int NCH = 2 * KS;
-    constexpr int SW = NCH >= 8 ? 7 : (NCH >= 4 ? 3 : (NCH >= 2 ? 1 : 0));
-    return chunk <= SW ? (chunk ^ (row & SW)) : chunk;
+// fp32 -> bf16 (round to nearest even) as plain vector casts: hipcc lowers them to v_cvt_pk_bf16_f32
+__device__ __forceinline__ uint4 pack8(const float *v) {
+    f32x8 f;
+#pragma unroll
+    for (int q = 0; q < 8; q++) f[q] = v[q];
+    union { bf16x8 b; uint4 u; } r;
+    r.b = __builtin_convertvector(f, bf16x8);
+    return r.u;
 }
 
-// NT = 32-column tiles per wave; D = 4 waves * NT * 32.  KS = KP / 16 k-steps.
-template <int NT, int KS>
-__global__ __launch_bounds__(256) void k_embed(EmbedArgs a) {
-    constexpr int D = 128 * NT;
-    constexpr int KP = 16 * KS;
+// NG = D / 128 column groups (each lane owns 8 consecutive columns per group); KS = KP / 32 k-steps.
+template <int NG, int KS, bool WANT_X, bool WANT_XHAT>
+__global__ __launch_bounds__(256, 2) void k_embed(EmbedArgs a) {
+    constexpr int D = 128 * NG, KP = 32 * KS, NACC = 8 * NG;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // LDS: stage f32 [32][D] | A tile bf16 [2][32][KP] | board u8 [C*R*Cc]
-    float *stage = (float *)smem;
-    unsigned short *atile = (unsigned short *)(smem + 32 * D * 4);
-    unsigned char *board = smem + 32 * D * 4 + 2 * 32 * KP * 2;
+    uint4 *bimg = (uint4 *)smem;                       // [NACC][KS][64 lanes] 16-byte B fragments
+    float *lnw = (float *)(smem + NACC * KS * 64 * 16);  // [D] LayerNorm weight, then [D] bias
+    float *lnb = lnw + D;
 
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int RC = a.R * a.Cc, T = a.T, kk = a.ksz * a.ksz, pad = a.ksz / 2, Kreal = a.C * kk;
-    const int mtiles = (T + 31) >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
 
-    // B fragments: conv weight columns owned by this wave, resident in registers for the whole kernel
-    bf16x8 bfrag[NT][KS];
-#pragma unroll
-    for (int nt = 0; nt < NT; nt++)
+    // ---- stage the weight in fragment order: fragment (acc, s) of lane l = wt[col(acc, l)][32 s + 8 (l>>4) .. +8] ----
+    for (int f = tid; f < NACC * KS * 64; f += 256) {
+        const int l = f & 63, s = (f >> 6) % KS, acc = (f >> 6) / KS;
+        const int col = 128 * (acc >> 3) + 8 * (l & 15) + (acc & 7);
+        bimg[f] = *(const uint4 *)(a.wt + (size_t)col * KP + 32 * s + 8 * (l >> 4));
+    }
+    if (WANT_XHAT)
+        for (int i = tid; i < D; i += 256) { lnw[i] = a.ln_w[i]; lnb[i] = a.ln_b[i]; }
+    __syncthreads();
+
+    const int RC = a.R * a.Cc, T = a.T, ksz = a.ksz, kk = ksz * ksz, pad = ksz / 2, ncell = a.C * RC;
+    const int tiles_per_leaf = (T + 15) >> 4;
+    const int nwaves = gridDim.x * 4;
+
+
+    // one wavefront owns one board: its bit string is built once, then the wave walks the board's 16-token tiles
+    for (int leaf = blockIdx.x * 4 + wave; leaf < a.n; leaf += nwaves) {
+        unsigned wbits = 0;                             // lane i holds bits [32 (i-1), 32 i) of the board bit string (lane 0: zeros)
+        if (!(a.ablate & 8)) {
+            for (int q = 0; q * 64 < ncell; q++) {
+                const int e = q * 64 + lane;
+                bool on = false;
+                if (e < ncell)
+                    on = a.boards_f32 ? ((const float *)a.boards)[(size_t)leaf * ncell + e] != 0.0f
+                                      : (((const unsigned short *)a.boards)[(size_t)leaf * ncell + e] & 0x7fff) != 0;
+                const unsigned long long m = __ballot(on);
+                if ((lane - 1) >> 1 == q && lane >= 1) wbits = ((lane - 1) & 1) ? (unsigned)(m >> 32) : (unsigned)m;
+            }
+        }
+      for (int tile = 0; tile < tiles_per_leaf; tile++) {
+        // ---- this lane's token (A-fragment row l&15) and its patch bits ----
+        const int t = tile * 16 + l15;
+        unsigned long long plo = 0, phi = 0;
+        {
+            const int j = t - 1, r = j / a.Cc, c = j - r * a.Cc;
+            const bool live = t >= 1 && t < T;
+            unsigned colmask = 0;
+            for (int kx = 0; kx < ksz; kx++) { const int cc = c + kx - pad; if (cc >= 0 && cc < a.Cc) colmask |= 1u << kx; }
+            for (int ch = 0; ch < ((a.ablate & 8) ? 0 : a.C); ch++)
+                for (int ky = 0; ky < ksz; ky++) {
+                    const int rr = r + ky - pad;
+                    // every lane takes part in the shuffles; dead rows contribute zero bits
+                    const int off = 32 + ch * RC + (rr < 0 ? 0 : (rr >= a.R ? a.R - 1 : rr)) * a.Cc + (c - pad);
+                    const int wi = off >> 5, sh = off & 31;
+                    const unsigned lo = __shfl(wbits, wi), hi = __shfl(wbits, wi + 1);
+                    unsigned bits = __funnelshift_r(lo, hi, sh) & colmask;
+                    if (!live || rr < 0 || rr >= a.R) bits = 0;
+                    const int p0 = ch * kk + ky * ksz;
+                    if (p0 < 64) { plo |= (unsigned long long)bits << p0; if (p0 + ksz > 64) phi |= (unsigned long long)bits >> (64 - p0); }
+                    else phi |= (unsigned long long)bits << (p0 - 64);
+                }
+        }
+        bf16x8 afrag[KS];
 #pragma unroll
         for (int s = 0; s < KS; s++) {
-            const int col = wave * 32 * NT + nt * 32 + (lane & 31);
-            bfrag[nt][s] = *(const bf16x8 *)(a.wt + (size_t)col * KP + 16 * s + 8 * (lane >> 5));
-        }
-
-    // im2col builder role: thread -> (row = tid >> 3 of the 32-row tile, 8 consecutive k's starting at 8*(tid & 7) [+64 per pass])
-    const int brow = tid >> 3;
-
-    for (int leaf = blockIdx.x; leaf < a.n; leaf += gridDim.x) {
-        __syncthreads();                                          // previous leaf's board / stage fully consumed
-        for (int i = tid; i < a.C * RC; i += 256) {
-            float v = a.boards_f32 ? ((const float *)a.boards)[(size_t)leaf * a.C * RC + i]
-                                   : bf16_bits_to_f32(((const unsigned short *)a.boards)[(size_t)leaf * a.C * RC + i]);
-            board[i] = v != 0.0f ? 1 : 0;
-        }
-        __syncthreads();
-
-        for (int mt = 0; mt < mtiles; mt++) {
-            unsigned short *at = atile + (mt & 1) * 32 * KP;
-            // ---- build the 32 x KP im2col tile (token t = mt*32 + brow; t == 0 is the cls row: all zeros) ----
-            {
-                const int t = mt * 32 + brow;
-                const int j = t - 1;
-                const int r = j / a.Cc, c = j - r * a.Cc;
-                const bool live = t >= 1 && t < T;
-                for (int kc = tid & 7; kc < KP / 8; kc += 8) {
-                    unsigned short v8[8];
+            const int b0 = 32 * s + 8 * l4;
+            const unsigned byte = (unsigned)((b0 < 64 ? (plo >> b0) : (phi >> (b0 - 64))) & 0xff);
+            union { bf16x8 v; unsigned short h[8]; } u;
 #pragma unroll
-                    for (int q = 0; q < 8; q++) {
-                        const int k = kc * 8 + q;
-                        unsigned short v = 0;
-                        if (live && k < Kreal) {
-                            const int ch = k / kk, rem = k - ch * kk, ky = rem / a.ksz, kx = rem - ky * a.ksz;
-                            const int rr = r + ky - pad, cc = c + kx - pad;
-                            if (rr >= 0 && rr < a.R && cc >= 0 && cc < a.Cc && board[ch * RC + rr * a.Cc + cc]) v = 0x3F80;  // bf16 1.0
-                        }
-                        v8[q] = v;
-                    }
-                    const int chunk = swz<KS>(kc, brow);
-                    uint4 pk;
-                    pk.x = v8[0] | ((unsigned)v8[1] << 16); pk.y = v8[2] | ((unsigned)v8[3] << 16);
-                    pk.z = v8[4] | ((unsigned)v8[5] << 16); pk.w = v8[6] | ((unsigned)v8[7] << 16);
-                    *(uint4 *)(at + brow * KP + chunk * 8) = pk;
-                }
+            for (int q = 0; q < 8; q++) u.h[q] = ((byte >> q) & 1) ? 0x3F80 : 0;
+            afrag[s] = u.v;
+        }
+        // ---- accumulators start at bias + positional embedding (C/D map: col = lane&15 -> permuted column,
+        //      row = 4 (lane>>4) + reg) ----
+        f32x4 acc[NACC];
+        int trow[4];
+#pragma unroll
+        for (int r4 = 0; r4 < 4; r4++) { const int tt = tile * 16 + 4 * l4 + r4; trow[r4] = tt < T ? tt : T - 1; }
+#pragma unroll
+        for (int g = 0; g < NG; g++)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; r4++) {
+                const float *src = a.cpos + ((a.ablate & 1) ? 0 : (size_t)trow[r4] * D) + 128 * g + 8 * l15;
+                const f32x4 c0 = *(const f32x4 *)src, c1 = *(const f32x4 *)(src + 4);
+                acc[g * 8 + 0][r4] = c0[0]; acc[g * 8 + 1][r4] = c0[1]; acc[g * 8 + 2][r4] = c0[2]; acc[g * 8 + 3][r4] = c0[3];
+                acc[g * 8 + 4][r4] = c1[0]; acc[g * 8 + 5][r4] = c1[1]; acc[g * 8 + 6][r4] = c1[2]; acc[g * 8 + 7][r4] = c1[3];
             }
-            __syncthreads();
-            // ---- MFMA: acc[nt] (32 x 32) += A(32 x KP) * B(KP x 32) ----
-            f32x16 acc[NT];
+        // ---- MFMA: acc[n] (16 x 16) += A (16 x KP) * B (KP x 16) ----
+        if (!(a.ablate & 4))
 #pragma unroll
-            for (int nt = 0; nt < NT; nt++)
-#pragma unroll
-                for (int i = 0; i < 16; i++) acc[nt][i] = 0.f;
+        for (int n = 0; n < NACC; n++) {
 #pragma unroll
             for (int s = 0; s < KS; s++) {
-                const int row = lane & 31, chunk = swz<KS>(2 * s + (lane >> 5), row);
-                const bf16x8 af = *(const bf16x8 *)(at + row * KP + chunk * 8);
-#pragma unroll
-                for (int nt = 0; nt < NT; nt++) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfrag[nt][s], acc[nt], 0, 0, 0);
+                union { uint4 u; bf16x8 v; } bf;
+                bf.u = bimg[(n * KS + s) * 64 + lane];
+                acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[s], bf.v, acc[n], 0, 0, 0);
             }
-            // ---- epilogue 1: + (bias + pos) and stage the fp32 tile in LDS (C/D map: col = lane&31, row = (i&3)+8*(i>>2)+4*(lane>>5)) ----
-#pragma unroll
-            for (int nt = 0; nt < NT; nt++)
-#pragma unroll
-                for (int i = 0; i < 16; i++) {
-                    const int row = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
-                    const int col = wave * 32 * NT + nt * 32 + (lane & 31);
-                    const int t = mt * 32 + row;
-                    const float v = acc[nt][i] + (t < T ? a.cpos[(size_t)t * D + col] : 0.f);
-                    stage[row * D + col] = v;
-                }
-            __syncthreads();
-            // ---- epilogue 2: each wave finishes 8 rows: optional LayerNorm in fp32, bf16 pack, whole-row stores ----
-            for (int rr = 0; rr < 8; rr++) {
-                const int row = wave * 8 + rr, t = mt * 32 + row;
-                if (t >= T) break;
-                const size_t orow = ((size_t)leaf * T + t) * D;
-                {
-                    const int col = lane * 8;                    // D <= 512: one pass of 64 lanes x 8 columns covers the row
-                    const bool act = col < D;
-                    float v[8];
-                    if (act) {
-                        const f32x4 v0 = *(const f32x4 *)(stage + row * D + col);
-                        const f32x4 v1 = *(const f32x4 *)(stage + row * D + col + 4);
-                        v[0] = v0[0]; v[1] = v0[1]; v[2] = v0[2]; v[3] = v0[3]; v[4] = v1[0]; v[5] = v1[1]; v[6] = v1[2]; v[7] = v1[3];
-                    } else {
-#pragma unroll
-                        for (int q = 0; q < 8; q++) v[q] = 0.f;
-                    }
-                    if (a.x && act) {
-                        unsigned short h[8];
-#pragma unroll
-                        for (int q = 0; q < 8; q++) h[q] = __bfloat16_as_ushort(__float2bfloat16(v[q]));
-                        uint4 pk;
-                        pk.x = h[0] | ((unsigned)h[1] << 16); pk.y = h[2] | ((unsigned)h[3] << 16);
-                        pk.z = h[4] | ((unsigned)h[5] << 16); pk.w = h[6] | ((unsigned)h[7] << 16);
-                        *(uint4 *)(a.x + orow + col) = pk;
-                    }
-                    if (a.xhat) {
-                        float s = 0.f;
-#pragma unroll
-                        for (int q = 0; q < 8; q++) s += v[q];
-#pragma unroll
-                        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-                        const float mean = s / (float)D;
-                        float ss = 0.f;
-                        if (act) {
-#pragma unroll
-                            for (int q = 0; q < 8; q++) { const float dlt = v[q] - mean; ss += dlt * dlt; }
-                        }
-#pragma unroll
-                        for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
-                        const float rstd = rsqrtf(ss / (float)D + a.eps);
-                        if (act) {
-                            unsigned short h[8];
-#pragma unroll
-                            for (int q = 0; q < 8; q++)
-                                h[q] = __bfloat16_as_ushort(__float2bfloat16((v[q] - mean) * rstd * a.ln_w[col + q] + a.ln_b[col + q]));
-                            uint4 pk;
-                            pk.x = h[0] | ((unsigned)h[1] << 16); pk.y = h[2] | ((unsigned)h[3] << 16);
-                            pk.z = h[4] | ((unsigned)h[5] << 16); pk.w = h[6] | ((unsigned)h[7] << 16);
-                            *(uint4 *)(a.xhat + orow + col) = pk;
-                        }
-                    }
-                }
-            }
-            // the next tile's A build writes the other A buffer; `stage` is rewritten only after the next tile's
-            // post-build barrier, which every wave reaches after finishing its rows above
+            if ((n & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // keep B-fragment prefetch to 4 accumulators (VGPR budget)
         }
+        // ---- epilogue: rows 4 (lane>>4) + r4, this lane's columns 128 g + 8 (lane&15) + q ----
+#pragma unroll
+        for (int r4 = 0; r4 < 4; r4++) {
+            const int tt = tile * 16 + 4 * l4 + r4;
+            const bool ok = tt < T && !((a.ablate & 2) && tt != 7777);
+            const size_t orow = ((size_t)leaf * T + (ok ? tt : 0)) * D;
+            float mean = 0.f, rstd = 0.f;
+            if (WANT_XHAT) {
+                float s = 0.f;
+#pragma unroll
+                for (int n = 0; n < NACC; n++) s += acc[n][r4];
+#pragma unroll
+                for (int off = 1; off < 16; off <<= 1) s += __shfl_xor(s, off);
+                mean = s * (1.0f / (float)D);
+                float ss = 0.f;
+#pragma unroll
+                for (int n = 0; n < NACC; n++) { const float dl = acc[n][r4] - mean; ss += dl * dl; }
+#pragma unroll
+                for (int off = 1; off < 16; off <<= 1) ss += __shfl_xor(ss, off);
+                rstd = rsqrtf(ss * (1.0f / (float)D) + a.eps);
+            }
+#pragma unroll
+            for (int g = 0; g < NG; g++) {
+                float v[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) v[q] = acc[g * 8 + q][r4];
+                if (WANT_X && ok) *(uint4 *)(a.x + orow + 128 * g + 8 * l15) = pack8(v);
+                if (WANT_XHAT) {
+                    const f32x4 w0 = *(const f32x4 *)(lnw + 128 * g + 8 * l15), w1 = *(const f32x4 *)(lnw + 128 * g + 8 * l15 + 4);
+                    const f32x4 b0 = *(const f32x4 *)(lnb + 128 * g + 8 * l15), b1 = *(const f32x4 *)(lnb + 128 * g + 8 * l15 + 4);
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        v[q] = (v[q] - mean) * rstd * w0[q] + b0[q];
+                        v[q + 4] = (v[q + 4] - mean) * rstd * w1[q] + b1[q];
+                    }
+                    if (ok) *(uint4 *)(a.xhat + orow + 128 * g + 8 * l15) = pack8(v);
+                }
+            }
+        }
+      }
     }
 }
 
-template <int NT, int KS>
-int launch_embed(const EmbedArgs &a, hipStream_t st) {
-    constexpr int D = 128 * NT, KP = 16 * KS;
-    const int lds = 32 * D * 4 + 2 * 32 * KP * 2 + ((a.C * a.R * a.Cc + 15) & ~15);
-    int grid = a.n < 512 ? a.n : 512;
+template <int NG, int KS, bool WX, bool WH>
+int launch_embed2(const EmbedArgs &a, hipStream_t st) {
+    constexpr int NACC = 8 * NG;
+    const int lds = NACC * KS * 64 * 16 + 2 * 128 * NG * 4;
+    long long blocks = ((long long)a.n + 3) / 4;
+    if (blocks > 512) blocks = 512;                    // 2 workgroups per CU resident (LDS + VGPR budget)
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void *)k_embed<NT, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return AZK_ERR_HIP;
+        if (hipFuncSetAttribute((const void *)k_embed<NG, KS, WX, WH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return AZK_ERR_HIP;
         attr_set = true;
     }
-    k_embed<NT, KS><<<grid, 256, lds, st>>>(a);
+    k_embed<NG, KS, WX, WH><<<(unsigned)blocks, 256, lds, st>>>(a);
     return hipGetLastError() == hipSuccess ? AZK_OK : AZK_ERR_HIP;
+}
+
+template <int NG, int KS>
+int launch_embed(const EmbedArgs &a, hipStream_t st) {
+    if (a.x && a.xhat) return launch_embed2<NG, KS, true, true>(a, st);
+    if (a.xhat) return launch_embed2<NG, KS, false, true>(a, st);
+    return launch_embed2<NG, KS, true, false>(a, st);
 }
 
 }  // namespace
@@ -215,19 +225,21 @@ extern "C" int32_t azk_nn_patch_embed(const void *boards_dev, int32_t boards_are
                                       float ln_eps, void *stream) {
     if (!boards_dev || !wt_bf16_dev || !cpos_dev || (!x_out_bf16_dev && !xhat_out_bf16_dev)) return AZK_ERR_ARG;
     if (xhat_out_bf16_dev && (!ln_w_dev || !ln_b_dev)) return AZK_ERR_ARG;
-    if (n < 0 || channels < 1 || rows < 1 || cols < 1 || ksize < 1 || (ksize & 1) == 0) return AZK_ERR_ARG;
-    if (kp < channels * ksize * ksize || kp % 16 != 0) return AZK_ERR_ARG;
+    if (n < 0 || channels < 1 || rows < 1 || cols < 1 || ksize < 1 || (ksize & 1) == 0 || ksize > 7) return AZK_ERR_ARG;
+    if (kp < channels * ksize * ksize || kp % 32 != 0 || kp > 128) return AZK_ERR_ARG;
+    if (channels * rows * cols > 62 * 32) return AZK_ERR_ARG;         // the board bit string lives in one wave's lanes
     if (n == 0) return AZK_OK;
     EmbedArgs a;
     a.boards = boards_dev; a.boards_f32 = boards_are_f32; a.wt = (const __hip_bfloat16 *)wt_bf16_dev; a.cpos = cpos_dev;
     a.ln_w = ln_w_dev; a.ln_b = ln_b_dev; a.x = (__hip_bfloat16 *)x_out_bf16_dev; a.xhat = (__hip_bfloat16 *)xhat_out_bf16_dev;
-    a.n = n; a.C = channels; a.R = rows; a.Cc = cols; a.ksz = ksize; a.KP = kp; a.T = rows * cols + 1; a.eps = ln_eps;
+    { const char *ab = getenv("AZK_EMBED_ABLATE"); a.ablate = ab ? atoi(ab) : 0; }
+    a.n = n; a.C = channels; a.R = rows; a.Cc = cols; a.ksz = ksize; a.T = rows * cols + 1; a.eps = ln_eps;
     hipStream_t st = (hipStream_t)stream;
-    const int ks = kp / 16;
-#define CASE(NT_, KS_) if (embed_dim == 128 * NT_ && ks == KS_) return launch_embed<NT_, KS_>(a, st)
-    CASE(4, 4); CASE(4, 5); CASE(4, 2); CASE(4, 1);
-    CASE(2, 4); CASE(2, 5); CASE(2, 2); CASE(2, 1);
-    CASE(1, 4); CASE(1, 5); CASE(1, 2); CASE(1, 1);
+    const int ks = kp / 32;
+#define CASE(NG_, KS_) if (embed_dim == 128 * NG_ && ks == KS_) return launch_embed<NG_, KS_>(a, st)
+    CASE(4, 2); CASE(4, 1); CASE(4, 3);
+    CASE(2, 2); CASE(2, 1); CASE(2, 3);
+    CASE(1, 2); CASE(1, 1); CASE(1, 3);
 #undef CASE
     return AZK_ERR_ARG;   // unsupported (embed_dim, kp): the caller keeps its generic path
 }

@@ -128,8 +128,8 @@ class PolicyValueNet:
         per-token additive term cpos [T, D] fp32 (row 0 = cls + pos[0]; row 1+j = conv bias + pos[1+j])."""
         cfg, m = self.cfg, self.master
         D, kreal = cfg.embed_dim, cfg.channels * cfg.patch_size ** 2
-        kp = (kreal + 15) // 16 * 16
-        if D not in (128, 256, 512) or kp // 16 not in (1, 2, 4, 5):
+        kp = (kreal + 31) // 32 * 32
+        if D not in (128, 256, 512) or kp // 32 not in (1, 2, 3) or cfg.channels * cfg.rows * cfg.cols > 62 * 32:
             return
         wt = torch.zeros(D, kp)
         wt[:, :kreal] = m["embedding.patch_embed.patch_embed.weight"].reshape(D, kreal)

@@ -186,14 +186,15 @@ int32_t azk_rules_canonical(int32_t game, int32_t rows, int32_t cols, const floa
 
 /* ---- policy-value network: token embedding on the matrix cores (ai/nn.py:5-36) ------------------------------
  * tokens[b,0,:] = cls + pos[0];  tokens[b,1+j,:] = Conv2d(C->D, k x k, stride 1, pad k/2)(board)[:, j] + pos[1+j]
- * as an im2col GEMM with v_mfma_f32_32x32x16_bf16 (fp32 accumulate), epilogue fused: + bias + positional embedding,
+ * as an im2col GEMM on the matrix cores (fp32 accumulate), epilogue fused: + bias + positional embedding,
  * and optionally the first block's LayerNorm (nn.py:53, eps 1e-5) so the block's Q/K/V GEMM reads xhat directly.
  *   boards_dev        [n][C][R][Cc] bf16 (boards_are_f32 = 0) or float32 (1), values 0/1 (the engine's leaf batch)
- *   wt_bf16_dev       [D][kp] bf16: conv weight reshaped [D][C*k*k], zero padded to kp (multiple of 16)
+ *   wt_bf16_dev       [D][kp] bf16: conv weight reshaped [D][C*k*k], zero padded to kp (multiple of 32)
  *   cpos_dev          [T][D] float32: row 0 = cls + pos[0], row 1+j = conv bias + pos[1+j]   (T = R*Cc + 1)
  *   ln_w_dev/ln_b_dev [D] float32 (required when xhat_out is given)
  *   x_out / xhat_out  [n][T][D] bf16, either may be NULL
- * Supported: embed_dim in {128, 256, 512}, kp/16 in {1, 2, 4, 5}; anything else returns AZK_ERR_ARG. */
+ * Supported: embed_dim in {128, 256, 512}, kp in {32, 64, 96}, C*R*Cc <= 1984; anything else returns AZK_ERR_ARG
+ * (the caller keeps a generic path).  v_mfma_f32_16x16x32_bf16; one wavefront per 16-token x D tile. */
 int32_t azk_nn_patch_embed(const void *boards_dev, int32_t boards_are_f32, const void *wt_bf16_dev,
                            const float *cpos_dev, const float *ln_w_dev, const float *ln_b_dev,
                            void *x_out_bf16_dev, void *xhat_out_bf16_dev, int32_t n, int32_t channels,
