@@ -25,7 +25,7 @@ SYMBOLS = [
     "azk_get_counters", "azk_reset_counters", "azk_check_device_error", "azk_gen_noise",
     "azk_rules_legal_moves", "azk_rules_legal_mask", "azk_rules_apply_move", "azk_rules_undo_move",
     "azk_rules_check_winner", "azk_rules_canonical", "azk_softmax_rows",
-    "azk_step_tree", "azk_step_gather", "azk_recycle_finished", "azk_nn_patch_embed",
+    "azk_step_tree", "azk_step_gather", "azk_recycle_finished", "azk_nn_patch_embed", "azk_nn_cls_attention",
 ]
 
 
@@ -109,6 +109,7 @@ def lib():
     L.azk_step_tree.argtypes = [vp, vp, vp, vp]
     L.azk_step_gather.argtypes = [vp, vp, vp, vp]
     L.azk_recycle_finished.argtypes = [vp, vp, vp]
+    L.azk_nn_cls_attention.argtypes = [vp, vp, vp, i32, vp, i32, i32, i32, i32, vp]
     L.azk_nn_patch_embed.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, C.c_float, vp]
     for name in SYMBOLS:
         f = getattr(L, name)
@@ -398,3 +399,18 @@ def nn_patch_embed(boards, wt, cpos, ln_w, ln_b, rows, cols, ksize, embed_dim, w
     if rc != 0:
         raise AzkError(f"azk_nn_patch_embed failed ({rc})")
     return x, xh
+
+
+def nn_cls_attention(xhat, m, c, num_heads):
+    """z[b,h,:] = sum_t softmax_t(xhat[b,t,:] . m[.,h,:] + c[.,h]) * xhat[b,t,:]  (azk_nn_cls_attention).
+    xhat bf16 [n,T,D]; m f32 [H,D] (shared) or [n,H,D]; c f32 [H] or [n,H].  Returns z bf16 [n,H,D]."""
+    torch = _torch()
+    assert xhat.is_cuda and xhat.dtype == torch.bfloat16 and xhat.is_contiguous()
+    n, T, D = xhat.shape
+    per_board = 1 if m.dim() == 3 else 0
+    m = m.to(torch.float32).contiguous(); c = c.to(torch.float32).contiguous()
+    z = torch.empty((n, num_heads, D), dtype=torch.bfloat16, device=xhat.device)
+    rc = lib().azk_nn_cls_attention(_p(xhat), _p(m), _p(c), per_board, _p(z), n, T, D, num_heads, _stream())
+    if rc != 0:
+        raise AzkError(f"azk_nn_cls_attention failed ({rc})")
+    return z

@@ -243,3 +243,139 @@ extern "C" int32_t azk_nn_patch_embed(const void *boards_dev, int32_t boards_are
 #undef CASE
     return AZK_ERR_ARG;   // unsupported (embed_dim, kp): the caller keeps its generic path
 }
+
+// =====================================================================================================
+// cls-row attention of the LAST block, folded (ai/nn.py:52-56 restricted to the row nn.py:80 reads).
+// With q = Wq LN1(x)[cls] + bq fixed per board, the scores against every token are
+//     s[h][t] = scale * q_h . (Wk_h xhat_t + bk_h) = xhat_t . m_h + c_h,   m_h = scale * Wk_h^T q_h,  c_h = scale * q_h . bk_h
+// and the head outputs are Wv_h (sum_t softmax_t(s[h])[t] xhat_t) + bv_h, so K and V are never formed:
+// this kernel streams xhat once (online softmax, flash-style running max / sum per wave) and emits
+//     z[b][h][:] = sum_t softmax_t(s[b][h][:])[t] * xhat[b][t][:]            ([n][H][D])
+// The tiny per-board GEMMs around it (m_h, Wv_h z_h, out-proj, MLP, heads) stay in the caller.
+// One workgroup (4 waves) per board; wave w takes tokens t = w (mod 4); lane l owns CPL = D/64 columns.
+// HBM-bound: reads T*D*2 bytes per board once.
+// =====================================================================================================
+namespace {
+
+struct ClsAttnArgs {
+    const __hip_bfloat16 *xhat;   // [n][T][D]
+    const float *m;               // [n or 1][H][D]  (already multiplied by the softmax scale)
+    const float *c;               // [n or 1][H]
+    long long m_stride, c_stride; // elements between boards (0 = shared by every board)
+    __hip_bfloat16 *z;            // [n][H][D]
+    int n, T;
+};
+
+template <int CPL, int NH>
+__global__ __launch_bounds__(256) void k_cls_attn(ClsAttnArgs a) {
+    constexpr int D = 64 * CPL;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *zpart = (float *)smem;                    // [4 waves][NH][D]
+    float *mlpart = (float *)(smem + 4 * NH * D * 4); // [4][NH] running max, then [4][NH] running sum
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x;
+    const float *mp = a.m + (size_t)b * a.m_stride, *cp = a.c + (size_t)b * a.c_stride;
+    float mh[NH][CPL], ch[NH];
+#pragma unroll
+    for (int h = 0; h < NH; h++) {
+        ch[h] = cp[h];
+#pragma unroll
+        for (int q = 0; q < CPL; q++) mh[h][q] = mp[h * D + lane * CPL + q];
+    }
+    float run_m[NH], run_l[NH], zacc[NH][CPL];
+#pragma unroll
+    for (int h = 0; h < NH; h++) {
+        run_m[h] = -3.0e38f; run_l[h] = 0.f;
+#pragma unroll
+        for (int q = 0; q < CPL; q++) zacc[h][q] = 0.f;
+    }
+    const unsigned short *base = (const unsigned short *)a.xhat + (size_t)b * a.T * D + lane * CPL;
+    for (int t = wave; t < a.T; t += 4) {
+        float xv[CPL];
+        if (CPL == 8) {
+            const uint4 raw = *(const uint4 *)(base + (size_t)t * D);
+            xv[0] = __uint_as_float(raw.x << 16); xv[1] = __uint_as_float(raw.x & 0xffff0000u);
+            xv[2] = __uint_as_float(raw.y << 16); xv[3] = __uint_as_float(raw.y & 0xffff0000u);
+            xv[4] = __uint_as_float(raw.z << 16); xv[5] = __uint_as_float(raw.z & 0xffff0000u);
+            xv[6] = __uint_as_float(raw.w << 16); xv[7] = __uint_as_float(raw.w & 0xffff0000u);
+        } else {
+#pragma unroll
+            for (int q = 0; q < CPL; q++) xv[q] = __uint_as_float((unsigned)base[(size_t)t * D + q] << 16);
+        }
+        float s[NH];
+#pragma unroll
+        for (int h = 0; h < NH; h++) {
+            float p = 0.f;
+#pragma unroll
+            for (int q = 0; q < CPL; q++) p += xv[q] * mh[h][q];
+            s[h] = p;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+            for (int h = 0; h < NH; h++) s[h] += __shfl_xor(s[h], off);
+#pragma unroll
+        for (int h = 0; h < NH; h++) {
+            const float sc = s[h] + ch[h];
+            const float nm = fmaxf(run_m[h], sc);
+            const float alpha = __expf(run_m[h] - nm), p = __expf(sc - nm);
+            run_m[h] = nm;
+            run_l[h] = run_l[h] * alpha + p;
+#pragma unroll
+            for (int q = 0; q < CPL; q++) zacc[h][q] = zacc[h][q] * alpha + p * xv[q];
+        }
+    }
+    // ---- combine the four waves' partial (max, sum, z) ----
+#pragma unroll
+    for (int h = 0; h < NH; h++) {
+        if (lane == 0) { mlpart[wave * NH + h] = run_m[h]; mlpart[4 * NH + wave * NH + h] = run_l[h]; }
+#pragma unroll
+        for (int q = 0; q < CPL; q++) zpart[(wave * NH + h) * D + lane * CPL + q] = zacc[h][q];
+    }
+    __syncthreads();
+    for (int i = tid; i < NH * D; i += 256) {
+        const int h = i / D, col = i - h * D;
+        float M = mlpart[h];
+#pragma unroll
+        for (int w = 1; w < 4; w++) M = fmaxf(M, mlpart[w * NH + h]);
+        float L = 0.f, Z = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            const float e = __expf(mlpart[w * NH + h] - M);
+            L += mlpart[4 * NH + w * NH + h] * e;
+            Z += zpart[(w * NH + h) * D + col] * e;
+        }
+        a.z[((size_t)b * NH + h) * D + col] = __float2bfloat16(Z / L);
+    }
+}
+
+template <int CPL, int NH>
+int launch_cls_attn(const ClsAttnArgs &a, hipStream_t st) {
+    constexpr int D = 64 * CPL;
+    const int lds = 4 * NH * D * 4 + 8 * NH * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void *)k_cls_attn<CPL, NH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return AZK_ERR_HIP;
+        attr_set = true;
+    }
+    k_cls_attn<CPL, NH><<<a.n, 256, lds, st>>>(a);
+    return hipGetLastError() == hipSuccess ? AZK_OK : AZK_ERR_HIP;
+}
+
+}  // namespace
+
+extern "C" int32_t azk_nn_cls_attention(const void *xhat_bf16_dev, const float *m_dev, const float *c_dev,
+                                        int32_t per_board_m, void *z_out_bf16_dev, int32_t n, int32_t tokens,
+                                        int32_t embed_dim, int32_t num_heads, void *stream) {
+    if (!xhat_bf16_dev || !m_dev || !c_dev || !z_out_bf16_dev || n < 0 || tokens < 1) return AZK_ERR_ARG;
+    if (n == 0) return AZK_OK;
+    ClsAttnArgs a;
+    a.xhat = (const __hip_bfloat16 *)xhat_bf16_dev; a.m = m_dev; a.c = c_dev; a.z = (__hip_bfloat16 *)z_out_bf16_dev;
+    a.m_stride = per_board_m ? (long long)num_heads * embed_dim : 0; a.c_stride = per_board_m ? num_heads : 0;
+    a.n = n; a.T = tokens;
+    hipStream_t st = (hipStream_t)stream;
+#define CASE(CPL_, NH_) if (embed_dim == 64 * CPL_ && num_heads == NH_) return launch_cls_attn<CPL_, NH_>(a, st)
+    CASE(8, 8); CASE(4, 8); CASE(4, 4); CASE(2, 4); CASE(2, 8); CASE(8, 4);
+#undef CASE
+    return AZK_ERR_ARG;
+}

@@ -12,6 +12,9 @@ Evaluation paths (all compute the SAME function: logits [n,A], value [n] in (-1,
           15x15 / D=512 / depth 1 config)
   "cls"   the last block only produces what is consumed: K,V for all tokens, Q / out-proj / MLP for the
           cls row alone (x[:,0] is the only row the heads read, nn.py:80-83).  0.254 GFLOP/board.
+  "clsfold" as "cls", with the cls query folded through Wk and the value projection applied after the
+          softmax-weighted token sum, so K and V are never formed (csrc/azk_nn.hip): 0.022 GFLOP/board,
+          one streaming pass over LayerNorm1(tokens).  GPU + bf16 only.
 Rectangular boards (Connect4 6x7) get rows*cols+1 tokens; the reference's Net is square-only
 (nn.py:26-28), so that case has no reference numerics ("parity unpinned - build-defined").
 """
@@ -43,6 +46,15 @@ class NetConfig:
         blk = 2 * T * D * 3 * D + 2 * 2 * T * T * D + 2 * T * D * D + 2 * 2 * T * D * 4 * D
         last = 2 * T * D * 2 * D + 2 * D * D + 2 * 2 * T * D + 2 * D * D + 2 * 2 * D * 4 * D
         return conv + (self.depth - 1) * blk + last + 2 * D * (A + 1)
+
+
+def flops_clsfold(cfg):
+    """Executed flops of the folded cls path: conv + per token (8 head scores + 8 weighted sums) + cls-row GEMVs."""
+    T, D, A, C, k, H = cfg.tokens, cfg.embed_dim, cfg.action_dim, cfg.channels, cfg.patch_size, cfg.num_heads
+    conv = 2 * (T - 1) * D * C * k * k
+    blk = 2 * T * D * 3 * D + 2 * 2 * T * T * D + 2 * T * D * D + 2 * 2 * T * D * 4 * D
+    last = 2 * 2 * T * D * H + 2 * D * D + 2 * D * D + 2 * 2 * D * 4 * D
+    return conv + (cfg.depth - 1) * blk + last + 2 * D * (A + 1)
 
 
 def reference_key_shapes(cfg):
@@ -119,9 +131,37 @@ class PolicyValueNet:
         D, H = self.cfg.embed_dim, self.cfg.num_heads
         self.scale = 1.0 / math.sqrt(D // H)
         self._hip = None
+        self._fold = None
         if self.device.type == "cuda" and self.dtype == torch.bfloat16:
             self._prepare_hip_embed()
+            if self._hip is not None:
+                self._prepare_folded()
         return self
+
+    def _prepare_folded(self):
+        """Operands of the folded cls-row attention of the LAST block (csrc/azk_nn.hip k_cls_attn):
+        scores[h][t] = xhat_t . m_h + c_h with m_h = scale * Wk_h^T q_h, c_h = scale * q_h . bk_h; head output =
+        Wv_h (sum_t a[h][t] xhat_t) + bv_h.  For depth 1 the cls query is input independent (x[:,0] = cls + pos[0]),
+        so m and c are constants of the weights."""
+        cfg, m = self.cfg, self.master
+        D, H = cfg.embed_dim, cfg.num_heads
+        dh = D // H
+        if (D, H) not in ((512, 8), (512, 4), (256, 8), (256, 4), (128, 4), (128, 8)):
+            return
+        b = f"blocks.{cfg.depth - 1}."
+        Wi, bi = m[b + "attn.in_proj_weight"], m[b + "attn.in_proj_bias"]
+        dev = self.device
+        f = dict(Wq=Wi[:D].to(dev), bq=bi[:D].to(dev), Wk=Wi[D:2 * D].reshape(H, dh, D).to(dev),
+                 bk=bi[D:2 * D].reshape(H, dh).to(dev),
+                 WvT=Wi[2 * D:].reshape(H, dh, D).transpose(1, 2).contiguous().to(dev, torch.bfloat16),   # [H, D, dh]
+                 bv=bi[2 * D:].to(dev, torch.bfloat16))
+        if cfg.depth == 1:
+            x0 = self._hip["cpos"][0]
+            h0 = F.layer_norm(x0, (D,), self._hip["ln_w"], self._hip["ln_b"], 1e-5)
+            q = (F.linear(h0, f["Wq"], f["bq"])).view(H, dh)
+            f["m"] = (torch.einsum("he,hed->hd", q, f["Wk"]) * self.scale).contiguous()
+            f["c"] = ((q * f["bk"]).sum(1) * self.scale).contiguous()
+        self._fold = f
 
     def _prepare_hip_embed(self):
         """Operands of azk_nn_patch_embed: conv weight [D, kp] bf16 (k padded to a multiple of 16) and the
@@ -209,6 +249,26 @@ class PolicyValueNet:
         h = F.linear(F.gelu(F.linear(h, w[b + "mlp.0.weight"], w[b + "mlp.0.bias"])), w[b + "mlp.3.weight"], w[b + "mlp.3.bias"])
         return x0 + h                                                          # [n, D]
 
+    def block_cls_folded(self, xhat, x0, i):
+        """Same function as block_cls, evaluated without forming K or V (see _prepare_folded)."""
+        import azk
+        w, cfg, f = self.w, self.cfg, self._fold
+        b = f"blocks.{i}."
+        n, T, D = xhat.shape
+        H, dh = cfg.num_heads, D // cfg.num_heads
+        if "m" in f:
+            mm, cc = f["m"], f["c"]
+        else:                                    # depth > 1: the cls query depends on the board
+            q = F.linear(xhat[:, 0].float(), f["Wq"], f["bq"]).view(n, H, dh)
+            mm = (torch.einsum("nhe,hed->nhd", q, f["Wk"]) * self.scale).contiguous()
+            cc = ((q * f["bk"]).sum(2) * self.scale).contiguous()
+        z = azk.nn_cls_attention(xhat, mm, cc, H)                                # [n, H, D] bf16
+        a = torch.bmm(z.transpose(0, 1), f["WvT"]).transpose(0, 1).reshape(n, D) + f["bv"]
+        x0 = x0 + F.linear(a, w[b + "attn.out_proj.weight"], w[b + "attn.out_proj.bias"])
+        h = self._ln(x0, b + "norm2")
+        h = F.linear(F.gelu(F.linear(h, w[b + "mlp.0.weight"], w[b + "mlp.0.bias"])), w[b + "mlp.3.weight"], w[b + "mlp.3.bias"])
+        return x0 + h
+
     def heads(self, x0):
         x0 = self._ln(x0, "norm")
         logits = F.linear(x0, self.w["policy_head.weight"], self.w["policy_head.bias"])
@@ -220,6 +280,20 @@ class PolicyValueNet:
         path = path or self.path
         x = x.to(self.device)
         depth = self.cfg.depth
+        if path == "clsfold":
+            if self._fold is None:
+                raise RuntimeError("path 'clsfold' needs the HIP kernels (CUDA, bf16, supported embed_dim/heads)")
+            last = depth - 1
+            if depth == 1:
+                _, xhat = self.embed_hip(x, want_x=False, want_xhat=True)
+                x0 = self._hip["cpos"][0].to(self.dtype).expand(x.shape[0], -1)
+            else:
+                t = self.embed(x)
+                for i in range(last):
+                    t = self.block_full(t, i)
+                xhat = self._ln(t, f"blocks.{last}.norm1").contiguous()
+                x0 = t[:, 0]
+            return self.heads(self.block_cls_folded(xhat, x0, last))
         if path == "cls" and depth == 1 and self._hip is not None:
             # tokens are never materialised: the embedding kernel emits LayerNorm1(tokens) and the cls residual
             # row is the constant cls + pos[0]

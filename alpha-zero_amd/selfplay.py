@@ -104,9 +104,12 @@ class SelfPlayRunner:
     """
 
     def __init__(self, game, evaluator, n_games, n_sims, size=None, seed=0, first_global_game=0, dirichlet=True,
-                 alpha=0.03, device=0, leaf_dtype="float32", recycle=True, on_records=None, kernel_timer=None):
+                 alpha=0.03, device=0, leaf_dtype="float32", recycle=True, on_records=None, kernel_timer=None,
+                 use_graph=False):
         import torch
         self.torch = torch
+        self.use_graph = use_graph
+        self._graph = None
         self.eng = Engine(game, n_games, n_sims, size=size, device=device, leaf_dtype=leaf_dtype)
         self.evaluator, self.n_sims, self.seed, self.first = evaluator, n_sims, seed, first_global_game
         self.dirichlet, self.alpha, self.recycle, self.on_records = dirichlet, alpha, recycle, on_records
@@ -124,12 +127,22 @@ class SelfPlayRunner:
         self.h_stats = torch.zeros(8, dtype=torch.int64, **pin)
         self.move_idx = 0
         self.plies_played = 0
+        # static buffers so a captured step graph always sees the same addresses
+        self.noise_buf = torch.zeros((e.G, e.action_dim), dtype=torch.float64, device=e.device) if dirichlet else None
+        self.logits_buf = torch.zeros((e.G, e.action_dim), dtype=torch.float32, device=e.device)
+        self.values_buf = torch.zeros(e.G, dtype=torch.float32, device=e.device)
         e.reset_games()
 
     def play_move(self):
         e = self.eng
         noise, uni = e.gen_noise(self.seed, self.first, self.move_idx, self.alpha, want_noise=self.dirichlet)
-        self.search(noise)
+        if self.dirichlet:
+            self.noise_buf.copy_(noise)
+            noise = self.noise_buf
+        if self.use_graph:
+            self.search_graph(noise)
+        else:
+            self.search(noise)
         pi, q, _ = e.root_stats()
         self.h_pi.copy_(pi, non_blocking=True)
         self.h_q.copy_(q, non_blocking=True)
@@ -168,6 +181,51 @@ class SelfPlayRunner:
                 logits = values = None
         if logits is not None:
             e.step_expand_backup(logits, values)
+
+    def _step_body(self):
+        """One simulation for every game, with no host round trip: expand+backup of the previous leaves, PUCT select,
+        leaf compaction, then the evaluator over the whole (fixed-size) leaf buffer.  Rows past n_leaf hold older
+        boards; their outputs are never read (slot indices stop at n_leaf)."""
+        e = self.eng
+        e.step(self.logits_buf, self.values_buf)
+        logits, values = self.evaluator(e.leaf_boards)
+        self.logits_buf.copy_(logits)
+        self.values_buf.copy_(values.reshape(-1))
+
+    def search_graph(self, noise):
+        """n_sims replays of one captured hipGraph (k_tree -> k_gather -> evaluator kernels)."""
+        e, torch = self.eng, self.torch
+        e.begin_search(noise)
+        if self._graph is None:
+            # the first simulations run eagerly on a side stream (allocator warm-up), the capture records one more
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    self._step_body()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._step_body()
+            self._graph = g
+            done = 4
+        else:
+            done = 0
+        kt = self.kernel_timer
+        for s in range(done, self.n_sims):
+            if kt is not None and kt.want(s):
+                # sampled steps run the same kernels eagerly so HIP events can bracket k_tree on its stream
+                kt.start()
+                e.step_tree(self.logits_buf, self.values_buf)
+                kt.stop()
+                e.step_gather()
+                logits, values = self.evaluator(e.leaf_boards)
+                self.logits_buf.copy_(logits)
+                self.values_buf.copy_(values.reshape(-1))
+            else:
+                self._graph.replay()
+        e.step_expand_backup(self.logits_buf, self.values_buf)
 
     @property
     def games_finished(self):

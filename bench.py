@@ -50,6 +50,9 @@ def cpu_baseline(n_sims, budget_s, mean_plies):
     import torch
     from oracle import az_oracle as ao
     from pvnet import NetConfig, PolicyValueNet
+    # batch-1 evaluation does not scale past a few threads (128 threads measured 45-64 sims/s on this class of
+    # host, 8 threads several times that); 8 is also what the survey's reference measurement used
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
     cfg = NetConfig(15, 15, 2, 225, 5, 512, 8, 1)
     net = PolicyValueNet(cfg, seed=0, device="cpu", dtype=torch.float32, path="full")
     game = ao.OracleGame("gomoku", 15)
@@ -76,21 +79,21 @@ def cpu_baseline(n_sims, budget_s, mean_plies):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--games", type=int, default=2048, help="concurrent games per GPU")
     ap.add_argument("--sims", type=int, default=800)
     ap.add_argument("--size", type=int, default=15)
-    ap.add_argument("--nn-path", default="cls", choices=["cls", "full"])
+    ap.add_argument("--nn-path", default="clsfold", choices=["clsfold", "cls", "full"])
+    ap.add_argument("--no-graph", action="store_true", help="eager stepping with a host sync per simulation (n_leaf-sized batches)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="wall-clock budget of the CPU baseline leg (0 = skip)")
     ap.add_argument("--seed", type=int, default=0)
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    from shard import env_world, shard_range
+    rank, local_rank, world = env_world()
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -104,8 +107,8 @@ def main():
     net = PolicyValueNet(cfg, seed=0, device=f"cuda:{local_rank}", dtype=torch.bfloat16, path=args.nn_path)
     kt = KernelTimer(stride=16)
     runner = SelfPlayRunner("gomoku", net, args.games, args.sims, size=args.size, seed=args.seed,
-                            first_global_game=rank * args.games, device=local_rank, leaf_dtype="bfloat16",
-                            recycle=True, kernel_timer=kt)
+                            first_global_game=shard_range(args.games, rank)[0], device=local_rank, leaf_dtype="bfloat16",
+                            recycle=True, kernel_timer=kt, use_graph=not args.no_graph)
     eng = runner.eng
 
     def sync_all():
@@ -131,14 +134,10 @@ def main():
     plies = runner.plies_played - plies0
     fin, finp = runner.games_finished, runner.finished_plies
 
-    # max time / summed work over ranks
-    tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    work = torch.tensor([plies, fin - fin0, fin, finp, c["sims"], c["leaves_evaluated"]], dtype=torch.float64, device="cuda")
-    if world > 1:
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dist.all_reduce(work, op=dist.ReduceOp.SUM)
-    dt_max = float(tt[0])
-    plies_all, fin_window, fin_all, finp_all, sims_all, leaves_all = [float(x) for x in work]
+    # max time / summed work over ranks (the only collectives: measurement, never the generation path)
+    from shard import reduce_measurement
+    dt_max, (plies_all, fin_window, fin_all, finp_all, sims_all, leaves_all) = reduce_measurement(
+        dt, [plies, fin - fin0, fin, finp, c["sims"], c["leaves_evaluated"]], dist if world > 1 else None, "cuda")
 
     if rank == 0:
         if fin_all > 0:
@@ -155,7 +154,9 @@ def main():
             roof = {"kernel": "k_tree<expand,select>", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": gbs / HBM_PEAK_GBS, "traffic": None, "avg_launch_us": tree_ms * 1e3,
                     "algorithmic_bytes_per_launch": alg_bytes, "event_samples": len(kt.pairs)}
-        flops = cfg.flops_cls() if args.nn_path == "cls" else cfg.flops_full()
+        from pvnet import flops_clsfold
+        flops = {"cls": cfg.flops_cls(), "full": cfg.flops_full(), "clsfold": flops_clsfold(cfg)}[args.nn_path]
+        evals = leaves_all if args.no_graph else sims_all      # graph mode evaluates the full fixed-size leaf buffer every step
         out = {
             "metric": "selfplay_games_per_sec", "value": games_per_s, "unit": "games/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt_max / args.steps * 1e3,
@@ -165,7 +166,8 @@ def main():
                        "sims_per_move": args.sims, "net": f"ViT patch5 embed512 heads8 depth1 (ai/nn.py), random init seed 0, path={args.nn_path}",
                        "parallelism": f"games sharded over {world} GPU(s), no collectives on the generation path"},
             "sims_per_sec": sims_all / dt_max, "leaf_evals_per_sec": leaves_all / dt_max,
-            "nn_tflops_algorithmic": leaves_all * flops / dt_max / 1e12, "nn_flops_per_leaf": flops,
+            "nn_tflops_executed": evals * flops / dt_max / 1e12, "nn_flops_per_board": flops, "nn_boards_evaluated": evals,
+            "stepping": "eager+sync" if args.no_graph else "hipGraph replay (tree+gather+net per simulation, no host sync)",
             "mean_plies_per_game": mean_plies, "game_length_source": src, "games_finished_in_window": fin_window,
             "plies_in_window": plies_all, "counters_rank0": c, "roofline": roof,
         }

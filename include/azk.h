@@ -201,6 +201,15 @@ int32_t azk_nn_patch_embed(const void *boards_dev, int32_t boards_are_f32, const
                            int32_t rows, int32_t cols, int32_t ksize, int32_t kp, int32_t embed_dim,
                            float ln_eps, void *stream);
 
+/* cls-row attention of the last block, folded (ai/nn.py:52-56 restricted to the row nn.py:80 reads): streams
+ * xhat = LayerNorm1(tokens) [n][T][D] bf16 once and writes z[b][h][:] = sum_t softmax_t(xhat_t . m[b][h] + c[b][h])[t] * xhat_t
+ * ([n][H][D] bf16) with an online softmax, so K and V are never materialised.  m_dev float32 [n or 1][H][D] =
+ * scale * Wk_h^T q_h, c_dev float32 [n or 1][H] = scale * q_h . bk_h (per_board_m = 0: one shared row set, the depth-1
+ * case where q is input independent).  Supported (embed_dim, heads): (512,8) (512,4) (256,8) (256,4) (128,4) (128,8). */
+int32_t azk_nn_cls_attention(const void *xhat_bf16_dev, const float *m_dev, const float *c_dev, int32_t per_board_m,
+                             void *z_out_bf16_dev, int32_t n, int32_t tokens, int32_t embed_dim, int32_t num_heads,
+                             void *stream);
+
 /* float32 softmax exactly as the engine applies it to logits (test hook; [n][A] -> [n][A]) */
 int32_t azk_softmax_rows(const float *logits_dev, int32_t n, int32_t action_dim, float *out_dev, void *stream);
 

@@ -63,3 +63,38 @@ def test_evaluator_paths_agree_and_match_reference_kat():
     net32 = PolicyValueNet(cfg, seed=0, device="cuda", dtype=torch.float32, path="cls")
     l32, v32 = net32(x)
     np.testing.assert_allclose(l32.cpu().numpy(), z["full_logits"], rtol=0, atol=1e-4)
+
+
+@pytest.mark.parametrize("R,D,heads,depth,k", [(15, 512, 8, 1, 5), (7, 256, 8, 2, 5), (7, 128, 4, 1, 3), (15, 256, 4, 2, 5)])
+def test_folded_cls_attention_matches_full_forward(R, D, heads, depth, k):
+    """path='clsfold' (hand-written embed + folded cls attention, K/V never formed) computes the same function as
+    the plain fp32 full forward: logits within 3e-2 absolute (bf16 activations), value within 2e-2."""
+    cfg = NetConfig(R, R, 2, R * R, k, D, heads, depth)
+    net32 = PolicyValueNet(cfg, seed=5, device="cuda", dtype=torch.float32, path="full")
+    net16 = PolicyValueNet(cfg, weights=net32.state_dict(), device="cuda", dtype=torch.bfloat16, path="clsfold")
+    assert net16._fold is not None
+    x = random_boards(64, 2, R, R, 9).cuda()
+    l32, v32 = net32(x)
+    l16, v16 = net16(x.to(torch.bfloat16))
+    torch.testing.assert_close(l16, l32, rtol=0, atol=4e-2 if depth == 1 else 8e-2)
+    torch.testing.assert_close(v16, v32, rtol=0, atol=3e-2)
+    # and the policy it induces: softmax rows within 1e-2 in total variation
+    tv = 0.5 * (torch.softmax(l16, 1) - torch.softmax(l32, 1)).abs().sum(1).max().item()
+    assert tv < 2e-2, tv
+
+
+def test_cls_attention_kernel_vs_torch():
+    """z = softmax(xhat m^T + c) weighted token sums, against the same op in plain PyTorch fp32."""
+    import azk
+    torch.manual_seed(0)
+    for (n, T, D, H, per_board) in [(33, 226, 512, 8, False), (17, 50, 256, 8, True), (9, 10, 128, 4, False), (5, 226, 512, 4, True)]:
+        xhat = torch.randn(n, T, D, device="cuda").to(torch.bfloat16)
+        m = torch.randn((n, H, D) if per_board else (H, D), device="cuda") * 0.1
+        c = torch.randn((n, H) if per_board else (H,), device="cuda")
+        z = azk.nn_cls_attention(xhat, m, c, H).float()
+        xf = xhat.float()
+        mm = m if per_board else m.expand(n, H, D)
+        cc = c if per_board else c.expand(n, H)
+        s = torch.einsum("ntd,nhd->nht", xf, mm) + cc[:, :, None]
+        ref = torch.einsum("nht,ntd->nhd", torch.softmax(s, dim=2), xf)
+        torch.testing.assert_close(z, ref, rtol=1e-2, atol=1e-2)     # output rounded to bf16; fp32 accumulation inside
