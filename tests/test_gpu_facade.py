@@ -1,0 +1,104 @@
+"""The reference-shaped facade on the GPU: `Game` statics and `MCTS.mcts(model, board, root, Game, n, dirichlet)`
+called exactly the way the reference's callers call them (gomoku.py:134-146, test.py:41-47), checked against
+golden vectors produced by the reference itself."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_meta, load_golden
+from fixture_eval import fixture_logits_value
+
+pytestmark = pytest.mark.gpu
+
+_SZ = load_golden("search.npz")
+_SMETA = golden_meta(_SZ)
+
+
+class GpuFixtureModel:
+    def __init__(self, A, variant):
+        self.A, self.variant = A, variant
+
+    def __call__(self, x):
+        logits, v = fixture_logits_value(x, self.A, self.variant)
+        return logits, v[:, None]
+
+
+def game_class(m):
+    from games import Connect4, Gomoku, TicTacToe
+    if m["game"] == "gomoku":
+        Gomoku.rows = Gomoku.cols = m["size"]                      # the reference's own way to resize
+        Gomoku.action_dim = Gomoku.state_dim = m["size"] ** 2
+        return Gomoku
+    return {"tictactoe": TicTacToe, "connect4": Connect4}[m["game"]]
+
+
+@pytest.mark.parametrize("m", [m for m in _SMETA if m["case"] in (1, 4, 9, 11, 12, 17, 19, 21, 24)],
+                         ids=lambda m: f"{m['case']}-{m['game']}{m['size']}-n{m['n_sims']}")
+def test_mcts_mcts_like_a_reference_caller(m):
+    from ai import MCTS, Node
+    Game = game_class(m)
+    k = f"c{m['case']}_"
+    g = Game()
+    board, player = g.board, 0
+    for cell in _SZ[k + "actions"]:
+        mv = (int(cell) // Game.cols, int(cell) % Game.cols)
+        assert mv in Game.get_valid_moves(board)
+        player = Game.make_move(board, player, mv)
+    assert player == m["player"]
+    before = board.copy()
+    root = Node(None, None, player, len(_SZ[k + "actions"]))
+    np.random.seed(1000 + m["case"])                               # the generator's seed: same Dirichlet draw
+    count0 = MCTS.mcts_count
+    MCTS.mcts(GpuFixtureModel(Game.action_dim, m["variant"]), board, root, Game, m["n_sims"], m["dirichlet"])
+    assert np.array_equal(board, before)                           # board restored (mcts.py contract)
+    assert MCTS.mcts_count - count0 == m["n_sims"]
+    assert root.visit == m["root_visit"] and root.value == m["root_value"]
+    assert [c.prevAction[0] * Game.cols + c.prevAction[1] for c in root.children] == _SZ[k + "child_cell"].tolist()
+    assert [c.visit for c in root.children] == _SZ[k + "child_visit"].tolist()
+    assert np.array([c.value for c in root.children]).tobytes() == _SZ[k + "child_value"].tobytes()
+    np.testing.assert_allclose([float(c.prior) for c in root.children], _SZ[k + "child_prior"], rtol=1e-6)
+    assert isinstance(root.children[0].prior, np.float64 if m["dirichlet"] else np.float32)
+    # what callers read afterwards
+    best = root.max_visit_child()
+    assert best.visit == max(_SZ[k + "child_visit"]) and best is next(c for c in root.children if c.visit == best.visit)
+    pi = root.visit_distribution(Game)
+    assert pi.tobytes() == _SZ[k + "pi"].tobytes()
+    assert all(c.currentPlayer == 1 - player and c.move_count == root.move_count + 1 and c.parent is root for c in root.children)
+    assert "Visit" in root.children[0].to_string(Game)
+
+
+def test_game_statics_behave_like_the_reference():
+    from games import Connect4, Gomoku, TicTacToe
+    Gomoku.rows = Gomoku.cols = 7
+    Gomoku.action_dim = Gomoku.state_dim = 49
+    g = Gomoku()
+    assert Gomoku.get_valid_moves(g.board) == [(3, 3)]              # empty board: centre only (gomoku.py:103-104)
+    assert Gomoku.make_move(g.board, 0, (3, 3)) == 1
+    assert Gomoku.get_valid_moves(g.board) == [(4, 4), (2, 4), (3, 4), (4, 3), (4, 2), (2, 3), (2, 2), (3, 2)]  # CPython set order
+    assert Gomoku.make_move(g.board, 1, (3, 3)) == 1                # occupied: unchanged player
+    assert Gomoku.check_winner(g.board, 0, (3, 3)) == -1
+    c = Gomoku.get_canonical_board(g.board, 1)
+    assert c[1, 3, 3] == 1 and c[0].sum() == 0 and Gomoku.get_canonical_board(g.board, 0) is g.board
+    Gomoku.undo_move(g.board, 1, (3, 3))
+    assert g.board.sum() == 0
+    t = TicTacToe()
+    for i, mv in enumerate([(0, 0), (1, 0), (0, 1), (1, 1)]):
+        assert TicTacToe.make_move(t.board, i % 2, mv) == 1 - i % 2
+    assert t.board[2, 0, 0] == 0                                    # side-to-move plane (tictactoe.py:41)
+    assert TicTacToe.make_move(t.board, 0, (0, 2)) == 1 and TicTacToe.check_winner(t.board, 0, (0, 2)) == 0
+    c4 = Connect4()
+    assert Connect4.get_valid_moves(c4.board) == [(5, c) for c in range(7)]
+    assert Connect4.make_move(c4.board, 0, (None, 3)) == 0          # full column: unchanged (connect4.py:57-60)
+
+
+def test_gomoku_self_play_returns_the_reference_tuple():
+    from games import Gomoku
+    Gomoku.rows = Gomoku.cols = 7
+    Gomoku.action_dim = Gomoku.state_dim = 49
+    np.random.seed(3)
+    boards, actions, pis, qs, winner = Gomoku().self_play(GpuFixtureModel(49, "hash"), 40)
+    assert actions[0] == (-1, -1) and len(actions) == len(boards) + 1 == len(pis) + 1 == len(qs) + 1
+    assert winner in (0, 1, -1) and boards[0].shape == (2, 7, 7) and boards[0].sum() == 0
+    assert all(abs(p.sum() - 1) < 1e-12 for p in pis) and actions[1] == (3, 3)
+    for i in range(1, len(boards)):                                 # raw boards, one more stone each ply
+        assert boards[i].sum() == i
