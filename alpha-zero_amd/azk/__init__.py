@@ -25,7 +25,7 @@ SYMBOLS = [
     "azk_get_counters", "azk_reset_counters", "azk_check_device_error", "azk_gen_noise",
     "azk_rules_legal_moves", "azk_rules_legal_mask", "azk_rules_apply_move", "azk_rules_undo_move",
     "azk_rules_check_winner", "azk_rules_canonical", "azk_softmax_rows",
-    "azk_step_tree", "azk_step_gather", "azk_recycle_finished", "azk_nn_patch_embed", "azk_nn_cls_attention",
+    "azk_step_tree", "azk_step_gather", "azk_recycle_finished", "azk_nn_patch_embed", "azk_nn_cls_attention", "azk_nn_patch_embed_scores", "azk_nn_cls_pool",
 ]
 
 
@@ -109,6 +109,8 @@ def lib():
     L.azk_step_tree.argtypes = [vp, vp, vp, vp]
     L.azk_step_gather.argtypes = [vp, vp, vp, vp]
     L.azk_recycle_finished.argtypes = [vp, vp, vp]
+    L.azk_nn_patch_embed_scores.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, C.c_float, vp]
+    L.azk_nn_cls_pool.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp]
     L.azk_nn_cls_attention.argtypes = [vp, vp, vp, i32, vp, i32, i32, i32, i32, vp]
     L.azk_nn_patch_embed.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, C.c_float, vp]
     for name in SYMBOLS:
@@ -413,4 +415,27 @@ def nn_cls_attention(xhat, m, c, num_heads):
     rc = lib().azk_nn_cls_attention(_p(xhat), _p(m), _p(c), per_board, _p(z), n, T, D, num_heads, _stream())
     if rc != 0:
         raise AzkError(f"azk_nn_cls_attention failed ({rc})")
+    return z
+
+
+def nn_embed_scores_pool(boards, wt, cpos, ln_w, ln_b, m, c, rows, cols, ksize, embed_dim, num_heads, eps=1e-5):
+    """Depth-1 folded cls attention in two launches: azk_nn_patch_embed_scores (xhat + per-token head scores) then
+    azk_nn_cls_pool (softmax + weighted token sum).  Returns z bf16 [n, H, D]."""
+    torch = _torch()
+    assert boards.is_cuda and boards.is_contiguous() and boards.dtype in (torch.bfloat16, torch.float32)
+    n, C = boards.shape[0], boards.shape[1]
+    T = rows * cols + 1
+    Tp = (T + 15) // 16 * 16
+    xh = torch.empty((n, T, embed_dim), dtype=torch.bfloat16, device=boards.device)
+    sc = torch.empty((n, num_heads, Tp), dtype=torch.float32, device=boards.device)
+    z = torch.empty((n, num_heads, embed_dim), dtype=torch.bfloat16, device=boards.device)
+    L = lib()
+    rc = L.azk_nn_patch_embed_scores(_p(boards), 1 if boards.dtype == torch.float32 else 0, _p(wt), _p(cpos), _p(ln_w), _p(ln_b),
+                                     _p(xh), _p(m), _p(sc), num_heads, n, C, rows, cols, ksize, wt.shape[1], embed_dim,
+                                     float(eps), _stream())
+    if rc != 0:
+        raise AzkError(f"azk_nn_patch_embed_scores failed ({rc})")
+    rc = L.azk_nn_cls_pool(_p(xh), _p(sc), _p(c), _p(z), n, T, embed_dim, num_heads, _stream())
+    if rc != 0:
+        raise AzkError(f"azk_nn_cls_pool failed ({rc})")
     return z

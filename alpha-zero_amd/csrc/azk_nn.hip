@@ -33,12 +33,25 @@ struct EmbedArgs {
     const float *ln_w, *ln_b;  // [D] LayerNorm affine (used when xhat != nullptr)
     __hip_bfloat16 *x;         // [n][T][D] tokens (may be null)
     __hip_bfloat16 *xhat;      // [n][T][D] LayerNorm(tokens) (may be null)
+    const float *mtab;         // [NH][D] folded score vectors (scale * Wk_h^T q_h), or null
+    float *scores;             // [n][NH][Tp] (Tp = 16*ceil(T/16)) xhat_t . m_h, written when mtab != null
+    int nh;
     int n, C, R, Cc, ksz, T;
     float eps;
     int ablate;                // debug only (AZK_EMBED_ABLATE): 1 no cpos loads, 2 no stores, 4 no MFMA, 8 no patch build
 };
 
 typedef __attribute__((ext_vector_type(8))) float f32x8;
+
+// Sum over the 16 lanes of a DPP row (lanes sharing lane>>4), result in every lane: quad_perm [1,0,3,2], quad_perm
+// [2,3,0,1], row_half_mirror, row_mirror - four v_add_f32 with a DPP operand instead of four ds_bpermute round trips.
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+    return v;
+}
 
 // fp32 -> bf16 (round to nearest even) as plain vector casts: hipcc lowers them to v_cvt_pk_bf16_f32
 __device__ __forceinline__ uint4 pack8(const float *v) {
@@ -51,13 +64,15 @@ __device__ __forceinline__ uint4 pack8(const float *v) {
 }
 
 // NG = D / 128 column groups (each lane owns 8 consecutive columns per group); KS = KP / 32 k-steps.
-template <int NG, int KS, bool WANT_X, bool WANT_XHAT>
+template <int NG, int KS, bool WANT_X, bool WANT_XHAT, int NH>
 __global__ __launch_bounds__(256, 2) void k_embed(EmbedArgs a) {
     constexpr int D = 128 * NG, KP = 32 * KS, NACC = 8 * NG;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint4 *bimg = (uint4 *)smem;                       // [NACC][KS][64 lanes] 16-byte B fragments
     float *lnw = (float *)(smem + NACC * KS * 64 * 16);  // [D] LayerNorm weight, then [D] bias
     float *lnb = lnw + D;
+    float *mt = lnw;                                   // NH > 0: [NH][D] folded score vectors replace the affine tables
+    constexpr bool AFFINE = WANT_XHAT && NH == 0;      // NH > 0 emits the plain normalised tokens (affine folded by the caller)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
@@ -68,8 +83,10 @@ __global__ __launch_bounds__(256, 2) void k_embed(EmbedArgs a) {
         const int col = 128 * (acc >> 3) + 8 * (l & 15) + (acc & 7);
         bimg[f] = *(const uint4 *)(a.wt + (size_t)col * KP + 32 * s + 8 * (l >> 4));
     }
-    if (WANT_XHAT)
+    if (AFFINE)
         for (int i = tid; i < D; i += 256) { lnw[i] = a.ln_w[i]; lnb[i] = a.ln_b[i]; }
+    if (NH > 0)
+        for (int i = tid; i < NH * D; i += 256) mt[i] = a.mtab[i];
     __syncthreads();
 
     const int RC = a.R * a.Cc, T = a.T, ksz = a.ksz, kk = ksz * ksz, pad = ksz / 2, ncell = a.C * RC;
@@ -152,77 +169,131 @@ __global__ __launch_bounds__(256, 2) void k_embed(EmbedArgs a) {
             if ((n & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // keep B-fragment prefetch to 4 accumulators (VGPR budget)
         }
         // ---- epilogue: rows 4 (lane>>4) + r4, this lane's columns 128 g + 8 (lane&15) + q ----
+        float mean[4], rstd[4];
+        if (WANT_XHAT) {
 #pragma unroll
-        for (int r4 = 0; r4 < 4; r4++) {
-            const int tt = tile * 16 + 4 * l4 + r4;
-            const bool ok = tt < T && !((a.ablate & 2) && tt != 7777);
-            const size_t orow = ((size_t)leaf * T + (ok ? tt : 0)) * D;
-            float mean = 0.f, rstd = 0.f;
-            if (WANT_XHAT) {
+            for (int r4 = 0; r4 < 4; r4++) {
                 float s = 0.f;
 #pragma unroll
                 for (int n = 0; n < NACC; n++) s += acc[n][r4];
-#pragma unroll
-                for (int off = 1; off < 16; off <<= 1) s += __shfl_xor(s, off);
-                mean = s * (1.0f / (float)D);
+                s = row16_sum(s);
+                mean[r4] = s * (1.0f / (float)D);
                 float ss = 0.f;
 #pragma unroll
-                for (int n = 0; n < NACC; n++) { const float dl = acc[n][r4] - mean; ss += dl * dl; }
+                for (int n = 0; n < NACC; n++) { const float dl = acc[n][r4] - mean[r4]; ss += dl * dl; }
+                ss = row16_sum(ss);
+                rstd[r4] = rsqrtf(ss * (1.0f / (float)D) + a.eps);
+            }
+        }
 #pragma unroll
-                for (int off = 1; off < 16; off <<= 1) ss += __shfl_xor(ss, off);
-                rstd = rsqrtf(ss * (1.0f / (float)D) + a.eps);
+        for (int g = 0; g < NG; g++) {
+            f32x4 w0, w1, b0, b1;
+            if (AFFINE) {
+                w0 = *(const f32x4 *)(lnw + 128 * g + 8 * l15); w1 = *(const f32x4 *)(lnw + 128 * g + 8 * l15 + 4);
+                b0 = *(const f32x4 *)(lnb + 128 * g + 8 * l15); b1 = *(const f32x4 *)(lnb + 128 * g + 8 * l15 + 4);
             }
 #pragma unroll
-            for (int g = 0; g < NG; g++) {
+            for (int r4 = 0; r4 < 4; r4++) {
+                const int tt = tile * 16 + 4 * l4 + r4;
+                const bool ok = tt < T && !((a.ablate & 2) && tt != 7777);
+                const size_t orow = ((size_t)leaf * T + (tt < T ? tt : 0)) * D;
                 float v[8];
 #pragma unroll
                 for (int q = 0; q < 8; q++) v[q] = acc[g * 8 + q][r4];
                 if (WANT_X && ok) *(uint4 *)(a.x + orow + 128 * g + 8 * l15) = pack8(v);
                 if (WANT_XHAT) {
-                    const f32x4 w0 = *(const f32x4 *)(lnw + 128 * g + 8 * l15), w1 = *(const f32x4 *)(lnw + 128 * g + 8 * l15 + 4);
-                    const f32x4 b0 = *(const f32x4 *)(lnb + 128 * g + 8 * l15), b1 = *(const f32x4 *)(lnb + 128 * g + 8 * l15 + 4);
+                    if (AFFINE) {
 #pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        v[q] = (v[q] - mean) * rstd * w0[q] + b0[q];
-                        v[q + 4] = (v[q + 4] - mean) * rstd * w1[q] + b1[q];
+                        for (int q = 0; q < 4; q++) {
+                            v[q] = (v[q] - mean[r4]) * rstd[r4] * w0[q] + b0[q];
+                            v[q + 4] = (v[q + 4] - mean[r4]) * rstd[r4] * w1[q] + b1[q];
+                        }
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 8; q++) v[q] = (v[q] - mean[r4]) * rstd[r4];
                     }
                     if (ok) *(uint4 *)(a.xhat + orow + 128 * g + 8 * l15) = pack8(v);
+                    if (NH > 0) {
+#pragma unroll
+                        for (int q = 0; q < 8; q++) acc[g * 8 + q][r4] = v[q];      // keep xhat in place for the scores
+                    }
                 }
             }
+        }
+        float sc[NH > 0 ? NH : 1][4];
+        if (NH > 0) {
+#pragma unroll
+            for (int h = 0; h < NH; h++) {
+#pragma unroll
+                for (int r4 = 0; r4 < 4; r4++) sc[h][r4] = 0.f;
+#pragma unroll
+                for (int g = 0; g < NG; g++) {
+                    const f32x4 m0 = *(const f32x4 *)(mt + h * D + 128 * g + 8 * l15), m1 = *(const f32x4 *)(mt + h * D + 128 * g + 8 * l15 + 4);
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; r4++) {
+                        float p = sc[h][r4];
+#pragma unroll
+                        for (int q = 0; q < 4; q++) { p += acc[g * 8 + q][r4] * m0[q]; p += acc[g * 8 + q + 4][r4] * m1[q]; }
+                        sc[h][r4] = p;
+                    }
+                }
+            }
+        }
+        if (NH > 0) {
+            // reduce over the 16 lanes that share these 4 tokens, then lane (l15) stores scores (h = l15 >> 1, r4 = 2 (l15 & 1) + {0,1})
+            const int Tp = tiles_per_leaf * 16;
+#pragma unroll
+            for (int h = 0; h < NH; h++)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; r4++) {
+                    sc[h][r4] = row16_sum(sc[h][r4]);
+                }
+#pragma unroll
+            for (int h = 0; h < NH; h++)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; r4++)
+                    if (l15 == h * 2 + (r4 >> 1) && NH * 2 <= 16)
+                        a.scores[((size_t)leaf * NH + h) * Tp + tile * 16 + 4 * l4 + r4] = sc[h][r4];
         }
       }
     }
 }
 
-template <int NG, int KS, bool WX, bool WH>
+template <int NG, int KS, bool WX, bool WH, int NH>
 int launch_embed2(const EmbedArgs &a, hipStream_t st) {
     constexpr int NACC = 8 * NG;
-    const int lds = NACC * KS * 64 * 16 + 2 * 128 * NG * 4;
+    const int lds = NACC * KS * 64 * 16 + (NH > 0 ? NH : 2) * 128 * NG * 4;
     long long blocks = ((long long)a.n + 3) / 4;
     if (blocks > 512) blocks = 512;                    // 2 workgroups per CU resident (LDS + VGPR budget)
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void *)k_embed<NG, KS, WX, WH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return AZK_ERR_HIP;
+        if (hipFuncSetAttribute((const void *)k_embed<NG, KS, WX, WH, NH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return AZK_ERR_HIP;
         attr_set = true;
     }
-    k_embed<NG, KS, WX, WH><<<(unsigned)blocks, 256, lds, st>>>(a);
+    k_embed<NG, KS, WX, WH, NH><<<(unsigned)blocks, 256, lds, st>>>(a);
     return hipGetLastError() == hipSuccess ? AZK_OK : AZK_ERR_HIP;
 }
 
 template <int NG, int KS>
 int launch_embed(const EmbedArgs &a, hipStream_t st) {
-    if (a.x && a.xhat) return launch_embed2<NG, KS, true, true>(a, st);
-    if (a.xhat) return launch_embed2<NG, KS, false, true>(a, st);
-    return launch_embed2<NG, KS, true, false>(a, st);
+    if (a.mtab) {                                     // scores ride along with xhat (folded cls attention, shared query)
+        if (!a.xhat || a.x) return AZK_ERR_ARG;
+        if (a.nh == 8) return launch_embed2<NG, KS, false, true, 8>(a, st);
+        if (a.nh == 4) return launch_embed2<NG, KS, false, true, 4>(a, st);
+        return AZK_ERR_ARG;
+    }
+    if (a.x && a.xhat) return launch_embed2<NG, KS, true, true, 0>(a, st);
+    if (a.xhat) return launch_embed2<NG, KS, false, true, 0>(a, st);
+    return launch_embed2<NG, KS, true, false, 0>(a, st);
 }
 
 }  // namespace
 
-extern "C" int32_t azk_nn_patch_embed(const void *boards_dev, int32_t boards_are_f32, const void *wt_bf16_dev,
-                                      const float *cpos_dev, const float *ln_w_dev, const float *ln_b_dev,
-                                      void *x_out_bf16_dev, void *xhat_out_bf16_dev, int32_t n, int32_t channels,
-                                      int32_t rows, int32_t cols, int32_t ksize, int32_t kp, int32_t embed_dim,
-                                      float ln_eps, void *stream) {
+static int32_t patch_embed_impl(const void *boards_dev, int32_t boards_are_f32, const void *wt_bf16_dev,
+                                const float *cpos_dev, const float *ln_w_dev, const float *ln_b_dev,
+                                void *x_out_bf16_dev, void *xhat_out_bf16_dev, int32_t n, int32_t channels,
+                                int32_t rows, int32_t cols, int32_t ksize, int32_t kp, int32_t embed_dim,
+                                float ln_eps, const float *mtab_dev, float *scores_dev, int32_t num_heads, void *stream) {
     if (!boards_dev || !wt_bf16_dev || !cpos_dev || (!x_out_bf16_dev && !xhat_out_bf16_dev)) return AZK_ERR_ARG;
     if (xhat_out_bf16_dev && (!ln_w_dev || !ln_b_dev)) return AZK_ERR_ARG;
     if (n < 0 || channels < 1 || rows < 1 || cols < 1 || ksize < 1 || (ksize & 1) == 0 || ksize > 7) return AZK_ERR_ARG;
@@ -232,6 +303,8 @@ extern "C" int32_t azk_nn_patch_embed(const void *boards_dev, int32_t boards_are
     EmbedArgs a;
     a.boards = boards_dev; a.boards_f32 = boards_are_f32; a.wt = (const __hip_bfloat16 *)wt_bf16_dev; a.cpos = cpos_dev;
     a.ln_w = ln_w_dev; a.ln_b = ln_b_dev; a.x = (__hip_bfloat16 *)x_out_bf16_dev; a.xhat = (__hip_bfloat16 *)xhat_out_bf16_dev;
+    a.mtab = mtab_dev; a.scores = scores_dev; a.nh = num_heads;
+    if ((mtab_dev != nullptr) != (scores_dev != nullptr)) return AZK_ERR_ARG;
     { const char *ab = getenv("AZK_EMBED_ABLATE"); a.ablate = ab ? atoi(ab) : 0; }
     a.n = n; a.C = channels; a.R = rows; a.Cc = cols; a.ksz = ksize; a.T = rows * cols + 1; a.eps = ln_eps;
     hipStream_t st = (hipStream_t)stream;
@@ -242,6 +315,26 @@ extern "C" int32_t azk_nn_patch_embed(const void *boards_dev, int32_t boards_are
     CASE(1, 2); CASE(1, 1); CASE(1, 3);
 #undef CASE
     return AZK_ERR_ARG;   // unsupported (embed_dim, kp): the caller keeps its generic path
+}
+
+extern "C" int32_t azk_nn_patch_embed(const void *boards_dev, int32_t boards_are_f32, const void *wt_bf16_dev,
+                                      const float *cpos_dev, const float *ln_w_dev, const float *ln_b_dev,
+                                      void *x_out_bf16_dev, void *xhat_out_bf16_dev, int32_t n, int32_t channels,
+                                      int32_t rows, int32_t cols, int32_t ksize, int32_t kp, int32_t embed_dim,
+                                      float ln_eps, void *stream) {
+    return patch_embed_impl(boards_dev, boards_are_f32, wt_bf16_dev, cpos_dev, ln_w_dev, ln_b_dev, x_out_bf16_dev,
+                            xhat_out_bf16_dev, n, channels, rows, cols, ksize, kp, embed_dim, ln_eps, nullptr, nullptr, 0, stream);
+}
+
+extern "C" int32_t azk_nn_patch_embed_scores(const void *boards_dev, int32_t boards_are_f32, const void *wt_bf16_dev,
+                                             const float *cpos_dev, const float *ln_w_dev, const float *ln_b_dev,
+                                             void *xhat_out_bf16_dev, const float *m_dev, float *scores_out_dev,
+                                             int32_t num_heads, int32_t n, int32_t channels, int32_t rows, int32_t cols,
+                                             int32_t ksize, int32_t kp, int32_t embed_dim, float ln_eps, void *stream) {
+    if (!m_dev || !scores_out_dev) return AZK_ERR_ARG;
+    return patch_embed_impl(boards_dev, boards_are_f32, wt_bf16_dev, cpos_dev, ln_w_dev, ln_b_dev, nullptr,
+                            xhat_out_bf16_dev, n, channels, rows, cols, ksize, kp, embed_dim, ln_eps, m_dev, scores_out_dev,
+                            num_heads, stream);
 }
 
 // =====================================================================================================
@@ -375,6 +468,163 @@ extern "C" int32_t azk_nn_cls_attention(const void *xhat_bf16_dev, const float *
     a.n = n; a.T = tokens;
     hipStream_t st = (hipStream_t)stream;
 #define CASE(CPL_, NH_) if (embed_dim == 64 * CPL_ && num_heads == NH_) return launch_cls_attn<CPL_, NH_>(a, st)
+    CASE(8, 8); CASE(4, 8); CASE(4, 4); CASE(2, 4); CASE(2, 8); CASE(8, 4);
+#undef CASE
+    return AZK_ERR_ARG;
+}
+
+// =====================================================================================================
+// k_cls_pool: the streaming half of the folded cls attention when the scores already exist (emitted by k_embed for the
+// depth-1 case, where the cls query is a constant of the weights):  a = softmax_t(scores[b][h][:] + c[h]),
+// z[b][h][:] = sum_t a[h][t] * xhat[b][t][:].  No cross-lane reduction in the token loop: each lane owns 8 (CPL)
+// columns, reads its 16 bytes of every token row and the token's NH weights (one broadcast LDS read).
+// One workgroup per board, 4 waves interleave tokens, 4 tokens in flight per wave.  HBM-read-bound.
+// =====================================================================================================
+namespace {
+
+struct ClsPoolArgs {
+    const __hip_bfloat16 *xhat;   // [n][T][D]
+    const float *scores;          // [n][NH][Tp]
+    const float *c;               // [NH]
+    __hip_bfloat16 *z;            // [n][NH][D]
+    int n, T, Tp;
+    int ablate;                   // debug only (AZK_POOL_ABLATE): 1 no softmax phase, 2 no token loop, 4 no combine
+};
+
+template <int CPL>
+__device__ __forceinline__ void load_row(const unsigned short *p, float *xv) {
+    if (CPL == 8) {
+        const uint4 raw = *(const uint4 *)p;
+        xv[0] = __uint_as_float(raw.x << 16); xv[1] = __uint_as_float(raw.x & 0xffff0000u);
+        xv[2] = __uint_as_float(raw.y << 16); xv[3] = __uint_as_float(raw.y & 0xffff0000u);
+        xv[4] = __uint_as_float(raw.z << 16); xv[5] = __uint_as_float(raw.z & 0xffff0000u);
+        xv[6] = __uint_as_float(raw.w << 16); xv[7] = __uint_as_float(raw.w & 0xffff0000u);
+    } else if (CPL == 4) {
+        const uint2 raw = *(const uint2 *)p;
+        xv[0] = __uint_as_float(raw.x << 16); xv[1] = __uint_as_float(raw.x & 0xffff0000u);
+        xv[2] = __uint_as_float(raw.y << 16); xv[3] = __uint_as_float(raw.y & 0xffff0000u);
+    } else {
+        const unsigned raw = *(const unsigned *)p;
+        xv[0] = __uint_as_float(raw << 16); xv[1] = __uint_as_float(raw & 0xffff0000u);
+    }
+}
+
+template <int CPL, int NH>
+__global__ __launch_bounds__(256) void k_cls_pool(ClsPoolArgs a) {
+    constexpr int D = 64 * CPL;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x * 4 + wave;                     // one wavefront per board, no workgroup barriers
+    if (b >= a.n) return;
+    float *aw = (float *)smem + (size_t)wave * a.Tp * NH;    // [Tp][NH] softmax weights of this wave's board
+    const float *sp = a.scores + (size_t)b * NH * a.Tp;
+    // ---- softmax over tokens, per head (scores are tiny: NH * T floats): all loads first, then the reductions ----
+    if (!(a.ablate & 1)) {
+        float e[NH][4];
+#pragma unroll
+        for (int h = 0; h < NH; h++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int t = lane + 64 * k;
+                e[h][k] = t < a.T ? sp[h * a.Tp + t] : -3.0e38f;
+            }
+#pragma unroll
+        for (int h = 0; h < NH; h++) {
+            const float ch = a.c[h];
+            float mx = -3.0e38f;
+#pragma unroll
+            for (int k = 0; k < 4; k++) { e[h][k] += ch; mx = fmaxf(mx, e[h][k]); }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+            float sum = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; k++) { e[h][k] = (lane + 64 * k) < a.T ? __expf(e[h][k] - mx) : 0.f; sum += e[h][k]; }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+            const float inv = 1.0f / sum;
+#pragma unroll
+            for (int k = 0; k < 4; k++) { const int t = lane + 64 * k; if (t < a.Tp) aw[t * NH + h] = e[h][k] * inv; }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // ---- weighted token sum: each lane owns CPL columns; two 8-row register sets, one in flight while the other is
+    //      consumed (software pipelining: the wave always has 8-16 KB of loads outstanding) ----
+    float zacc[NH][CPL];
+#pragma unroll
+    for (int h = 0; h < NH; h++)
+#pragma unroll
+        for (int q = 0; q < CPL; q++) zacc[h][q] = 0.f;
+    const unsigned short *base = (const unsigned short *)a.xhat + (size_t)b * a.T * D + lane * CPL;
+    const int T = (a.ablate & 2) ? 0 : a.T;
+    auto consume = [&](const float (&x)[8][CPL], int t0) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            float w[NH];
+#pragma unroll
+            for (int h = 0; h < NH; h += 4) {
+                const f32x4 w4 = *(const f32x4 *)(aw + (t0 + k) * NH + h);
+                w[h] = w4[0]; w[h + 1] = w4[1]; w[h + 2] = w4[2]; w[h + 3] = w4[3];
+            }
+#pragma unroll
+            for (int h = 0; h < NH; h++)
+#pragma unroll
+                for (int q = 0; q < CPL; q++) zacc[h][q] += w[h] * x[k][q];
+        }
+    };
+    // rows past T are clamped to the last row; their weights aw[t >= T] are exactly 0 (Tp padding), so they add nothing
+    auto fetch = [&](float (&x)[8][CPL], int t0) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) { const int t = t0 + k < a.T ? t0 + k : a.T - 1; load_row<CPL>(base + (size_t)t * D, x[k]); }
+    };
+    float xa[8][CPL], xb[8][CPL];
+    if (T > 0) fetch(xa, 0);
+    for (int t = 0; t < T; t += 16) {
+        if (t + 8 < T) fetch(xb, t + 8);
+        consume(xa, t);
+        if (t + 16 < T) fetch(xa, t + 16);
+        if (t + 8 < T) consume(xb, t + 8);
+    }
+    if (a.ablate & 4) return;
+#pragma unroll
+    for (int h = 0; h < NH; h++) {
+        unsigned short *dst = (unsigned short *)a.z + ((size_t)b * NH + h) * D + lane * CPL;
+        if (CPL == 8) {
+            *(uint4 *)dst = pack8(zacc[h]);
+        } else {
+#pragma unroll
+            for (int q = 0; q < CPL; q++) dst[q] = __bfloat16_as_ushort(__float2bfloat16(zacc[h][q]));
+        }
+    }
+}
+
+template <int CPL, int NH>
+int launch_cls_pool(const ClsPoolArgs &a, hipStream_t st) {
+    const int lds = 4 * a.Tp * NH * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void *)k_cls_pool<CPL, NH>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess) return AZK_ERR_HIP;
+        attr_set = true;
+    }
+    if (lds > 64 * 1024) return AZK_ERR_ARG;
+    k_cls_pool<CPL, NH><<<(a.n + 3) / 4, 256, lds, st>>>(a);
+    return hipGetLastError() == hipSuccess ? AZK_OK : AZK_ERR_HIP;
+}
+
+}  // namespace
+
+extern "C" int32_t azk_nn_cls_pool(const void *xhat_bf16_dev, const float *scores_dev, const float *c_dev,
+                                   void *z_out_bf16_dev, int32_t n, int32_t tokens, int32_t embed_dim,
+                                   int32_t num_heads, void *stream) {
+    if (!xhat_bf16_dev || !scores_dev || !c_dev || !z_out_bf16_dev || n < 0 || tokens < 1) return AZK_ERR_ARG;
+    if (n == 0) return AZK_OK;
+    ClsPoolArgs a;
+    a.xhat = (const __hip_bfloat16 *)xhat_bf16_dev; a.scores = scores_dev; a.c = c_dev; a.z = (__hip_bfloat16 *)z_out_bf16_dev;
+    a.n = n; a.T = tokens; a.Tp = (tokens + 15) / 16 * 16;
+    { const char *ab = getenv("AZK_POOL_ABLATE"); a.ablate = ab ? atoi(ab) : 0; }
+    hipStream_t st = (hipStream_t)stream;
+#define CASE(CPL_, NH_) if (embed_dim == 64 * CPL_ && num_heads == NH_) return launch_cls_pool<CPL_, NH_>(a, st)
     CASE(8, 8); CASE(4, 8); CASE(4, 4); CASE(2, 4); CASE(2, 8); CASE(8, 4);
 #undef CASE
     return AZK_ERR_ARG;

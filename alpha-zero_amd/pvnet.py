@@ -161,6 +161,14 @@ class PolicyValueNet:
             q = (F.linear(h0, f["Wq"], f["bq"])).view(H, dh)
             f["m"] = (torch.einsum("he,hed->hd", q, f["Wk"]) * self.scale).contiguous()
             f["c"] = ((q * f["bk"]).sum(1) * self.scale).contiguous()
+            # LayerNorm affine folded out of the kernels: with xn = (x - mean) * rstd and xhat = gamma * xn + beta,
+            #   xhat . m + c = xn . (gamma * m) + (beta . m + c);   sum_t a_t xhat_t = gamma * (sum_t a_t xn_t) + beta
+            g, bta = self._hip["ln_w"], self._hip["ln_b"]
+            f["m_n"] = (f["m"] * g).contiguous()
+            f["c_n"] = (f["c"] + f["m"] @ bta).contiguous()
+            Wv = Wi[2 * D:].reshape(H, dh, D).to(dev)
+            f["WvT_n"] = (Wv * g).transpose(1, 2).contiguous().to(torch.bfloat16)                      # [H, D, dh]
+            f["bv_n"] = (bi[2 * D:].to(dev) + (Wv @ bta).reshape(-1)).to(torch.bfloat16)
         self._fold = f
 
     def _prepare_hip_embed(self):
@@ -249,21 +257,24 @@ class PolicyValueNet:
         h = F.linear(F.gelu(F.linear(h, w[b + "mlp.0.weight"], w[b + "mlp.0.bias"])), w[b + "mlp.3.weight"], w[b + "mlp.3.bias"])
         return x0 + h                                                          # [n, D]
 
-    def block_cls_folded(self, xhat, x0, i):
+    def block_cls_folded(self, xhat, x0, i, z=None, normalised=False):
         """Same function as block_cls, evaluated without forming K or V (see _prepare_folded)."""
         import azk
         w, cfg, f = self.w, self.cfg, self._fold
         b = f"blocks.{i}."
-        n, T, D = xhat.shape
+        D = cfg.embed_dim
+        n = x0.shape[0]
         H, dh = cfg.num_heads, D // cfg.num_heads
-        if "m" in f:
-            mm, cc = f["m"], f["c"]
-        else:                                    # depth > 1: the cls query depends on the board
-            q = F.linear(xhat[:, 0].float(), f["Wq"], f["bq"]).view(n, H, dh)
-            mm = (torch.einsum("nhe,hed->nhd", q, f["Wk"]) * self.scale).contiguous()
-            cc = ((q * f["bk"]).sum(2) * self.scale).contiguous()
-        z = azk.nn_cls_attention(xhat, mm, cc, H)                                # [n, H, D] bf16
-        a = torch.bmm(z.transpose(0, 1), f["WvT"]).transpose(0, 1).reshape(n, D) + f["bv"]
+        if z is None:
+            if "m" in f:
+                mm, cc = f["m"], f["c"]
+            else:                                    # depth > 1: the cls query depends on the board
+                q = F.linear(xhat[:, 0].float(), f["Wq"], f["bq"]).view(n, H, dh)
+                mm = (torch.einsum("nhe,hed->nhd", q, f["Wk"]) * self.scale).contiguous()
+                cc = ((q * f["bk"]).sum(2) * self.scale).contiguous()
+            z = azk.nn_cls_attention(xhat, mm, cc, H)                            # [n, H, D] bf16
+        WvT, bv = (f["WvT_n"], f["bv_n"]) if normalised else (f["WvT"], f["bv"])
+        a = torch.bmm(z.transpose(0, 1), WvT).transpose(0, 1).reshape(n, D) + bv
         x0 = x0 + F.linear(a, w[b + "attn.out_proj.weight"], w[b + "attn.out_proj.bias"])
         h = self._ln(x0, b + "norm2")
         h = F.linear(F.gelu(F.linear(h, w[b + "mlp.0.weight"], w[b + "mlp.0.bias"])), w[b + "mlp.3.weight"], w[b + "mlp.3.bias"])
@@ -285,8 +296,17 @@ class PolicyValueNet:
                 raise RuntimeError("path 'clsfold' needs the HIP kernels (CUDA, bf16, supported embed_dim/heads)")
             last = depth - 1
             if depth == 1:
+                import azk
+                hp, f = self._hip, self._fold
+                x0 = hp["cpos"][0].to(self.dtype).expand(x.shape[0], -1)
+                if self.cfg.num_heads in (4, 8):
+                    if x.dtype not in (torch.bfloat16, torch.float32):
+                        x = x.float()
+                    z = azk.nn_embed_scores_pool(x.contiguous(), hp["wt"], hp["cpos"], hp["ln_w"], hp["ln_b"], f["m_n"], f["c_n"],
+                                                 self.cfg.rows, self.cfg.cols, self.cfg.patch_size, self.cfg.embed_dim,
+                                                 self.cfg.num_heads)
+                    return self.heads(self.block_cls_folded(None, x0, last, z=z, normalised=True))
                 _, xhat = self.embed_hip(x, want_x=False, want_xhat=True)
-                x0 = self._hip["cpos"][0].to(self.dtype).expand(x.shape[0], -1)
             else:
                 t = self.embed(x)
                 for i in range(last):
