@@ -36,6 +36,7 @@ struct EmbedArgs {
     const float *mtab;         // [NH][D] folded score vectors (scale * Wk_h^T q_h), or null
     float *scores;             // [n][NH][Tp] (Tp = 16*ceil(T/16)) xhat_t . m_h, written when mtab != null
     int nh;
+    const int *count;          // optional device-side number of valid boards (<= n): rows beyond it are skipped
     int n, C, R, Cc, ksz, T;
     float eps;
     int ablate;                // debug only (AZK_EMBED_ABLATE): 1 no cpos loads, 2 no stores, 4 no MFMA, 8 no patch build
@@ -95,7 +96,8 @@ __global__ __launch_bounds__(256, 2) void k_embed(EmbedArgs a) {
 
 
     // one wavefront owns one board: its bit string is built once, then the wave walks the board's 16-token tiles
-    for (int leaf = blockIdx.x * 4 + wave; leaf < a.n; leaf += nwaves) {
+    const int nvalid = a.count ? min(a.n, *a.count) : a.n;
+    for (int leaf = blockIdx.x * 4 + wave; leaf < nvalid; leaf += nwaves) {
         unsigned wbits = 0;                             // lane i holds bits [32 (i-1), 32 i) of the board bit string (lane 0: zeros)
         if (!(a.ablate & 8)) {
             for (int q = 0; q * 64 < ncell; q++) {
@@ -293,7 +295,8 @@ static int32_t patch_embed_impl(const void *boards_dev, int32_t boards_are_f32, 
                                 const float *cpos_dev, const float *ln_w_dev, const float *ln_b_dev,
                                 void *x_out_bf16_dev, void *xhat_out_bf16_dev, int32_t n, int32_t channels,
                                 int32_t rows, int32_t cols, int32_t ksize, int32_t kp, int32_t embed_dim,
-                                float ln_eps, const float *mtab_dev, float *scores_dev, int32_t num_heads, void *stream) {
+                                float ln_eps, const float *mtab_dev, float *scores_dev, int32_t num_heads,
+                                const int32_t *n_valid_dev, void *stream) {
     if (!boards_dev || !wt_bf16_dev || !cpos_dev || (!x_out_bf16_dev && !xhat_out_bf16_dev)) return AZK_ERR_ARG;
     if (xhat_out_bf16_dev && (!ln_w_dev || !ln_b_dev)) return AZK_ERR_ARG;
     if (n < 0 || channels < 1 || rows < 1 || cols < 1 || ksize < 1 || (ksize & 1) == 0 || ksize > 7) return AZK_ERR_ARG;
@@ -303,7 +306,7 @@ static int32_t patch_embed_impl(const void *boards_dev, int32_t boards_are_f32, 
     EmbedArgs a;
     a.boards = boards_dev; a.boards_f32 = boards_are_f32; a.wt = (const __hip_bfloat16 *)wt_bf16_dev; a.cpos = cpos_dev;
     a.ln_w = ln_w_dev; a.ln_b = ln_b_dev; a.x = (__hip_bfloat16 *)x_out_bf16_dev; a.xhat = (__hip_bfloat16 *)xhat_out_bf16_dev;
-    a.mtab = mtab_dev; a.scores = scores_dev; a.nh = num_heads;
+    a.mtab = mtab_dev; a.scores = scores_dev; a.nh = num_heads; a.count = n_valid_dev;
     if ((mtab_dev != nullptr) != (scores_dev != nullptr)) return AZK_ERR_ARG;
     { const char *ab = getenv("AZK_EMBED_ABLATE"); a.ablate = ab ? atoi(ab) : 0; }
     a.n = n; a.C = channels; a.R = rows; a.Cc = cols; a.ksz = ksize; a.T = rows * cols + 1; a.eps = ln_eps;
@@ -323,18 +326,19 @@ extern "C" int32_t azk_nn_patch_embed(const void *boards_dev, int32_t boards_are
                                       int32_t rows, int32_t cols, int32_t ksize, int32_t kp, int32_t embed_dim,
                                       float ln_eps, void *stream) {
     return patch_embed_impl(boards_dev, boards_are_f32, wt_bf16_dev, cpos_dev, ln_w_dev, ln_b_dev, x_out_bf16_dev,
-                            xhat_out_bf16_dev, n, channels, rows, cols, ksize, kp, embed_dim, ln_eps, nullptr, nullptr, 0, stream);
+                            xhat_out_bf16_dev, n, channels, rows, cols, ksize, kp, embed_dim, ln_eps, nullptr, nullptr, 0, nullptr, stream);
 }
 
 extern "C" int32_t azk_nn_patch_embed_scores(const void *boards_dev, int32_t boards_are_f32, const void *wt_bf16_dev,
                                              const float *cpos_dev, const float *ln_w_dev, const float *ln_b_dev,
                                              void *xhat_out_bf16_dev, const float *m_dev, float *scores_out_dev,
                                              int32_t num_heads, int32_t n, int32_t channels, int32_t rows, int32_t cols,
-                                             int32_t ksize, int32_t kp, int32_t embed_dim, float ln_eps, void *stream) {
+                                             int32_t ksize, int32_t kp, int32_t embed_dim, float ln_eps,
+                                             const int32_t *n_valid_dev, void *stream) {
     if (!m_dev || !scores_out_dev) return AZK_ERR_ARG;
     return patch_embed_impl(boards_dev, boards_are_f32, wt_bf16_dev, cpos_dev, ln_w_dev, ln_b_dev, nullptr,
                             xhat_out_bf16_dev, n, channels, rows, cols, ksize, kp, embed_dim, ln_eps, m_dev, scores_out_dev,
-                            num_heads, stream);
+                            num_heads, n_valid_dev, stream);
 }
 
 // =====================================================================================================
@@ -488,6 +492,7 @@ struct ClsPoolArgs {
     const float *c;               // [NH]
     __hip_bfloat16 *z;            // [n][NH][D]
     int n, T, Tp;
+    const int *count;             // optional device-side number of valid boards
     int ablate;                   // debug only (AZK_POOL_ABLATE): 1 no softmax phase, 2 no token loop, 4 no combine
 };
 
@@ -515,7 +520,7 @@ __global__ __launch_bounds__(256) void k_cls_pool(ClsPoolArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x * 4 + wave;                     // one wavefront per board, no workgroup barriers
-    if (b >= a.n) return;
+    if (b >= (a.count ? min(a.n, *a.count) : a.n)) return;
     float *aw = (float *)smem + (size_t)wave * a.Tp * NH;    // [Tp][NH] softmax weights of this wave's board
     const float *sp = a.scores + (size_t)b * NH * a.Tp;
     // ---- softmax over tokens, per head (scores are tiny: NH * T floats): all loads first, then the reductions ----
@@ -616,12 +621,12 @@ int launch_cls_pool(const ClsPoolArgs &a, hipStream_t st) {
 
 extern "C" int32_t azk_nn_cls_pool(const void *xhat_bf16_dev, const float *scores_dev, const float *c_dev,
                                    void *z_out_bf16_dev, int32_t n, int32_t tokens, int32_t embed_dim,
-                                   int32_t num_heads, void *stream) {
+                                   int32_t num_heads, const int32_t *n_valid_dev, void *stream) {
     if (!xhat_bf16_dev || !scores_dev || !c_dev || !z_out_bf16_dev || n < 0 || tokens < 1) return AZK_ERR_ARG;
     if (n == 0) return AZK_OK;
     ClsPoolArgs a;
     a.xhat = (const __hip_bfloat16 *)xhat_bf16_dev; a.scores = scores_dev; a.c = c_dev; a.z = (__hip_bfloat16 *)z_out_bf16_dev;
-    a.n = n; a.T = tokens; a.Tp = (tokens + 15) / 16 * 16;
+    a.n = n; a.T = tokens; a.Tp = (tokens + 15) / 16 * 16; a.count = n_valid_dev;
     { const char *ab = getenv("AZK_POOL_ABLATE"); a.ablate = ab ? atoi(ab) : 0; }
     hipStream_t st = (hipStream_t)stream;
 #define CASE(CPL_, NH_) if (embed_dim == 64 * CPL_ && num_heads == NH_) return launch_cls_pool<CPL_, NH_>(a, st)

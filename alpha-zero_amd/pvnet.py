@@ -114,6 +114,7 @@ class PolicyValueNet:
                 raise ValueError(f"{k_}: shape {tuple(w[k_].shape)} != {shp}")
         self.master = {k_: torch.as_tensor(v).detach().to(torch.float32).cpu().clone() for k_, v in w.items()}
         self.path = path
+        self.live_count = None      # optional int32 CUDA tensor: number of valid rows at the head of the batch (graph stepping)
         self.to(device, dtype)
 
     # ---- state_dict compatibility with utils.save_model / load_model (utils.py:57-69) ----------------
@@ -304,7 +305,7 @@ class PolicyValueNet:
                         x = x.float()
                     z = azk.nn_embed_scores_pool(x.contiguous(), hp["wt"], hp["cpos"], hp["ln_w"], hp["ln_b"], f["m_n"], f["c_n"],
                                                  self.cfg.rows, self.cfg.cols, self.cfg.patch_size, self.cfg.embed_dim,
-                                                 self.cfg.num_heads)
+                                                 self.cfg.num_heads, count=self.live_count)
                     return self.heads(self.block_cls_folded(None, x0, last, z=z, normalised=True))
                 _, xhat = self.embed_hip(x, want_x=False, want_xhat=True)
             else:

@@ -188,6 +188,8 @@ class SelfPlayRunner:
         boards; their outputs are never read (slot indices stop at n_leaf)."""
         e = self.eng
         e.step(self.logits_buf, self.values_buf)
+        if hasattr(self.evaluator, "live_count"):
+            self.evaluator.live_count = e.n_leaf          # kernels that honour it skip the rows past the live leaves
         logits, values = self.evaluator(e.leaf_boards)
         self.logits_buf.copy_(logits)
         self.values_buf.copy_(values.reshape(-1))

@@ -216,14 +216,18 @@ int32_t azk_nn_cls_attention(const void *xhat_bf16_dev, const float *m_dev, cons
  *       scores_out[b][h][t] = xn[b][t][:] . m[h][:]  (float32 [n][H][Tp], Tp = 16*ceil(T/16))
  *   azk_nn_cls_pool - a = softmax_t(scores + c[h]);  z[b][h][:] = sum_t a[h][t] * xhat[b][t][:]  ([n][H][D] bf16):
  *       one streaming pass over xhat with no cross-lane reductions (HBM-read-bound).
+ * n_valid_dev (optional, device int32): only the first min(n, *n_valid_dev) boards are processed - lets a captured
+ * hipGraph with fixed launch sizes do work proportional to the live leaf count (azk_step_select's n_leaf_dev).
  * Heads: 8 or 4 (and 2*H <= 16). */
 int32_t azk_nn_patch_embed_scores(const void *boards_dev, int32_t boards_are_f32, const void *wt_bf16_dev,
                                   const float *cpos_dev, const float *ln_w_dev, const float *ln_b_dev,
                                   void *xhat_out_bf16_dev, const float *m_dev, float *scores_out_dev,
                                   int32_t num_heads, int32_t n, int32_t channels, int32_t rows, int32_t cols,
-                                  int32_t ksize, int32_t kp, int32_t embed_dim, float ln_eps, void *stream);
+                                  int32_t ksize, int32_t kp, int32_t embed_dim, float ln_eps,
+                                  const int32_t *n_valid_dev, void *stream);
 int32_t azk_nn_cls_pool(const void *xhat_bf16_dev, const float *scores_dev, const float *c_dev, void *z_out_bf16_dev,
-                        int32_t n, int32_t tokens, int32_t embed_dim, int32_t num_heads, void *stream);
+                        int32_t n, int32_t tokens, int32_t embed_dim, int32_t num_heads, const int32_t *n_valid_dev,
+                        void *stream);
 
 /* float32 softmax exactly as the engine applies it to logits (test hook; [n][A] -> [n][A]) */
 int32_t azk_softmax_rows(const float *logits_dev, int32_t n, int32_t action_dim, float *out_dev, void *stream);
