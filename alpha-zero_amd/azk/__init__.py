@@ -25,7 +25,7 @@ SYMBOLS = [
     "azk_get_counters", "azk_reset_counters", "azk_check_device_error", "azk_gen_noise",
     "azk_rules_legal_moves", "azk_rules_legal_mask", "azk_rules_apply_move", "azk_rules_undo_move",
     "azk_rules_check_winner", "azk_rules_canonical", "azk_softmax_rows",
-    "azk_step_tree", "azk_step_gather", "azk_recycle_finished", "azk_nn_patch_embed", "azk_nn_cls_attention", "azk_nn_patch_embed_scores", "azk_nn_cls_pool",
+    "azk_step_tree", "azk_step_gather", "azk_recycle_finished", "azk_nn_patch_embed", "azk_nn_cls_attention", "azk_nn_patch_embed_scores", "azk_nn_cls_pool", "azk_debug_stamps",
 ]
 
 
@@ -96,6 +96,7 @@ def lib():
     L.azk_get_positions.argtypes = [vp, vp, vp, vp, vp]
     L.azk_get_counters.argtypes = [vp, C.POINTER(Counters), vp]
     L.azk_reset_counters.argtypes = [vp, vp]
+    L.azk_debug_stamps.argtypes = [vp, vp]
     L.azk_check_device_error.argtypes = [vp, vp]
     L.azk_gen_noise.argtypes = [vp, u64, i64, i32, f64, vp, vp, vp]
     for name in ("azk_rules_legal_moves",):

@@ -27,13 +27,38 @@ __device__ __forceinline__ int uniform_i32(int v) { return __builtin_amdgcn_read
 
 // ---- wave reductions -------------------------------------------------------------------------
 // argmax with "first maximum wins" (Python max(), node.py:47,81): larger value, then lower index.
+// Steps inside a 16-lane row use DPP lane permutes (quad_perm, row_half_mirror, row_mirror: any pairing of disjoint
+// halves is a valid reduction step); the two cross-row steps use ds_bpermute.  Every lane ends with the winner.
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false); }
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) { return __builtin_bit_cast(float, dpp_i32<CTRL>(__builtin_bit_cast(int, v))); }
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    long long b = __builtin_bit_cast(long long, v);
+    int lo = dpp_i32<CTRL>((int)b), hi = dpp_i32<CTRL>((int)(b >> 32));
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
+}
+template <int CTRL> __device__ __forceinline__ float dpp_val(float v) { return dpp_f32<CTRL>(v); }
+template <int CTRL> __device__ __forceinline__ double dpp_val(double v) { return dpp_f64<CTRL>(v); }
+template <int CTRL> __device__ __forceinline__ int dpp_val(int v) { return dpp_i32<CTRL>(v); }
+
+template <typename T>
+__device__ __forceinline__ void argmax_combine(T &v, int &idx, T ov, int oi) {
+    if (oi < 0x7fffffff && (idx == 0x7fffffff || ov > v || (ov == v && oi < idx))) { v = ov; idx = oi; }
+}
+
 template <typename T>
 __device__ __forceinline__ void wave_argmax_first(T &v, int &idx) {
+    argmax_combine(v, idx, dpp_val<0xB1>(v), dpp_i32<0xB1>(idx));     // quad_perm [1,0,3,2]
+    argmax_combine(v, idx, dpp_val<0x4E>(v), dpp_i32<0x4E>(idx));     // quad_perm [2,3,0,1]
+    argmax_combine(v, idx, dpp_val<0x141>(v), dpp_i32<0x141>(idx));   // row_half_mirror
+    argmax_combine(v, idx, dpp_val<0x140>(v), dpp_i32<0x140>(idx));   // row_mirror
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
+    for (int off = 16; off <= 32; off <<= 1) {
         T ov = __shfl_xor(v, off);
         int oi = __shfl_xor(idx, off);
-        if (oi < 0x7fffffff && (idx == 0x7fffffff || ov > v || (ov == v && oi < idx))) { v = ov; idx = oi; }
+        argmax_combine(v, idx, ov, oi);
     }
 }
 
@@ -82,23 +107,10 @@ struct MoveScratch {
     int16_t *ord;                // [rc] candidate cells in first-insertion order
     unsigned long long *chash;   // [rc] tuple hash per cell
     uint16_t *tabA, *tabB;       // [table_size] emulated set tables (cell+1, 0 = empty)
+    uint32_t *claim;             // [table_size] per-slot lowest claiming lane of the current round (0xffffffff = none)
+    uint32_t *rows;              // [64] row bitmasks: [0,32) stones, [32,64) occupied (bit c+1 of word r+1)
     int table_size;
 };
-
-// set_insert_clean (Objects/setobject.c): first free slot along the probe sequence
-__device__ __forceinline__ void py_set_insert_clean(uint16_t *tab, unsigned mask, uint16_t key, unsigned long long h) {
-    unsigned long long perturb = h;
-    unsigned i = (unsigned)h & mask;
-    for (;;) {
-        if (tab[i] == 0) { tab[i] = key; return; }
-        if (i + 9 <= mask) {
-            for (unsigned j = 1; j <= 9; j++)
-                if (tab[i + j] == 0) { tab[i + j] = key; return; }
-        }
-        perturb >>= 5;
-        i = (unsigned)((unsigned long long)i * 5 + 1 + perturb) & mask;
-    }
-}
 
 // get_valid_moves in the reference's LIST ORDER; returns the count (wave-uniform); moves[] in LDS.
 //   TicTacToe  tictactoe.py:82-83   empty cells, row-major
@@ -106,7 +118,8 @@ __device__ __forceinline__ void py_set_insert_clean(uint16_t *tab, unsigned mask
 //   Gomoku     gomoku.py:93-106     empty 8-neighbours of any stone as list(set(...)): CPython set
 //                                   iteration order; centre cell when there is no candidate.
 // All lanes must call this (it synchronises the single-wave workgroup).
-__device__ int azk_valid_moves(const uint8_t *b, const GameDesc &g, int16_t *moves, const MoveScratch &ms) {
+__device__ int azk_valid_moves(const uint8_t *b, const GameDesc &g, int16_t *moves, const MoveScratch &ms, bool skip_set = false,
+                               long long *dbgv = nullptr) {
     const int lane = azk_lane();
     int n = 0;
     if (g.kind == AZK_KIND_TTT) {
@@ -134,41 +147,65 @@ __device__ int azk_valid_moves(const uint8_t *b, const GameDesc &g, int16_t *mov
     // ---- Gomoku ----
     const int R = g.rows, C = g.cols, rc = g.rc;
     const int nwords = (rc * 8 + 31) >> 5;
+    constexpr int KMAX = 7;                                       // cells per lane: rc <= 448
+    long long s0 = dbgv ? clock64() : 0, s1 = 0, s2 = 0, s3 = 0;
+    // row bitmasks (bit c+1 of word r+1; zero border all around): stones (code & 3) and occupied (code != 0)
+    uint32_t *rowst = ms.rows, *rowoc = ms.rows + 32;
     for (int w = lane; w < nwords; w += AZK_WAVE) ms.bits[w] = 0u;
+    for (int i = lane; i < ms.table_size; i += AZK_WAVE) { ms.tabA[i] = 0; ms.tabB[i] = 0; ms.claim[i] = 0xffffffffu; }
+    if (lane < 64) ms.rows[lane] = 0u;
     __syncthreads();
-    // 1. per empty cell: key = (row-major index of the first stone that adds it) * 8 + (its slot in that
-    //    stone's add order: (0,+1) (0,-1) (+1,0) (-1,0) (+1,+1) (-1,-1) (+1,-1) (-1,+1)), gomoku.py:97-102
-    for (int e = lane; e < rc; e += AZK_WAVE) {
-        if (b[e] != 0) continue;
-        int r = e / C, c = e % C;
-        unsigned key = 0xffffffffu;
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            int d = j >> 1, sg = (j & 1) ? -1 : 1;
-            int dr = (d > 0 ? 1 : 0) * sg;
-            int dc = (d == 0 ? 1 : (d == 1 ? 0 : (d == 2 ? 1 : -1))) * sg;
-            int sr = r - dr, sc = c - dc;                       // the stone that would add e through slot j
-            if (sr >= 0 && sr < R && sc >= 0 && sc < C && (b[sr * C + sc] & 3)) {
-                unsigned k = (unsigned)(sr * C + sc) * 8u + (unsigned)j;
-                key = k < key ? k : key;
+    for (int k = 0; k < KMAX; k++) {
+        const int e = lane + AZK_WAVE * k;
+        if (e < rc) {
+            const uint8_t code = b[e];
+            if (code) {
+                const int r = e / C, c = e - r * C;
+                atomicOr(&rowoc[r + 1], 1u << (c + 1));
+                if (code & 3) atomicOr(&rowst[r + 1], 1u << (c + 1));
             }
         }
-        if (key != 0xffffffffu) {
-            atomicOr(&ms.bits[key >> 5], 1u << (key & 31));
-            ms.chash[e] = py_tuple2_hash(r, c);
-        }
-        // stash the key for pass 2 in the ord array's upper half? keys are recomputed instead (cheap, LDS-resident board)
     }
     __syncthreads();
+    // 1. per empty cell: key = (row-major index of the first stone that adds it) * 8 + (its slot in that stone's add
+    //    order: (0,+1) (0,-1) (+1,0) (-1,0) (+1,+1) (-1,-1) (+1,-1) (-1,+1)), gomoku.py:97-102.  The smallest key belongs
+    //    to the smallest stone index, i.e. row r-1 (c-1, c, c+1), then row r (c-1, c+1), then row r+1 (c-1, c, c+1).
+    unsigned key[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; k++) {
+        const int e = lane + AZK_WAVE * k;
+        unsigned kk = 0xffffffffu;
+        if (e < rc) {
+            const int r = e / C, c = e - r * C;
+            const uint32_t up = rowst[r] >> c, mid = rowst[r + 1] >> c, dn = rowst[r + 2] >> c;   // bit0 = col c-1, bit1 = c, bit2 = c+1
+            const bool empty = ((rowoc[r + 1] >> (c + 1)) & 1u) == 0u;
+            if (empty) {
+                const unsigned ib = (unsigned)((r - 1) * C + c - 1), im = (unsigned)(r * C + c - 1), id = (unsigned)((r + 1) * C + c - 1);
+                if (up & 1u) kk = ib * 8u + 4u;                     // stone (r-1, c-1) adds e through (+1,+1)
+                else if (up & 2u) kk = (ib + 1u) * 8u + 2u;         // (r-1, c)   through (+1, 0)
+                else if (up & 4u) kk = (ib + 2u) * 8u + 6u;         // (r-1, c+1) through (+1,-1)
+                else if (mid & 1u) kk = im * 8u + 0u;               // (r, c-1)   through (0,+1)
+                else if (mid & 4u) kk = (im + 2u) * 8u + 1u;        // (r, c+1)   through (0,-1)
+                else if (dn & 1u) kk = id * 8u + 7u;                // (r+1, c-1) through (-1,+1)
+                else if (dn & 2u) kk = (id + 1u) * 8u + 3u;         // (r+1, c)   through (-1, 0)
+                else if (dn & 4u) kk = (id + 2u) * 8u + 5u;         // (r+1, c+1) through (-1,-1)
+            }
+            if (kk != 0xffffffffu) atomicOr(&ms.bits[kk >> 5], 1u << (kk & 31));
+        }
+        key[k] = kk;
+    }
+    __syncthreads();
+    if (dbgv) s1 = clock64();
     // 2. exclusive popcount prefix over the key bitmap (<= 128 words)
     int total = 0;
     for (int base = 0; base < nwords; base += AZK_WAVE) {
-        int w = base + lane;
-        int p = w < nwords ? __popc(ms.bits[w]) : 0;
+        const int w = base + lane;
+        const int p = w < nwords ? __popc(ms.bits[w]) : 0;
         int incl = p;
 #pragma unroll
         for (int off = 1; off < AZK_WAVE; off <<= 1) {
-            int t = __shfl_up(incl, off);
+            const int t = __shfl_up(incl, off);
             if (lane >= off) incl += t;
         }
         if (w < nwords) ms.pref[w] = (uint16_t)(total + incl - p);
@@ -181,65 +218,102 @@ __device__ int azk_valid_moves(const uint8_t *b, const GameDesc &g, int16_t *mov
         __syncthreads();
         return 1;
     }
-    // 3. rank every candidate by its key -> first-insertion order
-    for (int e = lane; e < rc; e += AZK_WAVE) {
-        if (b[e] != 0) continue;
-        int r = e / C, c = e % C;
-        unsigned key = 0xffffffffu;
+    // 3. rank every candidate by its key -> first-insertion order (ord[] holds cell + 1)
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            int d = j >> 1, sg = (j & 1) ? -1 : 1;
-            int dr = (d > 0 ? 1 : 0) * sg;
-            int dc = (d == 0 ? 1 : (d == 1 ? 0 : (d == 2 ? 1 : -1))) * sg;
-            int sr = r - dr, sc = c - dc;
-            if (sr >= 0 && sr < R && sc >= 0 && sc < C && (b[sr * C + sc] & 3)) {
-                unsigned k = (unsigned)(sr * C + sc) * 8u + (unsigned)j;
-                key = k < key ? k : key;
-            }
-        }
-        if (key != 0xffffffffu) {
-            int rank = ms.pref[key >> 5] + __popc(ms.bits[key >> 5] & ((1u << (key & 31)) - 1u));
-            ms.ord[rank] = (int16_t)e;
+    for (int k = 0; k < KMAX; k++) {
+        if (key[k] != 0xffffffffu) {
+            const int rank = ms.pref[key[k] >> 5] + __popc(ms.bits[key[k] >> 5] & ((1u << (key[k] & 31)) - 1u));
+            ms.ord[rank] = (int16_t)(lane + AZK_WAVE * k + 1);
         }
     }
-    for (int i = lane; i < ms.table_size; i += AZK_WAVE) ms.tabA[i] = 0;
     __syncthreads();
-    // 4. replay the inserts into the emulated CPython set (set_add_entry + set_table_resize); serial by nature
+    if (skip_set) {   // timing experiment only: first-insertion order instead of CPython set order
+        for (int i = lane; i < m; i += AZK_WAVE) moves[i] = (int16_t)(ms.ord[i] - 1);
+        __syncthreads();
+        return m;
+    }
+    if (dbgv) s2 = clock64();
+    // 4. replay the inserts into the emulated CPython set (set_add_entry + set_table_resize).  Sequential semantics,
+    //    parallel execution: up to 64 keys IN ORDER per round, one per lane.  Every lane probes for its key against the
+    //    committed table (probe = slot i..i+9 then perturb, LINEAR_PROBES = 9); atomicMin claims on the chosen (first
+    //    empty) slot expose clashes; the conflict-free PREFIX commits (a later key may only commit once every earlier key
+    //    has, otherwise an earlier key re-probing could have reached its slot first); the rest retry next round.
+    auto insert_batch = [&](uint16_t *tb, unsigned msk, const int16_t *list, int count) {
+        for (int c0 = 0; c0 < count; c0 += AZK_WAVE) {
+            const int idx = c0 + lane;
+            const bool have = idx < count;
+            const unsigned keyv = have ? (unsigned)list[idx] : 0u;   // cell + 1
+            const int cell = (int)keyv - 1;
+            const unsigned long long h = py_tuple2_hash(cell / C, cell % C);
+            bool placed = !have;
+            while (__ballot(!placed) != 0ull) {
+                unsigned slot = 0;
+                if (!placed) {
+                    unsigned long long perturb = h;
+                    unsigned i = (unsigned)h & msk;
+                    for (;;) {
+                        const unsigned win = (i + 9 <= msk) ? 10u : 1u;
+                        bool found = false;
+                        for (unsigned j = 0; j < win; j++)
+                            if (tb[i + j] == 0) { slot = i + j; found = true; break; }
+                        if (found) break;
+                        perturb >>= 5;
+                        i = (unsigned)((unsigned long long)i * 5 + 1 + perturb) & msk;
+                    }
+                    atomicMin(&ms.claim[slot], (unsigned)lane);
+                }
+                __syncthreads();
+                const bool conflict = !placed && ms.claim[slot] != (unsigned)lane;
+                const unsigned long long cb = __ballot(conflict);
+                const int first_bad = cb ? __ffsll((long long)cb) - 1 : AZK_WAVE;
+                __syncthreads();
+                if (!placed) {
+                    ms.claim[slot] = 0xffffffffu;
+                    if (lane < first_bad) { tb[slot] = (uint16_t)keyv; placed = true; }
+                }
+                __syncthreads();
+            }
+        }
+    };
     uint16_t *tab = ms.tabA, *other = ms.tabB;
     unsigned mask = 7;
-    if (lane == 0) {
-        int fill = 0;
-        for (int t = 0; t < m; t++) {
-            int cell = ms.ord[t];
-            unsigned long long h = ms.chash[cell];
-            py_set_insert_clean(tab, mask, (uint16_t)(cell + 1), h);   // keys are distinct: add == clean insert
-            fill++;
-            if ((unsigned)fill * 5u >= mask * 3u) {
-                unsigned newsize = 8, minused = (unsigned)fill * 4u;
-                while (newsize <= minused) newsize <<= 1;
-                for (unsigned i = 0; i < newsize; i++) other[i] = 0;
-                for (unsigned i = 0; i <= mask; i++) {
-                    uint16_t k = tab[i];
-                    if (k) py_set_insert_clean(other, newsize - 1, k, ms.chash[k - 1]);
-                }
-                uint16_t *tmp = tab; tab = other; other = tmp;
-                mask = newsize - 1;
+    int fill = 0, pos = 0;
+    while (pos < m) {
+        const int thr = (int)((mask * 3u + 4u) / 5u);             // smallest fill with fill*5 >= mask*3
+        int cnt = m - pos;
+        if (cnt > thr - fill) cnt = thr - fill;
+        insert_batch(tab, mask, ms.ord + pos, cnt);
+        fill += cnt; pos += cnt;
+        if ((unsigned)fill * 5u >= mask * 3u) {                   // set_table_resize(so, used * 4)
+            unsigned newsize = 8;
+            const unsigned minused = (unsigned)fill * 4u;
+            while (newsize <= minused) newsize <<= 1;
+            int n2 = 0;                                           // old table in slot order = re-insertion order
+            for (unsigned base = 0; base <= mask; base += AZK_WAVE) {
+                const unsigned i = base + lane;
+                const uint16_t kv = i <= mask ? tab[i] : (uint16_t)0;
+                const unsigned long long bm = __ballot(kv != 0);
+                if (kv) moves[n2 + __popcll(bm & ((1ull << lane) - 1ull))] = (int16_t)kv;   // `moves` doubles as the scratch list
+                n2 += __popcll(bm);
+                if (i <= mask) tab[i] = 0;
             }
+            __syncthreads();
+            insert_batch(other, newsize - 1, moves, n2);
+            uint16_t *tmp = tab; tab = other; other = tmp;
+            mask = newsize - 1;
         }
     }
-    __syncthreads();
-    mask = (unsigned)uniform_i32((int)mask);
-    bool useB = uniform_i32(tab == ms.tabB ? 1 : 0) != 0;
-    tab = useB ? ms.tabB : ms.tabA;
+    if (dbgv) s3 = clock64();
     // 5. list(set): table order
     for (unsigned base = 0; base <= mask; base += AZK_WAVE) {
-        unsigned i = base + lane;
-        uint16_t k = i <= mask ? tab[i] : (uint16_t)0;
-        unsigned long long bm = __ballot(k != 0);
-        if (k) moves[n + __popcll(bm & ((1ull << lane) - 1ull))] = (int16_t)(k - 1);
+        const unsigned i = base + lane;
+        const uint16_t kv = i <= mask ? tab[i] : (uint16_t)0;
+        const unsigned long long bm = __ballot(kv != 0);
+        if (kv) moves[n + __popcll(bm & ((1ull << lane) - 1ull))] = (int16_t)(kv - 1);
         n += __popcll(bm);
     }
     __syncthreads();
+    if (dbgv && lane == 0) { dbgv[0] += s1 - s0; dbgv[1] += s2 - s1; dbgv[2] += s3 - s2; dbgv[3] += clock64() - s3; dbgv[4] += m; }
     return n;
 }
 

@@ -8,6 +8,7 @@
 #include <hip/hip_bf16.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -29,9 +30,8 @@ struct Dev {               // device view of the engine, passed to kernels by va
     int *N;                // Node.visit
     double *W;             // Node.value (running sum)
     float *P;              // Node.prior (float32 softmax entries)
-    int16_t *cell;         // Node.prevAction as r*cols+c
+    uint32_t *meta;        // (Node.prevAction as r*cols+c) << 16 | len(Node.children); cell 0xFFFF = root
     int *first_child;      // index of children[0] in this game's arena, -1 = not expanded
-    int16_t *n_children;
     double *rootP;         // [G][rc] float64 root priors after Dirichlet mixing (utils.py:24-25), by child position
     int *root_f64;         // [G] root children use rootP (float64 UCB) instead of P (float32 UCB)
     int *arena_top;        // [G] bump allocator
@@ -44,6 +44,8 @@ struct Dev {               // device view of the engine, passed to kernels by va
     const double *noise;   // [G][A] or nullptr
     long long *counters;   // [CNT_N][G]
     int *err;              // sticky error word
+    int ablate;            // debug only (AZK_TREE_ABLATE): timing experiments that break parity on purpose
+    long long *dbg;        // debug only: [G][8] cycle stamps per phase when ablate & 16
 };
 
 struct LdsView {
@@ -60,7 +62,7 @@ struct LdsView {
 __host__ __device__ inline int up16(int x) { return (x + 15) & ~15; }
 
 __host__ __device__ inline int lds_layout(const GameDesc &g, int path_cap, int table_size, int *off) {
-    // offsets (bytes) of: board, path, moves, e, racc, cnt, cdf, bits, pref, ord, chash, tabA, tabB
+    // offsets (bytes) of: board, path, moves, e, racc, cnt, cdf, bits, pref, ord, chash, tabA, tabB, claim, rows
     int o = 0;
     off[0] = o; o += up16(g.rc);
     off[1] = o; o += up16(path_cap * 4);
@@ -77,13 +79,15 @@ __host__ __device__ inline int lds_layout(const GameDesc &g, int path_cap, int t
     off[10] = o; o += up16(g.rc * 8);
     off[11] = o; o += up16(table_size * 2);
     off[12] = o; o += up16(table_size * 2);
+    off[13] = o; o += up16(table_size * 4);
+    off[14] = o; o += 256;
     return o;
 }
 
 extern __shared__ __attribute__((aligned(16))) unsigned char azk_smem[];
 
 __device__ __forceinline__ LdsView carve(const GameDesc &g, int path_cap, int table_size) {
-    int off[13];
+    int off[15];
     lds_layout(g, path_cap, table_size, off);
     LdsView L;
     L.board = azk_smem + off[0];
@@ -99,9 +103,15 @@ __device__ __forceinline__ LdsView carve(const GameDesc &g, int path_cap, int ta
     L.ms.chash = (unsigned long long *)(azk_smem + off[10]);
     L.ms.tabA = (uint16_t *)(azk_smem + off[11]);
     L.ms.tabB = (uint16_t *)(azk_smem + off[12]);
+    L.ms.claim = (uint32_t *)(azk_smem + off[13]);
+    L.ms.rows = (uint32_t *)(azk_smem + off[14]);
     L.ms.table_size = table_size;
     return L;
 }
+
+__device__ __forceinline__ uint32_t meta_pack(int cell, int nch) { return ((uint32_t)(cell & 0xffff) << 16) | (uint32_t)nch; }
+__device__ __forceinline__ int meta_cell(uint32_t m) { return (int)(m >> 16); }
+__device__ __forceinline__ int meta_nch(uint32_t m) { return (int)(m & 0xffffu); }
 
 // Node.backup (node.py:62-74): the node at trace index i gets value * (-1)^(depth - i); lanes take one node each.
 __device__ __forceinline__ void backup_path(const Dev &d, size_t base, const int *path, int depth, double value) {
@@ -126,6 +136,8 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev d, const float *__restric
     const int A = gd.action_dim, rc = gd.rc;
     const size_t base = (size_t)g * (size_t)d.cap;
     LdsView L = carve(gd, d.path_cap, d.table_size);
+    const bool stamp = (d.ablate & 16) != 0;
+    long long t0 = stamp ? clock64() : 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
 
     if (EXPAND) {
         const int node = uniform_i32(d.leaf_node[g]);
@@ -135,7 +147,7 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev d, const float *__restric
             const int nv = uniform_i32(d.leaf_nmoves[g]);
             const float *lg = logits + (size_t)slot * A;
             // float32 softmax, no max subtraction (mcts.py:48-49)
-            for (int i = lane; i < A; i += AZK_WAVE) L.e[i] = azk_exp_det(lg[i]);
+            for (int i = lane; i < A; i += AZK_WAVE) L.e[i] = (d.ablate & 1) ? 1.0f : azk_exp_det(lg[i]);
             __syncthreads();
             const float s = azk_pairwise_sum(L.e, A, L.racc);
             const int fc = uniform_i32(d.arena_top[g]);
@@ -147,12 +159,13 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev d, const float *__restric
                     const int a = azk_action_idx(gd, cell);
                     const float p = L.e[a] / s;
                     const size_t idx = base + fc + i;
-                    d.N[idx] = 0; d.W[idx] = 0.0; d.P[idx] = p; d.cell[idx] = (int16_t)cell;
-                    d.first_child[idx] = -1; d.n_children[idx] = 0;
+                    d.N[idx] = 0; d.W[idx] = 0.0; d.P[idx] = p; d.meta[idx] = meta_pack(cell, 0);
+                    d.first_child[idx] = -1;
                     if (mix) d.rootP[(size_t)g * rc + i] = (double)(0.75f * p) + 0.25 * d.noise[(size_t)g * A + a];  // utils.py:24-25
                 }
                 if (lane == 0) {
-                    d.first_child[base + node] = fc; d.n_children[base + node] = (int16_t)nv;
+                    d.first_child[base + node] = fc;
+                    d.meta[base + node] = (d.meta[base + node] & 0xffff0000u) | (uint32_t)nv;
                     d.arena_top[g] = fc + nv;
                     if (depth == 0) d.root_f64[g] = mix ? 1 : 0;
                     d.counters[(size_t)CNT_CREATED * d.G + g] += nv;
@@ -176,51 +189,77 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev d, const float *__restric
             if (lane == 0) d.leaf_flag[g] = 0;
             return;
         }
+        if (stamp) t1 = clock64();
         for (int i = lane; i < rc; i += AZK_WAVE) L.board[i] = d.cells[(size_t)g * d.rc_pad + i];
         const int root_player = uniform_i32(d.to_move[g]);
         const int root_mc = uniform_i32(d.move_count[g]);
         if (lane == 0) L.path[0] = 0;
         __syncthreads();
         int node = 0, depth = 0, scanned = 0;
+        // header of the current node, carried in registers: one dependent round trip per level (the child scan itself
+        // brings every candidate's header along, and the winner's is taken from the winning lane)
+        int fc = uniform_i32(d.first_child[base]);
+        int Np = uniform_i32(d.N[base]);
+        uint32_t nmeta = (uint32_t)uniform_i32((int)d.meta[base]);
+        int node_cell = -1;
+        const bool root_f64 = uniform_i32(d.root_f64[g]) != 0;
         for (;;) {                                                    // mcts.py:20-23
-            const int nch = uniform_i32((int)d.n_children[base + node]);
-            if (nch <= 0) break;
-            const int fc = uniform_i32(d.first_child[base + node]);
-            const int Np = uniform_i32(d.N[base + node]);
-            const bool f64 = node == 0 && uniform_i32(d.root_f64[g]) != 0;
-            int best = 0x7fffffff;
-            if (f64) {                                                // float64 priors => float64 UCB
-                const double s = sqrt((double)Np);
-                double bu = 0.0;
-                for (int i = lane; i < nch; i += AZK_WAVE) {
-                    const int Nc = d.N[base + fc + i];
-                    const double Wc = d.W[base + fc + i];
-                    const double Pc = d.rootP[(size_t)g * rc + i];
-                    double u = Pc * s / (double)(Nc + 1);
-                    if (Nc != 0) u = Wc / (double)Nc + u;
-                    if (best == 0x7fffffff || u > bu) { bu = u; best = i; }
+            const int nch = meta_nch(nmeta);
+            if (nch <= 0 || (d.ablate & 2)) break;
+            const bool f64 = node == 0 && root_f64;
+            double bu64 = 0.0;
+            float bu32 = 0.f;
+            int best = 0x7fffffff, bN = 0, bfc = -1;
+            uint32_t bmeta = 0;
+            // all of this level's loads are issued before any arithmetic: 4 candidates per lane per 256-child chunk
+            for (int c0 = 0; c0 < nch; c0 += 4 * AZK_WAVE) {
+                int Nc[4], fcc[4];
+                double Wc[4], P64[4];
+                float P32[4];
+                uint32_t mc[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int i = c0 + lane + AZK_WAVE * k;
+                    const size_t ci = base + fc + (i < nch ? i : 0);
+                    Nc[k] = d.N[ci]; Wc[k] = d.W[ci]; mc[k] = d.meta[ci]; fcc[k] = d.first_child[ci];
+                    if (f64) P64[k] = d.rootP[(size_t)g * rc + (i < nch ? i : 0)];
+                    else P32[k] = d.P[ci];
                 }
-                wave_argmax_first<double>(bu, best);
-            } else {                                                  // float32 priors => float32 UCB (numpy>=2)
-                const float s = (float)sqrt((double)Np);
-                float bu = 0.f;
-                for (int i = lane; i < nch; i += AZK_WAVE) {
-                    const int Nc = d.N[base + fc + i];
-                    const double Wc = d.W[base + fc + i];
-                    const float Pc = d.P[base + fc + i];
-                    float u = (Pc * s) / (float)(Nc + 1);
-                    if (Nc != 0) u = (float)(Wc / (double)Nc) + u;
-                    if (best == 0x7fffffff || u > bu) { bu = u; best = i; }
+                if (f64) {                                            // float64 priors => float64 UCB
+                    const double s = sqrt((double)Np);
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const int i = c0 + lane + AZK_WAVE * k;
+                        if (i >= nch) continue;
+                        double u = P64[k] * s / (double)(Nc[k] + 1);
+                        if (Nc[k] != 0) u = Wc[k] / (double)Nc[k] + u;
+                        if (best == 0x7fffffff || u > bu64) { bu64 = u; best = i; bN = Nc[k]; bmeta = mc[k]; bfc = fcc[k]; }
+                    }
+                } else {                                              // float32 priors => float32 UCB (numpy>=2)
+                    const float s = (float)sqrt((double)Np);
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const int i = c0 + lane + AZK_WAVE * k;
+                        if (i >= nch) continue;
+                        float u = (P32[k] * s) / (float)(Nc[k] + 1);
+                        if (Nc[k] != 0) u = (float)(Wc[k] / (double)Nc[k]) + u;
+                        if (best == 0x7fffffff || u > bu32) { bu32 = u; best = i; bN = Nc[k]; bmeta = mc[k]; bfc = fcc[k]; }
+                    }
                 }
-                wave_argmax_first<float>(bu, best);
             }
+            if (f64) wave_argmax_first<double>(bu64, best);
+            else wave_argmax_first<float>(bu32, best);
             best = uniform_i32(best);
+            const int wl = best & 63;                                 // the lane whose own best candidate won
             scanned += nch;
             const int child = fc + best;
-            const int cellc = uniform_i32((int)d.cell[base + child]);
+            Np = __shfl(bN, wl); nmeta = (uint32_t)__shfl((int)bmeta, wl); fc = __shfl(bfc, wl);
+            Np = uniform_i32(Np); nmeta = (uint32_t)uniform_i32((int)nmeta); fc = uniform_i32(fc);
+            const int cellc = meta_cell(nmeta);
             const int mover = (root_player + depth) & 1;
             depth++;
             node = child;
+            node_cell = cellc;
             if (lane == 0) {
                 L.path[depth] = node;
                 // make_move (gomoku.py:51-58 / tictactoe.py:37-45 test emptiness; connect4.py:56-63 does not)
@@ -230,12 +269,12 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev d, const float *__restric
             if (depth + 1 >= d.path_cap) break;
         }
         __syncthreads();
+        if (stamp) t2 = clock64();
         const int node_player = (root_player + depth) & 1;
         const int node_mc = root_mc + depth;
         int term = -1;
         if (depth > 0) {                                              // mcts.py:25-32 (root is never tested)
-            const int cellc = uniform_i32((int)d.cell[base + node]);
-            const int w = azk_check_winner(L.board, gd, 1 - node_player, cellc);
+            const int w = azk_check_winner(L.board, gd, 1 - node_player, node_cell);
             if (w != -1) term = 1;
             else if (node_mc == gd.state_dim) term = 0;
         }
@@ -252,7 +291,11 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev d, const float *__restric
             }
             return;
         }
-        const int nv = azk_valid_moves(L.board, gd, L.moves, L.ms);  // mcts.py:34
+        if (stamp) t3 = clock64();
+        int nv;
+        if (d.ablate & 4) { nv = 1; if (lane == 0) L.moves[0] = (int16_t)(gd.rc / 2); __syncthreads(); }
+        else nv = azk_valid_moves(L.board, gd, L.moves, L.ms, (d.ablate & 8) != 0, (d.ablate & 32) ? d.dbg + (size_t)g * 8 : nullptr);  // mcts.py:34
+        if (stamp) t4 = clock64();
         for (int i = lane; i < nv; i += AZK_WAVE) d.leaf_moves[(size_t)g * rc + i] = L.moves[i];
         for (int i = lane; i < rc; i += AZK_WAVE) d.leaf_cells[(size_t)g * d.rc_pad + i] = L.board[i];
         for (int i = lane; i <= depth; i += AZK_WAVE) d.path[(size_t)g * d.path_cap + i] = L.path[i];
@@ -260,6 +303,10 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev d, const float *__restric
             d.leaf_node[g] = node; d.leaf_depth[g] = depth; d.leaf_nmoves[g] = nv;
             d.leaf_flag[g] = 1;
             d.counters[(size_t)CNT_LEAVES * d.G + g] += 1;
+            if (stamp) {
+                long long *q = d.dbg + (size_t)g * 8;
+                q[0] += t1 - t0; q[1] += t2 - t1; q[2] += t3 - t2; q[3] += t4 - t3; q[4] += clock64() - t4; q[5] += depth; q[6] += 1;
+            }
         }
     }
 }
@@ -310,8 +357,8 @@ __global__ void k_begin_search(Dev d) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= d.G) return;
     const size_t base = (size_t)g * d.cap;
-    d.N[base] = 0; d.W[base] = 0.0; d.P[base] = 0.f; d.cell[base] = -1;
-    d.first_child[base] = -1; d.n_children[base] = 0;
+    d.N[base] = 0; d.W[base] = 0.0; d.P[base] = 0.f; d.meta[base] = meta_pack(0xffff, 0);
+    d.first_child[base] = -1;
     d.arena_top[g] = 1; d.leaf_node[g] = -1; d.root_f64[g] = 0; d.leaf_flag[g] = 0;
 }
 
@@ -342,13 +389,13 @@ __global__ __launch_bounds__(AZK_WAVE) void k_root_stats(Dev d, double *pi, doub
     const size_t base = (size_t)g * d.cap;
     const int A = d.g.action_dim;
     LdsView L = carve(d.g, d.path_cap, d.table_size);
-    const int fc = d.first_child[base], nch = d.n_children[base];
+    const int fc = d.first_child[base], nch = meta_nch(d.meta[base]);
     for (int a = lane; a < A; a += AZK_WAVE) L.cnt[a] = 0;
     __syncthreads();
     int sum = 0;
     for (int i = lane; i < nch; i += AZK_WAVE) {
         const int n = d.N[base + fc + i];
-        L.cnt[azk_action_idx(d.g, d.cell[base + fc + i])] = n;
+        L.cnt[azk_action_idx(d.g, meta_cell(d.meta[base + fc + i]))] = n;
         sum += n;
     }
     sum = wave_sum_i32(sum);
@@ -376,7 +423,7 @@ __global__ __launch_bounds__(AZK_WAVE) void k_advance(Dev d, const double *unifo
         }
         return;
     }
-    const int fc = uniform_i32(d.first_child[base]), nch = uniform_i32((int)d.n_children[base]);
+    const int fc = uniform_i32(d.first_child[base]), nch = uniform_i32(meta_nch(d.meta[base]));
     const int mc = uniform_i32(d.move_count[g]), mover = uniform_i32(d.to_move[g]);
     for (int i = lane; i < rc; i += AZK_WAVE) L.board[i] = d.cells[(size_t)g * d.rc_pad + i];
     for (int a = lane; a < A; a += AZK_WAVE) L.cnt[a] = 0;
@@ -384,7 +431,7 @@ __global__ __launch_bounds__(AZK_WAVE) void k_advance(Dev d, const double *unifo
     int sum = 0;
     for (int i = lane; i < nch; i += AZK_WAVE) {
         const int n = d.N[base + fc + i];
-        L.cnt[azk_action_idx(gd, d.cell[base + fc + i])] = n;
+        L.cnt[azk_action_idx(gd, meta_cell(d.meta[base + fc + i]))] = n;
         sum += n;
     }
     sum = wave_sum_i32(sum);
@@ -409,10 +456,10 @@ __global__ __launch_bounds__(AZK_WAVE) void k_advance(Dev d, const double *unifo
         const int act = L.cnt[0];
         int found = 0x7fffffff;
         for (int i = lane; i < nch; i += AZK_WAVE)
-            if (azk_action_idx(gd, d.cell[base + fc + i]) == act && i < found) found = i;
+            if (azk_action_idx(gd, meta_cell(d.meta[base + fc + i])) == act && i < found) found = i;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) { int o = __shfl_xor(found, off); found = o < found ? o : found; }
-        cellc = found != 0x7fffffff ? (int)d.cell[base + fc + found] : -1;
+        cellc = found != 0x7fffffff ? meta_cell(d.meta[base + fc + found]) : -1;
     } else {
         // Node.max_visit_child (node.py:76-81): first child with the most visits
         int best = 0x7fffffff, bn = 0;
@@ -421,7 +468,7 @@ __global__ __launch_bounds__(AZK_WAVE) void k_advance(Dev d, const double *unifo
             if (best == 0x7fffffff || n > bn) { bn = n; best = i; }
         }
         wave_argmax_first<int>(bn, best);
-        cellc = (int)d.cell[base + fc + uniform_i32(best)];
+        cellc = meta_cell(d.meta[base + fc + uniform_i32(best)]);
     }
     cellc = uniform_i32(cellc);
     if (cellc < 0) {
@@ -679,24 +726,26 @@ int32_t azk_create(const azk_config *cfg, azk_engine **out) {
     if (cap > 0x7ffffff0LL) return fail(AZK_ERR_ARG, "arena too large");
     d.G = cfg->n_games; d.cap = (int)cap; d.path_cap = g.state_dim + 2; d.rc_pad = up16(g.rc);
     d.leaf_dtype = cfg->leaf_dtype; d.table_size = table_size_for(g);
-    int off[13];
+    { const char *ab = getenv("AZK_TREE_ABLATE"); d.ablate = ab ? atoi(ab) : 0; }
+    int off[15];
     d.lds_bytes = lds_layout(g, d.path_cap, d.table_size, off);
     const size_t G = d.G, nodes = G * (size_t)d.cap;
     hipError_t s = hipSuccess;
 #define DA(ptr, count) if (s == hipSuccess) s = dalloc(e, &ptr, (count))
     DA(d.cells, G * d.rc_pad); DA(d.to_move, G); DA(d.move_count, G); DA(d.done, G); DA(d.winner, G);
-    DA(d.N, nodes); DA(d.W, nodes); DA(d.P, nodes); DA(d.cell, nodes); DA(d.first_child, nodes); DA(d.n_children, nodes);
+    DA(d.N, nodes); DA(d.W, nodes); DA(d.P, nodes); DA(d.meta, nodes); DA(d.first_child, nodes);
     DA(d.rootP, G * g.rc); DA(d.root_f64, G); DA(d.arena_top, G);
     DA(d.leaf_node, G); DA(d.leaf_depth, G); DA(d.leaf_nmoves, G); DA(d.leaf_slot, G);
     DA(d.path, G * d.path_cap); DA(d.leaf_cells, G * d.rc_pad); DA(d.leaf_moves, G * g.rc);
     DA(d.leaf_flag, ((G + 511) / 512) * 512 + 512);
-    DA(d.counters, (size_t)CNT_N * G); DA(d.err, 1); DA(e->counter_sums, CNT_N); DA(e->n_leaf_scratch, 1);
+    DA(d.counters, (size_t)CNT_N * G); DA(d.err, 1); DA(d.dbg, G * 8); DA(e->counter_sums, CNT_N); DA(e->n_leaf_scratch, 1);
     if (s == hipSuccess) { uint8_t *ls = nullptr; s = dalloc(e, &ls, G * g.planes * g.rc * 4); e->leaf_scratch = ls; }
 #undef DA
     if (s != hipSuccess) return fail(AZK_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(s));
     (void)hipMemset(d.leaf_flag, 0, ((G + 511) / 512) * 512 + 512);
     (void)hipMemset(d.counters, 0, sizeof(long long) * CNT_N * G);
     (void)hipMemset(d.err, 0, sizeof(int));
+    (void)hipMemset(d.dbg, 0, sizeof(long long) * G * 8);
     (void)hipMemset(d.leaf_node, 0xff, sizeof(int) * G);
     k_reset_games<<<(unsigned)((G * d.rc_pad + 255) / 256), 256>>>(d, 0, d.G);
     k_begin_search<<<(unsigned)((G + 255) / 256), 256>>>(d);
@@ -841,7 +890,8 @@ struct HostTree {
     std::vector<int> N, first_child;
     std::vector<double> W, rootP;
     std::vector<float> P;
-    std::vector<int16_t> cell, nch;
+    std::vector<uint32_t> meta;
+    std::vector<int> cell, nch;
     int top = 0, root_f64 = 0;
 };
 
@@ -852,16 +902,20 @@ static int32_t fetch_tree(azk_engine *e, int game, HostTree *t, hipStream_t st) 
     HIPCHK(e, hipMemcpyAsync(&t->root_f64, d.root_f64 + game, sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHK(e, hipStreamSynchronize(st));
     const size_t n = (size_t)t->top, base = (size_t)game * d.cap;
-    t->N.resize(n); t->first_child.resize(n); t->W.resize(n); t->P.resize(n); t->cell.resize(n); t->nch.resize(n);
+    t->N.resize(n); t->first_child.resize(n); t->W.resize(n); t->P.resize(n); t->cell.resize(n); t->nch.resize(n); t->meta.resize(n);
     t->rootP.resize(d.g.rc);
     HIPCHK(e, hipMemcpyAsync(t->N.data(), d.N + base, n * sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHK(e, hipMemcpyAsync(t->first_child.data(), d.first_child + base, n * sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHK(e, hipMemcpyAsync(t->W.data(), d.W + base, n * sizeof(double), hipMemcpyDeviceToHost, st));
     HIPCHK(e, hipMemcpyAsync(t->P.data(), d.P + base, n * sizeof(float), hipMemcpyDeviceToHost, st));
-    HIPCHK(e, hipMemcpyAsync(t->cell.data(), d.cell + base, n * sizeof(int16_t), hipMemcpyDeviceToHost, st));
-    HIPCHK(e, hipMemcpyAsync(t->nch.data(), d.n_children + base, n * sizeof(int16_t), hipMemcpyDeviceToHost, st));
+    HIPCHK(e, hipMemcpyAsync(t->meta.data(), d.meta + base, n * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     HIPCHK(e, hipMemcpyAsync(t->rootP.data(), d.rootP + (size_t)game * d.g.rc, d.g.rc * sizeof(double), hipMemcpyDeviceToHost, st));
     HIPCHK(e, hipStreamSynchronize(st));
+    for (size_t i = 0; i < n; i++) {
+        const int c = (int)(t->meta[i] >> 16);
+        t->cell[i] = c == 0xffff ? -1 : c;
+        t->nch[i] = (int)(t->meta[i] & 0xffffu);
+    }
     return AZK_OK;
 }
 
@@ -939,6 +993,14 @@ int32_t azk_get_counters(azk_engine *e, azk_counters *out, void *stream) {
     return AZK_OK;
 }
 
+int32_t azk_debug_stamps(azk_engine *e, int64_t *out8_host) {
+    if (!e || !out8_host) return AZK_ERR_ARG;
+    std::vector<long long> h((size_t)e->d.G * 8);
+    if (hipMemcpy(h.data(), e->d.dbg, h.size() * sizeof(long long), hipMemcpyDeviceToHost) != hipSuccess) return AZK_ERR_HIP;
+    for (int k = 0; k < 8; k++) { long long s = 0; for (int g = 0; g < e->d.G; g++) s += h[(size_t)g * 8 + k]; out8_host[k] = s; }
+    return AZK_OK;
+}
+
 int32_t azk_reset_counters(azk_engine *e, void *stream) {
     if (!e) return AZK_ERR_ARG;
     HIPCHK(e, hipMemsetAsync(e->d.counters, 0, sizeof(long long) * CNT_N * e->d.G, (hipStream_t)stream));
@@ -977,7 +1039,7 @@ static int32_t run_rules(int mode, int32_t game, int32_t rows, int32_t cols, con
     a.mode = mode; a.n = n; a.table_size = table_size_for(a.g);
     a.boards_in = in; a.boards = inout; a.players = players; a.cells = cells;
     a.moves = moves; a.counts = counts; a.mask = mask; a.out_i = out_i; a.out_f = out_f;
-    int off[13];
+    int off[15];
     const int lds = lds_layout(a.g, 4, a.table_size, off);
     k_rules<<<n, AZK_WAVE, lds, (hipStream_t)stream>>>(a);
     hipError_t s = hipGetLastError();

@@ -151,6 +151,9 @@ int32_t azk_get_positions(azk_engine *e, int8_t *cells_host, int32_t *to_move_ho
 
 int32_t azk_get_counters(azk_engine *e, azk_counters *out, void *stream);   /* synchronises */
 int32_t azk_reset_counters(azk_engine *e, void *stream);
+/* debug only: per-phase shader-clock sums of k_tree (collected when AZK_TREE_ABLATE has bit 16): expand, board+root
+ * load, walk, terminal test, valid moves, writes (cycles), then summed depth and sample count.  Synchronises. */
+int32_t azk_debug_stamps(azk_engine *e, int64_t *out8_host);
 /* sticky device-side error word (arena overflow etc.); synchronises; returns AZK_OK or the error */
 int32_t azk_check_device_error(azk_engine *e, void *stream);
 
