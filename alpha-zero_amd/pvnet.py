@@ -114,6 +114,7 @@ class PolicyValueNet:
                 raise ValueError(f"{k_}: shape {tuple(w[k_].shape)} != {shp}")
         self.master = {k_: torch.as_tensor(v).detach().to(torch.float32).cpu().clone() for k_, v in w.items()}
         self.path = path
+        self.fast_outputs = False   # True: logits may come back as a bf16 view (the caller converts while copying)
         self.live_count = None      # optional int32 CUDA tensor: number of valid rows at the head of the batch (graph stepping)
         self.to(device, dtype)
 
@@ -170,7 +171,37 @@ class PolicyValueNet:
             Wv = Wi[2 * D:].reshape(H, dh, D).to(dev)
             f["WvT_n"] = (Wv * g).transpose(1, 2).contiguous().to(torch.bfloat16)                      # [H, D, dh]
             f["bv_n"] = (bi[2 * D:].to(dev) + (Wv @ bta).reshape(-1)).to(torch.bfloat16)
+            # cls-row tail as few GEMMs: value projection and output projection composed per head
+            #   x1 = x0 + bo + sum_h Wo[:, h] (Wv'_h zn_h + bv'_h) = zn_flat @ Wcomb + bias1        (x0 = cls + pos[0], constant)
+            Wo, bo = m[b + "attn.out_proj.weight"].to(dev), m[b + "attn.out_proj.bias"].to(dev)
+            Wvn = (Wv * g)                                                                              # [H, dh, D]
+            Wcomb = torch.einsum("ohe,hed->hdo", Wo.view(D, H, dh), Wvn).reshape(H * D, D)              # [H*D, D]
+            bvn = bi[2 * D:].to(dev) + (Wv @ bta).reshape(-1)
+            f["Wcomb"] = Wcomb.to(torch.bfloat16).contiguous()
+            f["bias1"] = (x0 + bo + Wo @ bvn).to(torch.bfloat16)
+            # policy and value heads as one GEMM ([A+1] outputs, padded to a multiple of 8 columns)
+            A = cfg.action_dim
+            Ap = (A + 1 + 7) // 8 * 8
+            Wh = torch.zeros(Ap, D, device=dev)
+            bh = torch.zeros(Ap, device=dev)
+            Wh[:A], bh[:A] = m["policy_head.weight"].to(dev), m["policy_head.bias"].to(dev)
+            Wh[A], bh[A] = m["value_head.weight"].to(dev)[0], m["value_head.bias"].to(dev)[0]
+            f["Wh"], f["bh"] = Wh.to(torch.bfloat16), bh.to(torch.bfloat16)
         self._fold = f
+
+    def tail_fast(self, z):
+        """depth-1 cls row after the pooled tokens zn [n, H, D]: composed projection, MLP, final norm, merged heads."""
+        w, cfg, f = self.w, self.cfg, self._fold
+        n, A = z.shape[0], cfg.action_dim
+        x1 = torch.addmm(f["bias1"], z.view(n, -1), f["Wcomb"])                                        # nn.py:54-56
+        h = self._ln(x1, "blocks.0.norm2")
+        h = F.gelu(F.linear(h, w["blocks.0.mlp.0.weight"], w["blocks.0.mlp.0.bias"]))
+        x2 = torch.addmm(x1, h, w["blocks.0.mlp.3.weight"].t()) + w["blocks.0.mlp.3.bias"]            # nn.py:59-60
+        out = F.linear(self._ln(x2, "norm"), f["Wh"], f["bh"])                                          # nn.py:78-83
+        logits = out[:, :A]
+        # callers that copy into their own float32 buffers (the step graph) take the bf16 view and save a conversion kernel
+        return (logits if self.fast_outputs else logits.float()), torch.tanh(out[:, A:A + 1].float())
+
 
     def _prepare_hip_embed(self):
         """Operands of azk_nn_patch_embed: conv weight [D, kp] bf16 (k padded to a multiple of 16) and the
@@ -306,7 +337,7 @@ class PolicyValueNet:
                     z = azk.nn_embed_scores_pool(x.contiguous(), hp["wt"], hp["cpos"], hp["ln_w"], hp["ln_b"], f["m_n"], f["c_n"],
                                                  self.cfg.rows, self.cfg.cols, self.cfg.patch_size, self.cfg.embed_dim,
                                                  self.cfg.num_heads, count=self.live_count)
-                    return self.heads(self.block_cls_folded(None, x0, last, z=z, normalised=True))
+                    return self.tail_fast(z)
                 _, xhat = self.embed_hip(x, want_x=False, want_xhat=True)
             else:
                 t = self.embed(x)

@@ -190,6 +190,7 @@ class SelfPlayRunner:
         e.step(self.logits_buf, self.values_buf)
         if hasattr(self.evaluator, "live_count"):
             self.evaluator.live_count = e.n_leaf          # kernels that honour it skip the rows past the live leaves
+            self.evaluator.fast_outputs = True
         logits, values = self.evaluator(e.leaf_boards)
         self.logits_buf.copy_(logits)
         self.values_buf.copy_(values.reshape(-1))
