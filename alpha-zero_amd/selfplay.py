@@ -94,30 +94,13 @@ def self_play_batch(game, evaluator, n_games, n_sims, size=None, seed=0, first_g
     return results
 
 
-class SelfPlayRunner:
-    """Continuous self-play: G slots advance one move per `play_move()`; a slot whose game ends restarts
-    from an empty board in the same call (azk_recycle_finished), so every move does G searches.
-    Per move the records the reference's self_play keeps (raw board, pi, q, action; gomoku.py:138-146)
-    are copied to pinned host buffers; `on_records` (optional) receives them.
+class _Half:
+    """State of one independently stepped group of games (an engine + its static step buffers + pinned records)."""
 
-    RNG key = (seed, first_global_game + slot, move counter): results do not depend on the sharding.
-    """
-
-    def __init__(self, game, evaluator, n_games, n_sims, size=None, seed=0, first_global_game=0, dirichlet=True,
-                 alpha=0.03, device=0, leaf_dtype="float32", recycle=True, on_records=None, kernel_timer=None,
-                 use_graph=False):
-        import torch
-        self.torch = torch
-        self.use_graph = use_graph
-        self._graph = None
-        self.eng = Engine(game, n_games, n_sims, size=size, device=device, leaf_dtype=leaf_dtype)
-        self.evaluator, self.n_sims, self.seed, self.first = evaluator, n_sims, seed, first_global_game
-        self.dirichlet, self.alpha, self.recycle, self.on_records = dirichlet, alpha, recycle, on_records
-        self.sample_until = SAMPLE_UNTIL[game]
-        self.kernel_timer = kernel_timer
-        e = self.eng
+    def __init__(self, torch, eng, dirichlet):
+        self.eng = eng
+        e = eng
         self.stats = torch.zeros(8, dtype=torch.int64, device=e.device)
-        self.cells_dev = torch.zeros((e.G, e.rows * e.cols), dtype=torch.int8, device=e.device)
         pin = dict(pin_memory=True)
         self.h_pi = torch.zeros((e.G, e.action_dim), dtype=torch.float64, **pin)
         self.h_q = torch.zeros(e.G, dtype=torch.float64, **pin)
@@ -125,42 +108,83 @@ class SelfPlayRunner:
         self.h_winner = torch.zeros(e.G, dtype=torch.int32, **pin)
         self.h_done = torch.zeros(e.G, dtype=torch.int32, **pin)
         self.h_stats = torch.zeros(8, dtype=torch.int64, **pin)
-        self.move_idx = 0
-        self.plies_played = 0
         # static buffers so a captured step graph always sees the same addresses
         self.noise_buf = torch.zeros((e.G, e.action_dim), dtype=torch.float64, device=e.device) if dirichlet else None
         self.logits_buf = torch.zeros((e.G, e.action_dim), dtype=torch.float32, device=e.device)
         self.values_buf = torch.zeros(e.G, dtype=torch.float32, device=e.device)
-        e.reset_games()
+        self.uni = None
 
+
+class SelfPlayRunner:
+    """Continuous self-play: G slots advance one move per `play_move()`; a slot whose game ends restarts
+    from an empty board in the same call (azk_recycle_finished), so every move does G searches.
+    Per move the records the reference's self_play keeps (pi, q, action, winner; gomoku.py:138-146)
+    are copied to pinned host buffers; `on_records` (optional) receives them.
+
+    `n_split` groups of G/n_split games are stepped on separate HIP streams inside ONE captured graph: the
+    latency-bound kernels of one group (tree walk, the cls-row tail) run under the bandwidth/VALU-bound kernels
+    of the other.  Groups are independent games, so this changes no result.
+
+    RNG key = (seed, first_global_game + slot, move counter): results do not depend on the sharding.
+    """
+
+    def __init__(self, game, evaluator, n_games, n_sims, size=None, seed=0, first_global_game=0, dirichlet=True,
+                 alpha=0.03, device=0, leaf_dtype="float32", recycle=True, on_records=None, kernel_timer=None,
+                 use_graph=False, n_split=1):
+        import torch
+        self.torch = torch
+        self.use_graph = use_graph
+        self._graph = None
+        assert n_games % n_split == 0
+        self.n_split = n_split if use_graph else 1
+        per = n_games // self.n_split
+        self.halves = [_Half(torch, Engine(game, per, n_sims, size=size, device=device, leaf_dtype=leaf_dtype), dirichlet)
+                       for _ in range(self.n_split)]
+        self.eng = self.halves[0].eng
+        self.G = n_games
+        self.evaluator, self.n_sims, self.seed, self.first = evaluator, n_sims, seed, first_global_game
+        self.dirichlet, self.alpha, self.recycle, self.on_records = dirichlet, alpha, recycle, on_records
+        self.sample_until = SAMPLE_UNTIL[game]
+        self.kernel_timer = kernel_timer
+        self.streams = [torch.cuda.Stream(device=self.eng.device) for _ in range(self.n_split)] if self.n_split > 1 else []
+        self.move_idx = 0
+        self.plies_played = 0
+        for h in self.halves:
+            h.eng.reset_games()
+
+    # ---- one move for every slot -------------------------------------------------------------------------
     def play_move(self):
-        e = self.eng
-        noise, uni = e.gen_noise(self.seed, self.first, self.move_idx, self.alpha, want_noise=self.dirichlet)
-        if self.dirichlet:
-            self.noise_buf.copy_(noise)
-            noise = self.noise_buf
+        torch = self.torch
+        per = self.halves[0].eng.G
+        for i, h in enumerate(self.halves):
+            noise, h.uni = h.eng.gen_noise(self.seed, self.first + i * per, self.move_idx, self.alpha, want_noise=self.dirichlet)
+            if self.dirichlet:
+                h.noise_buf.copy_(noise)
         if self.use_graph:
-            self.search_graph(noise)
+            self.search_graph()
         else:
-            self.search(noise)
-        pi, q, _ = e.root_stats()
-        self.h_pi.copy_(pi, non_blocking=True)
-        self.h_q.copy_(q, non_blocking=True)
-        chosen, winner, done = e.advance(uni, self.sample_until)
-        self.h_chosen.copy_(chosen, non_blocking=True)
-        self.h_winner.copy_(winner, non_blocking=True)
-        self.h_done.copy_(done, non_blocking=True)
-        if self.recycle:
-            e.recycle_finished(self.stats)
-        self.h_stats.copy_(self.stats, non_blocking=True)
-        self.torch.cuda.current_stream().synchronize()
-        self.plies_played += int((self.h_chosen >= 0).sum())
-        if self.on_records is not None:
-            self.on_records(self.move_idx, self.h_pi, self.h_q, self.h_chosen, self.h_winner, self.h_done)
+            self.search(self.halves[0].noise_buf)
+        for h in self.halves:
+            e = h.eng
+            pi, q, _ = e.root_stats()
+            h.h_pi.copy_(pi, non_blocking=True)
+            h.h_q.copy_(q, non_blocking=True)
+            chosen, winner, done = e.advance(h.uni, self.sample_until)
+            h.h_chosen.copy_(chosen, non_blocking=True)
+            h.h_winner.copy_(winner, non_blocking=True)
+            h.h_done.copy_(done, non_blocking=True)
+            if self.recycle:
+                e.recycle_finished(h.stats)
+            h.h_stats.copy_(h.stats, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        for i, h in enumerate(self.halves):
+            self.plies_played += int((h.h_chosen >= 0).sum())
+            if self.on_records is not None:
+                self.on_records(self.move_idx, i * per, h.h_pi, h.h_q, h.h_chosen, h.h_winner, h.h_done)
         self.move_idx += 1
 
     def search(self, noise):
-        """Engine.search with optional per-kernel event timing of k_tree (sampled steps)."""
+        """Eager stepping (host sync per simulation, n_leaf-sized evaluator batches); optional k_tree event timing."""
         e, torch, kt = self.eng, self.torch, self.kernel_timer
         e.begin_search(noise)
         logits = values = None
@@ -182,61 +206,106 @@ class SelfPlayRunner:
         if logits is not None:
             e.step_expand_backup(logits, values)
 
-    def _step_body(self):
-        """One simulation for every game, with no host round trip: expand+backup of the previous leaves, PUCT select,
-        leaf compaction, then the evaluator over the whole (fixed-size) leaf buffer.  Rows past n_leaf hold older
-        boards; their outputs are never read (slot indices stop at n_leaf)."""
-        e = self.eng
-        e.step(self.logits_buf, self.values_buf)
+    def _step_body(self, h, timer=None):
+        """One simulation for every game of one group, with no host round trip: expand+backup of the previous leaves,
+        PUCT select, leaf compaction, then the evaluator over the (fixed-size) leaf buffer.  Rows past n_leaf hold
+        older boards; kernels that honour `live_count` skip them and nothing ever reads their outputs."""
+        e = h.eng
+        if timer is not None:
+            timer.start()
+            e.step_tree(h.logits_buf, h.values_buf)
+            timer.stop()
+            e.step_gather()
+        else:
+            e.step(h.logits_buf, h.values_buf)
         if hasattr(self.evaluator, "live_count"):
-            self.evaluator.live_count = e.n_leaf          # kernels that honour it skip the rows past the live leaves
+            self.evaluator.live_count = e.n_leaf
             self.evaluator.fast_outputs = True
         logits, values = self.evaluator(e.leaf_boards)
-        self.logits_buf.copy_(logits)
-        self.values_buf.copy_(values.reshape(-1))
+        h.logits_buf.copy_(logits)
+        h.values_buf.copy_(values.reshape(-1))
 
-    def search_graph(self, noise):
-        """n_sims replays of one captured hipGraph (k_tree -> k_gather -> evaluator kernels)."""
-        e, torch = self.eng, self.torch
-        e.begin_search(noise)
+    def _all_bodies(self):
+        torch = self.torch
+        if self.n_split == 1:
+            self._step_body(self.halves[0])
+            return
+        cur = torch.cuda.current_stream()
+        for st in self.streams:
+            st.wait_stream(cur)
+        for h, st in zip(self.halves, self.streams):
+            with torch.cuda.stream(st):
+                self._step_body(h)
+        for st in self.streams:
+            cur.wait_stream(st)
+
+    def search_graph(self):
+        """n_sims replays of captured hipGraphs (per group: k_tree -> k_gather -> evaluator kernels).  Each group has its
+        own graph, replayed on its own stream, so the groups' kernels can overlap on the GPU."""
+        torch = self.torch
+        for h in self.halves:
+            h.eng.begin_search(h.noise_buf)
+        cur = torch.cuda.current_stream()
         if self._graph is None:
             # the first simulations run eagerly on a side stream (allocator warm-up), the capture records one more
             side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
+            side.wait_stream(cur)
             with torch.cuda.stream(side):
                 for _ in range(3):
-                    self._step_body()
-            torch.cuda.current_stream().wait_stream(side)
+                    for h in self.halves:
+                        self._step_body(h)
+            cur.wait_stream(side)
             torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self._step_body()
-            self._graph = g
+            self._graph = []
+            for h in self.halves:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._step_body(h)
+                self._graph.append(g)
             done = 4
         else:
             done = 0
         kt = self.kernel_timer
+        streams = self.streams if self.n_split > 1 else [cur]
+        for st in self.streams:
+            st.wait_stream(cur)
         for s in range(done, self.n_sims):
-            if kt is not None and kt.want(s):
-                # sampled steps run the same kernels eagerly so HIP events can bracket k_tree on its stream
-                kt.start()
-                e.step_tree(self.logits_buf, self.values_buf)
-                kt.stop()
-                e.step_gather()
-                logits, values = self.evaluator(e.leaf_boards)
-                self.logits_buf.copy_(logits)
-                self.values_buf.copy_(values.reshape(-1))
-            else:
-                self._graph.replay()
-        e.step_expand_backup(self.logits_buf, self.values_buf)
+            timed = kt is not None and kt.want(s)
+            for h, g, st in zip(self.halves, self._graph, streams):
+                with torch.cuda.stream(st):
+                    if timed:
+                        # sampled steps run the same kernels eagerly so HIP events can bracket k_tree on its stream
+                        self._step_body(h, timer=kt)
+                    else:
+                        g.replay()
+        for h, st in zip(self.halves, streams):
+            with torch.cuda.stream(st):
+                h.eng.step_expand_backup(h.logits_buf, h.values_buf)
+        for st in self.streams:
+            cur.wait_stream(st)
 
     @property
     def games_finished(self):
-        return int(self.h_stats[0])
+        return sum(int(h.h_stats[0]) for h in self.halves)
 
     @property
     def finished_plies(self):
-        return int(self.h_stats[1])
+        return sum(int(h.h_stats[1]) for h in self.halves)
+
+    def counters(self):
+        tot = {}
+        for h in self.halves:
+            for k, v in h.eng.counters().items():
+                tot[k] = tot.get(k, 0) + v
+        return tot
+
+    def reset_counters(self):
+        for h in self.halves:
+            h.eng.reset_counters()
+
+    def check_error(self):
+        for h in self.halves:
+            h.eng.check_error()
 
 
 class KernelTimer:

@@ -86,6 +86,7 @@ def main():
     ap.add_argument("--size", type=int, default=15)
     ap.add_argument("--nn-path", default="clsfold", choices=["clsfold", "cls", "full"])
     ap.add_argument("--no-graph", action="store_true", help="eager stepping with a host sync per simulation (n_leaf-sized batches)")
+    ap.add_argument("--split", type=int, default=1, help="independent game groups stepped on separate streams inside the step graph")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="wall-clock budget of the CPU baseline leg (0 = skip)")
     ap.add_argument("--seed", type=int, default=0)
     args = ap.parse_args()
@@ -108,7 +109,7 @@ def main():
     kt = KernelTimer(stride=16)
     runner = SelfPlayRunner("gomoku", net, args.games, args.sims, size=args.size, seed=args.seed,
                             first_global_game=shard_range(args.games, rank)[0], device=local_rank, leaf_dtype="bfloat16",
-                            recycle=True, kernel_timer=kt, use_graph=not args.no_graph)
+                            recycle=True, kernel_timer=kt, use_graph=not args.no_graph, n_split=args.split)
     eng = runner.eng
 
     def sync_all():
@@ -119,7 +120,7 @@ def main():
 
     for _ in range(args.warmup):
         runner.play_move()
-    eng.reset_counters()
+    runner.reset_counters()
     plies0, fin0, finp0 = runner.plies_played, runner.games_finished, runner.finished_plies
     kt.enabled = True
     sync_all()
@@ -129,8 +130,8 @@ def main():
     sync_all()
     dt = time.perf_counter() - t0
     kt.enabled = False
-    eng.check_error()
-    c = eng.counters()
+    runner.check_error()
+    c = runner.counters()
     plies = runner.plies_played - plies0
     fin, finp = runner.games_finished, runner.finished_plies
 
@@ -146,13 +147,20 @@ def main():
             mean_plies, src = 30.0, "no game finished in this run: assumed 30 plies"
         games_per_s = plies_all / mean_plies / dt_max
         tree_ms = kt.mean_ms()
-        launches = args.steps * args.sims
+        launches = args.steps * args.sims * runner.n_split      # k_tree launches (one per game group per simulation)
         alg_bytes = algorithmic_bytes(c, A) / launches
         roof = None
+        traffic, traffic_src = None, None
+        try:        # HBM bytes per k_tree launch from the PMC passes committed under profiles/ (FETCH_SIZE + WRITE_SIZE)
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            traffic = pmc["k_tree<true, true>"]["bytes_per_launch"]
+            traffic_src = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same workload)"
+        except Exception:
+            pass
         if tree_ms:
             gbs = alg_bytes / (tree_ms * 1e-3) / 1e9
             roof = {"kernel": "k_tree<expand,select>", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": gbs / HBM_PEAK_GBS, "traffic": None, "avg_launch_us": tree_ms * 1e3,
+                    "frac": gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "avg_launch_us": tree_ms * 1e3,
                     "algorithmic_bytes_per_launch": alg_bytes, "event_samples": len(kt.pairs)}
         from pvnet import flops_clsfold
         flops = {"cls": cfg.flops_cls(), "full": cfg.flops_full(), "clsfold": flops_clsfold(cfg)}[args.nn_path]
@@ -167,7 +175,7 @@ def main():
                        "parallelism": f"games sharded over {world} GPU(s), no collectives on the generation path"},
             "sims_per_sec": sims_all / dt_max, "leaf_evals_per_sec": leaves_all / dt_max,
             "nn_tflops_executed": evals * flops / dt_max / 1e12, "nn_flops_per_board": flops, "nn_boards_evaluated": evals,
-            "stepping": "eager+sync" if args.no_graph else "hipGraph replay (tree+gather+net per simulation, no host sync)",
+            "stepping": "eager+sync" if args.no_graph else f"hipGraph replay, {runner.n_split} game group(s) on separate streams (tree+gather+net per simulation, no host sync)",
             "mean_plies_per_game": mean_plies, "game_length_source": src, "games_finished_in_window": fin_window,
             "plies_in_window": plies_all, "counters_rank0": c, "roofline": roof,
         }
