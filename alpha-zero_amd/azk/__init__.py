@@ -25,7 +25,7 @@ SYMBOLS = [
     "azk_get_counters", "azk_reset_counters", "azk_check_device_error", "azk_gen_noise",
     "azk_rules_legal_moves", "azk_rules_legal_mask", "azk_rules_apply_move", "azk_rules_undo_move",
     "azk_rules_check_winner", "azk_rules_canonical", "azk_softmax_rows",
-    "azk_step_tree", "azk_step_gather", "azk_recycle_finished", "azk_nn_patch_embed", "azk_nn_cls_attention", "azk_nn_patch_embed_scores", "azk_nn_cls_pool", "azk_debug_stamps",
+    "azk_step_tree", "azk_step_gather", "azk_recycle_finished", "azk_nn_patch_embed", "azk_nn_cls_attention", "azk_nn_patch_embed_scores", "azk_nn_cls_pool", "azk_debug_stamps", "azk_emit_finished",
 ]
 
 
@@ -96,6 +96,7 @@ def lib():
     L.azk_get_positions.argtypes = [vp, vp, vp, vp, vp]
     L.azk_get_counters.argtypes = [vp, C.POINTER(Counters), vp]
     L.azk_reset_counters.argtypes = [vp, vp]
+    L.azk_emit_finished.argtypes = [vp, vp, vp, vp, i64, vp, vp, vp]
     L.azk_debug_stamps.argtypes = [vp, vp]
     L.azk_check_device_error.argtypes = [vp, vp]
     L.azk_gen_noise.argtypes = [vp, u64, i64, i32, f64, vp, vp, vp]
@@ -234,6 +235,13 @@ class Engine:
         """stats: int64 CUDA tensor [8] accumulating (games, plies, wins0, wins1, draws)."""
         assert stats.dtype == self.torch.int64 and stats.is_cuda and stats.numel() >= 8
         self._chk(self.L.azk_recycle_finished(self.h, _p(stats), _stream()))
+
+    def emit_finished(self, replay):
+        """Append the (state, pi, z) tuples of every just-finished game to a DeviceReplay; returns int32 [G] first indices."""
+        base = self.torch.empty(self.G, dtype=self.torch.int32, device=self.device)
+        self._chk(self.L.azk_emit_finished(self.h, _p(replay.states), _p(replay.pis), _p(replay.zs), replay.capacity,
+                                           _p(replay.cursor), _p(base), _stream()))
+        return base
 
     def step_select(self):
         self._chk(self.L.azk_step_select(self.h, _p(self.leaf_boards), _p(self.n_leaf), _stream()))
@@ -441,3 +449,26 @@ def nn_embed_scores_pool(boards, wt, cpos, ln_w, ln_b, m, c, rows, cols, ksize, 
     if rc != 0:
         raise AzkError(f"azk_nn_cls_pool failed ({rc})")
     return z
+
+
+class DeviceReplay:
+    """HBM-resident ring of (state, pi, z) tuples: the device form of replay_buffer.ReplayBuffer (deque(maxlen),
+    replay_buffer.py:7-13).  Filled by Engine.emit_finished; `sample` draws uniformly without replacement
+    (replay_buffer.py:15-25) and returns float32 CUDA tensors ready for the training step."""
+
+    def __init__(self, capacity, planes, rows, cols, action_dim, device=0):
+        torch = _torch()
+        self.torch, self.capacity = torch, int(capacity)
+        dev = torch.device("cuda", device) if isinstance(device, int) else device
+        self.states = torch.zeros((capacity, planes, rows, cols), dtype=torch.float32, device=dev)
+        self.pis = torch.zeros((capacity, action_dim), dtype=torch.float64, device=dev)
+        self.zs = torch.zeros(capacity, dtype=torch.float32, device=dev)
+        self.cursor = torch.zeros(1, dtype=torch.int64, device=dev)
+
+    def size(self):
+        return min(int(self.cursor.item()), self.capacity)
+
+    def sample(self, batch_size):
+        n = self.size()
+        idx = self.torch.randperm(n, device=self.states.device)[:batch_size]
+        return self.states[idx], self.pis[idx].float(), self.zs[idx][:, None]

@@ -42,6 +42,9 @@ struct Dev {               // device view of the engine, passed to kernels by va
     int16_t *leaf_moves;   // [G][rc] valid moves at the leaf, reference list order
     uint8_t *leaf_flag;    // [G] 1 = this game contributes a leaf to the evaluator batch this step
     const double *noise;   // [G][A] or nullptr
+    int16_t *traj_action;  // [G][state_dim] cell played at each ply of the current game (square boards only, else null)
+    double *traj_pi;       // [G][state_dim][A] visit distribution recorded at each ply
+    int *emit_base;        // [G] first tuple index of a game being emitted
     long long *counters;   // [CNT_N][G]
     int *err;              // sticky error word
     int ablate;            // debug only (AZK_TREE_ABLATE): timing experiments that break parity on purpose
@@ -450,10 +453,10 @@ __global__ __launch_bounds__(AZK_WAVE) void k_advance(Dev d, const double *unifo
             const double lastv = L.cdf[A - 1], u = uniforms[g];
             int lo = 0, hi = A;
             while (lo < hi) { int mid = (lo + hi) >> 1; if (u < L.cdf[mid] / lastv) hi = mid; else lo = mid + 1; }
-            L.cnt[0] = lo < A ? lo : A - 1;                          // action drawn
+            L.path[0] = lo < A ? lo : A - 1;                         // action drawn (path scratch: cnt[] is still needed)
         }
         __syncthreads();
-        const int act = L.cnt[0];
+        const int act = L.path[0];
         int found = 0x7fffffff;
         for (int i = lane; i < nch; i += AZK_WAVE)
             if (azk_action_idx(gd, meta_cell(d.meta[base + fc + i])) == act && i < found) found = i;
@@ -475,6 +478,11 @@ __global__ __launch_bounds__(AZK_WAVE) void k_advance(Dev d, const double *unifo
         if (lane == 0) atomicExch(d.err, AZK_ERR_STATE);
         return;
     }
+    if (d.traj_pi != nullptr && mc < gd.state_dim) {               // gomoku.py:138-146: pi and the action of this ply
+        double *tp = d.traj_pi + ((size_t)g * gd.state_dim + mc) * A;
+        for (int a = lane; a < A; a += AZK_WAVE) tp[a] = (double)L.cnt[a] / (double)sum;
+        if (lane == 0) d.traj_action[(size_t)g * gd.state_dim + mc] = (int16_t)cellc;
+    }
     if (lane == 0) {
         if (gd.kind == AZK_KIND_C4) L.board[cellc] |= (uint8_t)(1 << mover);
         else if (L.board[cellc] == 0) L.board[cellc] = (uint8_t)(1 << mover);
@@ -494,6 +502,82 @@ __global__ __launch_bounds__(AZK_WAVE) void k_advance(Dev d, const double *unifo
         if (done_out) done_out[g] = dn;
         d.counters[(size_t)CNT_MOVES * d.G + g] += 1;
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// (state, pi, z) emission: train.save_data_to_buffer (train.py:30-49) with rotate_data / flip_data (train.py:8-27).
+// Position i of a finished game (side to move = i & 1): z = +-1 by winner (0 for a draw), state = canonical board;
+// positions 0 and 1 once, the others 8 times in the order rot0, lr(rot0), tb(rot0), rot90, lr(rot90), tb(rot90),
+// rot180, rot270 (np.rot90 is counter-clockwise).  Tuple t of the stream lands in slot t % capacity (deque(maxlen)).
+// ------------------------------------------------------------------------------------------------
+__global__ void k_emit_alloc(Dev d, unsigned long long *cursor, int *game_base_out) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= d.G) return;
+    int base = -1;
+    if (d.done[g] == 1) {
+        const int n = d.move_count[g];
+        const int tuples = n <= 2 ? n : 2 + 8 * (n - 2);
+        base = (int)atomicAdd(cursor, (unsigned long long)tuples);
+    }
+    d.emit_base[g] = base;
+    if (game_base_out) game_base_out[g] = base;
+}
+
+__device__ __forceinline__ int d4_source(int t, int i, int j, int N) {
+    // source cell (row-major) of output cell (i, j) under transform t of the reference's emission order
+    int si, sj;
+    switch (t) {
+        case 0: si = i; sj = j; break;                          // rot0
+        case 1: si = i; sj = N - 1 - j; break;                  // lr(rot0)
+        case 2: si = N - 1 - i; sj = j; break;                  // tb(rot0)
+        case 3: si = j; sj = N - 1 - i; break;                  // rot90 (ccw): out[i][j] = in[j][N-1-i]
+        case 4: si = N - 1 - j; sj = N - 1 - i; break;          // lr(rot90)
+        case 5: si = j; sj = i; break;                          // tb(rot90)
+        case 6: si = N - 1 - i; sj = N - 1 - j; break;          // rot180
+        default: si = N - 1 - j; sj = i; break;                 // rot270: out[i][j] = in[N-1-j][i]
+    }
+    return si * N + sj;
+}
+
+__global__ __launch_bounds__(AZK_WAVE) void k_emit_tuples(Dev d, float *states, double *pis, float *zs, long long capacity,
+                                                            const unsigned long long *cursor) {
+    const int S = d.g.state_dim, A = d.g.action_dim, rc = d.g.rc, F = d.g.planes, N = d.g.rows;
+    const int g = blockIdx.x / S, i = blockIdx.x - g * S, lane = azk_lane();
+    const int base = d.emit_base[g];
+    if (base < 0 || i >= d.move_count[g]) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+    uint8_t *cells = sm;                                          // board before ply i
+    for (int c = lane; c < rc; c += AZK_WAVE) cells[c] = 0;
+    __syncthreads();
+    const int16_t *acts = d.traj_action + (size_t)g * S;
+    for (int j = lane; j < i; j += AZK_WAVE) cells[acts[j]] = (uint8_t)(1 << (j & 1));
+    __syncthreads();
+    const int side = i & 1, winner = d.winner[g];
+    const float z = winner == -1 ? 0.0f : (side == winner ? 1.0f : -1.0f);
+    const double *pi = d.traj_pi + ((size_t)g * S + i) * A;
+    const int ntr = i < 2 ? 1 : 8;
+    const long long first = (long long)base + (i < 2 ? i : 2 + 8 * (i - 2));
+    const long long stream_end = (long long)*cursor;              // after k_emit_alloc: one past the newest tuple of this call
+    for (int t = 0; t < ntr; t++) {
+        if (first + t < stream_end - capacity) continue;          // already pushed out of the ring by newer tuples (deque(maxlen))
+        const long long slot = (first + t) % capacity;
+        float *so = states + (size_t)slot * F * rc;
+        double *po = pis + (size_t)slot * A;
+        for (int e = lane; e < rc; e += AZK_WAVE) {
+            const int src = d4_source(t, e / N, e % N, N);
+            const uint8_t code = cells[src];
+            so[e] = (float)((code >> side) & 1);                    // canonical: own stones first (gomoku.py:34-40)
+            so[rc + e] = (float)((code >> (side ^ 1)) & 1);
+            if (F == 3) so[2 * rc + e] = (float)side;
+            po[e] = pi[src];                                        // square boards: action index == cell index
+        }
+        if (lane == 0) zs[slot] = z;
+    }
+}
+
+__global__ void k_emit_mark(Dev d) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < d.G && d.done[g] == 1 && d.emit_base[g] >= 0) d.done[g] = 2;      // emitted; recycle / later calls skip it
 }
 
 __global__ void k_sum_counters(const long long *counters, int G, long long *out) {
@@ -738,7 +822,8 @@ int32_t azk_create(const azk_config *cfg, azk_engine **out) {
     DA(d.leaf_node, G); DA(d.leaf_depth, G); DA(d.leaf_nmoves, G); DA(d.leaf_slot, G);
     DA(d.path, G * d.path_cap); DA(d.leaf_cells, G * d.rc_pad); DA(d.leaf_moves, G * g.rc);
     DA(d.leaf_flag, ((G + 511) / 512) * 512 + 512);
-    DA(d.counters, (size_t)CNT_N * G); DA(d.err, 1); DA(d.dbg, G * 8); DA(e->counter_sums, CNT_N); DA(e->n_leaf_scratch, 1);
+    DA(d.counters, (size_t)CNT_N * G); DA(d.err, 1); DA(d.dbg, G * 8); DA(d.emit_base, G);
+    if (g.rows == g.cols && g.action_dim == g.rc) { DA(d.traj_action, G * g.state_dim); DA(d.traj_pi, G * g.state_dim * g.action_dim); } DA(e->counter_sums, CNT_N); DA(e->n_leaf_scratch, 1);
     if (s == hipSuccess) { uint8_t *ls = nullptr; s = dalloc(e, &ls, G * g.planes * g.rc * 4); e->leaf_scratch = ls; }
 #undef DA
     if (s != hipSuccess) return fail(AZK_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(s));
@@ -858,6 +943,20 @@ int32_t azk_step_tree(azk_engine *e, const float *logits_dev, const float *value
 int32_t azk_step_gather(azk_engine *e, void *leaf_boards_dev, int32_t *n_leaf_dev, void *stream) {
     if (!e || !leaf_boards_dev || !n_leaf_dev) return AZK_ERR_ARG;
     k_gather<<<e->d.G, AZK_WAVE, 0, (hipStream_t)stream>>>(e->d, leaf_boards_dev, n_leaf_dev);
+    HIPCHK(e, hipGetLastError());
+    return AZK_OK;
+}
+
+int32_t azk_emit_finished(azk_engine *e, float *states_dev, double *pis_dev, float *zs_dev, int64_t capacity,
+                          int64_t *cursor_dev, int32_t *game_base_dev, void *stream) {
+    if (!e || !states_dev || !pis_dev || !zs_dev || !cursor_dev || capacity < 1) return AZK_ERR_ARG;
+    const Dev &d = e->d;
+    if (!d.traj_pi) { e->err = "azk_emit_finished: (state, pi, z) emission needs a square board with one action per cell"; return AZK_ERR_ARG; }
+    hipStream_t st = (hipStream_t)stream;
+    k_emit_alloc<<<(unsigned)((d.G + 255) / 256), 256, 0, st>>>(d, (unsigned long long *)cursor_dev, game_base_dev);
+    k_emit_tuples<<<(unsigned)(d.G * d.g.state_dim), AZK_WAVE, up16(d.g.rc), st>>>(d, states_dev, pis_dev, zs_dev, (long long)capacity,
+                                                                                  (const unsigned long long *)cursor_dev);
+    k_emit_mark<<<(unsigned)((d.G + 255) / 256), 256, 0, st>>>(d);
     HIPCHK(e, hipGetLastError());
     return AZK_OK;
 }

@@ -28,10 +28,11 @@ def cells_to_board(cells, planes, rows, cols, side_to_move):
 
 
 class SelfPlayResult:
-    __slots__ = ("boards", "actions", "pis", "qs", "winner", "cells")
+    __slots__ = ("boards", "actions", "pis", "qs", "winner", "cells", "replay_base")
 
     def __init__(self):
         self.boards, self.actions, self.pis, self.qs, self.winner, self.cells = [], [(-1, -1)], [], [], None, []
+        self.replay_base = None      # first tuple index in the DeviceReplay stream (when a replay ring is attached)
 
     def as_reference_tuple(self):
         """(boards, actions, policy_distributions, qs, winner) - gomoku.py:164"""
@@ -40,7 +41,7 @@ class SelfPlayResult:
 
 def self_play_batch(game, evaluator, n_games, n_sims, size=None, seed=0, first_global_game=0, dirichlet=True,
                     alpha=0.03, noise_fn=None, uniform_fn=None, device=0, leaf_dtype="float32", engine=None,
-                    max_moves=None, sample_until=None, stats=None):
+                    max_moves=None, sample_until=None, stats=None, replay=None):
     """Play n_games games to the end in one batch.
 
     evaluator(boards[n,F,R,C] CUDA) -> (logits [n,A], values [n] | [n,1]).
@@ -71,6 +72,7 @@ def self_play_batch(game, evaluator, n_games, n_sims, size=None, seed=0, first_g
         pi, q, _ = eng.root_stats()
         cells_before, to_move, _ = eng.get_positions()
         chosen, winner, done = eng.advance(uni, su)
+        bases = eng.emit_finished(replay).cpu().numpy() if replay is not None else None     # train.save_data_to_buffer on device
         pi_h, q_h = pi.cpu().numpy(), q.cpu().numpy()
         chosen_h, winner_h, done_h = chosen.cpu().numpy(), winner.cpu().numpy(), done.cpu().numpy()
         for g in np.nonzero(active)[0]:
@@ -84,6 +86,8 @@ def self_play_batch(game, evaluator, n_games, n_sims, size=None, seed=0, first_g
             if done_h[g]:
                 r.winner = int(winner_h[g])
                 active[g] = False
+                if bases is not None:
+                    r.replay_base = int(bases[g])
         move += 1
         if max_moves is not None and move >= max_moves:
             break
@@ -130,8 +134,9 @@ class SelfPlayRunner:
 
     def __init__(self, game, evaluator, n_games, n_sims, size=None, seed=0, first_global_game=0, dirichlet=True,
                  alpha=0.03, device=0, leaf_dtype="float32", recycle=True, on_records=None, kernel_timer=None,
-                 use_graph=False, n_split=1):
+                 use_graph=False, n_split=1, replay=None):
         import torch
+        self.replay = replay
         self.torch = torch
         self.use_graph = use_graph
         self._graph = None
@@ -173,6 +178,8 @@ class SelfPlayRunner:
             h.h_chosen.copy_(chosen, non_blocking=True)
             h.h_winner.copy_(winner, non_blocking=True)
             h.h_done.copy_(done, non_blocking=True)
+            if self.replay is not None:
+                e.emit_finished(self.replay)              # (state, pi, z) tuples with D4 augmentation, on device
             if self.recycle:
                 e.recycle_finished(h.stats)
             h.h_stats.copy_(h.stats, non_blocking=True)

@@ -120,6 +120,17 @@ int32_t azk_step_gather(azk_engine *e, void *leaf_boards_dev, int32_t *n_leaf_de
  * [0] games finished, [1] their total plies, [2] wins of player 0, [3] wins of player 1, [4] draws. */
 int32_t azk_recycle_finished(azk_engine *e, int64_t *stats_dev, void *stream);
 
+/* (state, pi, z) emission for every game that has just finished (train.save_data_to_buffer, train.py:30-49, with the D4
+ * augmentation of rotate_data / flip_data, train.py:8-27).  Call after azk_advance and before azk_recycle_finished.
+ * Position i of the game (side to move i & 1): state = canonical board float32 [F][R][C], pi float64 [A] as recorded by
+ * azk_advance, z = +1 / -1 / 0; positions 0 and 1 once, the rest 8 times in the reference's order (rot0, lr, tb, rot90,
+ * lr, tb, rot180, rot270).  The engine appends at *cursor_dev (uint64, monotonically increasing) and writes tuple t to
+ * slot t % capacity of the caller's ring buffers - the device-resident form of ReplayBuffer's deque(maxlen)
+ * (replay_buffer.py:7-13).  game_base_dev (optional, int32 [G]) receives each emitted game's first tuple index, -1 for
+ * the others.  Square boards with one action per cell only (Gomoku, TicTacToe); others return AZK_ERR_ARG. */
+int32_t azk_emit_finished(azk_engine *e, float *states_dev, double *pis_dev, float *zs_dev, int64_t capacity,
+                          int64_t *cursor_dev, int32_t *game_base_dev, void *stream);
+
 /* Root statistics after a search, for all G games (device outputs, any may be NULL):
  *   pi_dev float64 [G][A]   utils.get_probablity_distribution_of_children (utils.py:46-55)
  *   q_dev  float64 [G]      root.value / root.visit (gomoku.py:140)

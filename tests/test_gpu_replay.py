@@ -1,0 +1,60 @@
+"""(state, pi, z) emission on the GPU (azk_emit_finished): whole games replayed with the reference's recorded RNG
+draws must put into the device ring exactly the tuples train.save_data_to_buffer produced (sha256 recorded from the
+reference in tests/golden/games.npz), in the reference's order; plus ring / sampling behaviour."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_meta, load_golden
+from fixture_eval import fixture_logits_value
+
+pytestmark = pytest.mark.gpu
+
+_GZ = load_golden("games.npz")
+_META = [m for m in golden_meta(_GZ) if "buffer_digest" in m]
+
+
+@pytest.mark.parametrize("m", _META, ids=[f"g{m['game']}-gomoku{m['size']}-n{m['n_sims']}-{m['variant']}" for m in _META])
+def test_emitted_tuples_match_reference_buffer(m):
+    import azk
+    from oracle import replay_oracle as ro
+    from selfplay import self_play_batch
+    k = f"g{m['game']}_"
+    noise, uniforms = _GZ[k + "noise"], _GZ[k + "uniforms"]
+    size, A, G = m["size"], m["size"] ** 2, 3
+    replay = azk.DeviceReplay(3 * m["buffer_len"] + 16, 2, size, size, A)
+    res = self_play_batch("gomoku", lambda x: fixture_logits_value(x, A, m["variant"]), G, m["n_sims"], size=size,
+                          noise_fn=lambda mv: np.tile(noise[min(mv, len(noise) - 1)], (G, 1)),
+                          uniform_fn=lambda mv: np.full(G, uniforms[mv] if mv < len(uniforms) else 0.5), replay=replay)
+    assert replay.size() == G * m["buffer_len"]
+    states, pis, zs = replay.states.cpu().numpy(), replay.pis.cpu().numpy(), replay.zs.cpu().numpy()
+    bases = sorted(r.replay_base for r in res)
+    assert bases == [0, m["buffer_len"], 2 * m["buffer_len"]]
+    for r in res:
+        b = r.replay_base
+        tuples = [(states[b + t], pis[b + t], float(zs[b + t])) for t in range(m["buffer_len"])]
+        assert ro.digest(tuples) == m["buffer_digest"]                      # == the reference's ReplayBuffer contents
+        want = ro.emit_tuples(r.boards, r.pis, r.winner)                    # and the oracle on the engine's own game record
+        assert ro.digest(want) == m["buffer_digest"]
+
+
+def test_ring_overwrites_oldest_and_sampling():
+    import azk
+    from selfplay import self_play_batch
+    A = 49
+    replay = azk.DeviceReplay(100, 2, 7, 7, A)                               # smaller than one batch's output
+    res = self_play_batch("gomoku", lambda x: fixture_logits_value(x, A, "hash"), 8, 32, size=7, seed=1, replay=replay)
+    total = sum((len(r.cells) if len(r.cells) <= 2 else 2 + 8 * (len(r.cells) - 2)) for r in res)
+    assert int(replay.cursor.item()) == total and replay.size() == 100       # deque(maxlen) semantics (replay_buffer.py:10)
+    s, p, z = replay.sample(64)
+    assert s.shape == (64, 2, 7, 7) and p.shape == (64, A) and z.shape == (64, 1) and p.dtype == torch.float32
+    assert torch.all((s == 0) | (s == 1)) and torch.allclose(p.sum(1), torch.ones(64, device=p.device), atol=1e-5)
+    assert set(np.unique(z.cpu().numpy()).tolist()) <= {-1.0, 0.0, 1.0}
+
+
+def test_rectangular_board_is_rejected():
+    import azk
+    eng = azk.Engine("connect4", 2, 8)
+    replay = azk.DeviceReplay(16, 3, 6, 7, 7)
+    with pytest.raises(azk.AzkError):
+        eng.emit_finished(replay)
