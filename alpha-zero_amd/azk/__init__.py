@@ -36,15 +36,15 @@ class AzkError(RuntimeError):
 class Config(C.Structure):
     _fields_ = [("game", C.c_int32), ("rows", C.c_int32), ("cols", C.c_int32), ("n_games", C.c_int32),
                 ("max_sims", C.c_int32), ("leaf_dtype", C.c_int32), ("device", C.c_int32),
-                ("arena_nodes", C.c_int32), ("reserved", C.c_int32 * 8)]
+                ("arena_nodes", C.c_int32), ("cache_entries", C.c_int32), ("reserved", C.c_int32 * 7)]
 
 
 class Counters(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ("sims", "edges_scanned", "trace_nodes", "edges_created",
-                                          "leaves_evaluated", "terminal_sims", "moves_played")] + [("reserved", C.c_int64 * 9)]
+                                          "leaves_evaluated", "terminal_sims", "moves_played", "cache_hits")] + [("reserved", C.c_int64 * 8)]
 
     def as_dict(self):
-        return {n: int(getattr(self, n)) for n, _ in self._fields_[:7]}
+        return {n: int(getattr(self, n)) for n, _ in self._fields_[:8]}
 
 
 def build(force=False, verbose=False):
@@ -146,7 +146,7 @@ def _np(a):
 class Engine:
     """G concurrent games + their search trees resident on one GPU (one engine per process / GPU)."""
 
-    def __init__(self, game, n_games, max_sims, size=None, device=0, leaf_dtype="float32", arena_nodes=0):
+    def __init__(self, game, n_games, max_sims, size=None, device=0, leaf_dtype="float32", arena_nodes=0, cache_entries=0):
         torch = _torch()
         self.torch = torch
         self.L = lib()
@@ -155,6 +155,7 @@ class Engine:
         cfg.game = GAME_ID[game]
         cfg.rows = cfg.cols = int(size or 0)
         cfg.n_games, cfg.max_sims, cfg.device, cfg.arena_nodes = int(n_games), int(max_sims), int(device), int(arena_nodes)
+        cfg.cache_entries = int(cache_entries)
         cfg.leaf_dtype = LEAF_BF16 if leaf_dtype in ("bfloat16", "bf16", torch.bfloat16) else LEAF_F32
         self.device = torch.device("cuda", device)
         torch.cuda.set_device(self.device)
@@ -178,6 +179,10 @@ class Engine:
         self.winner = torch.zeros(self.G, dtype=torch.int32, device=dev)
         self.done = torch.zeros(self.G, dtype=torch.int32, device=dev)
         self._noise = None
+        self.cache_entries = int(cache_entries)
+        # with the eval cache a step can have pending (cached) leaves to expand although no leaf went to the evaluator
+        self._no_logits = torch.zeros((1, self.action_dim), dtype=torch.float32, device=dev) if cache_entries else None
+        self._no_values = torch.zeros(1, dtype=torch.float32, device=dev) if cache_entries else None
 
     def _chk(self, rc):
         if rc < 0:
@@ -264,6 +269,8 @@ class Engine:
                 logits = logits.to(torch.float32).contiguous()
                 values = values.to(torch.float32).reshape(-1).contiguous()
                 assert logits.shape == (n, self.action_dim) and values.shape[0] == n
+            elif self.cache_entries:
+                logits, values = self._no_logits, self._no_values      # cache hits still need their expand + backup
             else:
                 logits = values = None
         if logits is not None:

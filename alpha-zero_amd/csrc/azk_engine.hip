@@ -18,7 +18,7 @@
 
 namespace {
 
-enum { CNT_SIMS = 0, CNT_SCANNED, CNT_TRACE, CNT_CREATED, CNT_LEAVES, CNT_TERMINAL, CNT_MOVES, CNT_N };
+enum { CNT_SIMS = 0, CNT_SCANNED, CNT_TRACE, CNT_CREATED, CNT_LEAVES, CNT_TERMINAL, CNT_MOVES, CNT_CACHE_HITS, CNT_N };
 
 struct Dev {               // device view of the engine, passed to kernels by value
     GameDesc g;
@@ -42,6 +42,12 @@ struct Dev {               // device view of the engine, passed to kernels by va
     int16_t *leaf_moves;   // [G][rc] valid moves at the leaf, reference list order
     uint8_t *leaf_flag;    // [G] 1 = this game contributes a leaf to the evaluator batch this step
     const double *noise;   // [G][A] or nullptr
+    // eval cache (MCTS.cache, ai/mcts.py:7,38-51): per-game direct-mapped table keyed by the exact canonical position
+    int cache_entries, key_words;          // entries per game (power of two, 0 = off); 64-bit words per key
+    unsigned long long *cache_key;         // [G][E][key_words] own-stone bit plane, opponent bit plane (+ side bit)
+    float *cache_logits;                   // [G][E][A] the evaluator's logits row
+    float *cache_value;                    // [G][E]
+    int *leaf_cache;                       // [G] >= 0: pending leaf was a cache hit (entry index); < 0: miss, insert at -(x)-1
     int16_t *traj_action;  // [G][state_dim] cell played at each ply of the current game (square boards only, else null)
     double *traj_pi;       // [G][state_dim][A] visit distribution recorded at each ply
     int *emit_base;        // [G] first tuple index of a game being emitted
@@ -148,7 +154,12 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev d, const float *__restric
             const int slot = uniform_i32(d.leaf_slot[g]);
             const int depth = uniform_i32(d.leaf_depth[g]);
             const int nv = uniform_i32(d.leaf_nmoves[g]);
-            const float *lg = logits + (size_t)slot * A;
+            const int centry = d.cache_entries ? uniform_i32(d.leaf_cache[g]) : -1;
+            const bool hit = d.cache_entries && centry >= 0;
+            const size_t crow = ((size_t)g * d.cache_entries + (hit ? centry : -(centry + 1)));
+            const float *lg = hit ? d.cache_logits + crow * A : logits + (size_t)slot * A;
+            if (d.cache_entries && !hit)                              // MCTS.cache[board_key] = (...)  (mcts.py:51)
+                for (int i = lane; i < A; i += AZK_WAVE) d.cache_logits[crow * A + i] = lg[i];
             // float32 softmax, no max subtraction (mcts.py:48-49)
             for (int i = lane; i < A; i += AZK_WAVE) L.e[i] = (d.ablate & 1) ? 1.0f : azk_exp_det(lg[i]);
             __syncthreads();
@@ -176,7 +187,10 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev d, const float *__restric
             } else if (lane == 0) {
                 atomicExch(d.err, AZK_ERR_ARENA_FULL);
             }
-            const double v = -(double)values[slot];                  // mcts.py:56
+            float vraw;
+            if (hit) vraw = d.cache_value[crow];
+            else { vraw = values[slot]; if (d.cache_entries && lane == 0) d.cache_value[crow] = vraw; }
+            const double v = -(double)vraw;                          // mcts.py:56
             backup_path(d, base, d.path + (size_t)g * d.path_cap, depth, v);
             if (lane == 0) {
                 d.leaf_node[g] = -1;
@@ -302,10 +316,34 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev d, const float *__restric
         for (int i = lane; i < nv; i += AZK_WAVE) d.leaf_moves[(size_t)g * rc + i] = L.moves[i];
         for (int i = lane; i < rc; i += AZK_WAVE) d.leaf_cells[(size_t)g * d.rc_pad + i] = L.board[i];
         for (int i = lane; i <= depth; i += AZK_WAVE) d.path[(size_t)g * d.path_cap + i] = L.path[i];
+        bool cached = false;
+        if (d.cache_entries) {                                        // mcts.py:37-44: key = canonical board bytes
+            // key = ballots of "own stone" / "opponent stone" over the cells (own = the side to move at the leaf)
+            const int KW = d.key_words, half = KW >> 1;
+            unsigned long long mykey = 0ull, h = 0x9E3779B97F4A7C15ull;
+            for (int q = 0; q < half; q++) {
+                const int c = q * AZK_WAVE + lane;
+                const uint8_t code = c < rc ? L.board[c] : (uint8_t)0;
+                unsigned long long own = __ballot((code >> node_player) & 1);
+                const unsigned long long opp = __ballot((code >> (node_player ^ 1)) & 1);
+                if (q == half - 1) own |= (unsigned long long)node_player << 63;   // side to move (3-plane games; cell 63 of the last word is never a cell)
+                if (lane == q) mykey = own;
+                if (lane == half + q) mykey = opp;
+                h = (h ^ own) * 0xFF51AFD7ED558CCDull; h ^= h >> 29;
+                h = (h ^ opp) * 0xC4CEB9FE1A85EC53ull; h ^= h >> 32;
+            }
+            const int entry = (int)(h & (unsigned long long)(d.cache_entries - 1));
+            unsigned long long *kp = d.cache_key + ((size_t)g * d.cache_entries + entry) * KW;
+            const bool same = lane < KW ? kp[lane] == mykey : true;
+            cached = __ballot(!same) == 0ull;
+            if (!cached && lane < KW) kp[lane] = mykey;                // claim the slot now; logits/value land at expansion
+            if (lane == 0) d.leaf_cache[g] = cached ? entry : -(entry + 1);
+        }
         if (lane == 0) {
             d.leaf_node[g] = node; d.leaf_depth[g] = depth; d.leaf_nmoves[g] = nv;
-            d.leaf_flag[g] = 1;
-            d.counters[(size_t)CNT_LEAVES * d.G + g] += 1;
+            d.leaf_flag[g] = cached ? 0 : 1;
+            if (cached) d.counters[(size_t)CNT_CACHE_HITS * d.G + g] += 1;
+            d.counters[(size_t)CNT_LEAVES * d.G + g] += cached ? 0 : 1;
             if (stamp) {
                 long long *q = d.dbg + (size_t)g * 8;
                 q[0] += t1 - t0; q[1] += t2 - t1; q[2] += t3 - t2; q[3] += t4 - t3; q[4] += clock64() - t4; q[5] += depth; q[6] += 1;
@@ -355,10 +393,20 @@ __global__ __launch_bounds__(AZK_WAVE) void k_gather(Dev d, void *__restrict__ l
     }
 }
 
+// A leaf that missed the eval cache claims its entry's key at selection and fills logits/value at expansion; if the search
+// is abandoned in between (new search, reset, recycle) the half-written entry must not survive.
+__device__ __forceinline__ void drop_pending_cache_claim(const Dev &d, int g) {
+    if (d.cache_entries && d.leaf_node[g] >= 0 && d.leaf_cache[g] < 0) {
+        unsigned long long *kp = d.cache_key + ((size_t)g * d.cache_entries + (size_t)(-(d.leaf_cache[g] + 1))) * d.key_words;
+        for (int w = 0; w < d.key_words; w++) kp[w] = ~0ull;
+    }
+}
+
 // Node(None, None, current_player, move_count) for every game (gomoku.py:134)
 __global__ void k_begin_search(Dev d) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= d.G) return;
+    drop_pending_cache_claim(d, g);
     const size_t base = (size_t)g * d.cap;
     d.N[base] = 0; d.W[base] = 0.0; d.P[base] = 0.f; d.meta[base] = meta_pack(0xffff, 0);
     d.first_child[base] = -1;
@@ -370,6 +418,7 @@ __global__ void k_reset_games(Dev d, int first, int count) {
     if (t >= count * d.rc_pad) return;
     const int g = first + t / d.rc_pad, i = t % d.rc_pad;
     d.cells[(size_t)g * d.rc_pad + i] = 0;
+    if (i == 0) drop_pending_cache_claim(d, g);
     if (i == 0) { d.to_move[g] = 0; d.move_count[g] = 0; d.done[g] = 0; d.winner[g] = -2; d.leaf_node[g] = -1; d.leaf_flag[g] = 0; }
 }
 
@@ -382,6 +431,7 @@ __global__ void k_recycle(Dev d, long long *stats) {
     atomicAdd((unsigned long long *)&stats[1], (unsigned long long)d.move_count[g]);
     const int w = d.winner[g];
     atomicAdd((unsigned long long *)&stats[w == 0 ? 2 : (w == 1 ? 3 : 4)], 1ull);
+    drop_pending_cache_claim(d, g);
     for (int i = 0; i < d.rc_pad; i++) d.cells[(size_t)g * d.rc_pad + i] = 0;
     d.to_move[g] = 0; d.move_count[g] = 0; d.done[g] = 0; d.winner[g] = -2; d.leaf_node[g] = -1; d.leaf_flag[g] = 0;
 }
@@ -799,6 +849,7 @@ int32_t azk_create(const azk_config *cfg, azk_engine **out) {
     if (!make_game(cfg->game, cfg->rows, cfg->cols, &d.g, &gerr)) return fail(AZK_ERR_ARG, gerr);
     if (cfg->n_games < 1 || cfg->max_sims < 1) return fail(AZK_ERR_ARG, "n_games and max_sims must be >= 1");
     if (cfg->leaf_dtype != AZK_LEAF_F32 && cfg->leaf_dtype != AZK_LEAF_BF16) return fail(AZK_ERR_ARG, "bad leaf_dtype");
+    if (cfg->cache_entries < 0 || (cfg->cache_entries & (cfg->cache_entries - 1)) != 0) return fail(AZK_ERR_ARG, "cache_entries must be 0 or a power of two");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
         return fail(AZK_ERR_HIP, "no HIP device visible: libazk needs an MI355X (there is no CPU fallback)");
@@ -823,6 +874,12 @@ int32_t azk_create(const azk_config *cfg, azk_engine **out) {
     DA(d.path, G * d.path_cap); DA(d.leaf_cells, G * d.rc_pad); DA(d.leaf_moves, G * g.rc);
     DA(d.leaf_flag, ((G + 511) / 512) * 512 + 512);
     DA(d.counters, (size_t)CNT_N * G); DA(d.err, 1); DA(d.dbg, G * 8); DA(d.emit_base, G);
+    d.cache_entries = cfg->cache_entries;
+    d.key_words = 2 * ((g.rc + 64) / 64);                         // one spare bit (63 of the last own-plane word) for the side to move
+    if (d.cache_entries) {
+        DA(d.cache_key, G * (size_t)d.cache_entries * d.key_words); DA(d.cache_logits, G * (size_t)d.cache_entries * g.action_dim);
+        DA(d.cache_value, G * (size_t)d.cache_entries); DA(d.leaf_cache, G);
+    }
     if (g.rows == g.cols && g.action_dim == g.rc) { DA(d.traj_action, G * g.state_dim); DA(d.traj_pi, G * g.state_dim * g.action_dim); } DA(e->counter_sums, CNT_N); DA(e->n_leaf_scratch, 1);
     if (s == hipSuccess) { uint8_t *ls = nullptr; s = dalloc(e, &ls, G * g.planes * g.rc * 4); e->leaf_scratch = ls; }
 #undef DA
@@ -830,6 +887,7 @@ int32_t azk_create(const azk_config *cfg, azk_engine **out) {
     (void)hipMemset(d.leaf_flag, 0, ((G + 511) / 512) * 512 + 512);
     (void)hipMemset(d.counters, 0, sizeof(long long) * CNT_N * G);
     (void)hipMemset(d.err, 0, sizeof(int));
+    if (d.cache_entries) (void)hipMemset(d.cache_key, 0xff, sizeof(unsigned long long) * G * (size_t)d.cache_entries * d.key_words);   // all-ones = no position
     (void)hipMemset(d.dbg, 0, sizeof(long long) * G * 8);
     (void)hipMemset(d.leaf_node, 0xff, sizeof(int) * G);
     k_reset_games<<<(unsigned)((G * d.rc_pad + 255) / 256), 256>>>(d, 0, d.G);
@@ -1088,7 +1146,7 @@ int32_t azk_get_counters(azk_engine *e, azk_counters *out, void *stream) {
     memset(out, 0, sizeof *out);
     out->sims = h[CNT_SIMS]; out->edges_scanned = h[CNT_SCANNED]; out->trace_nodes = h[CNT_TRACE];
     out->edges_created = h[CNT_CREATED]; out->leaves_evaluated = h[CNT_LEAVES]; out->terminal_sims = h[CNT_TERMINAL];
-    out->moves_played = h[CNT_MOVES];
+    out->moves_played = h[CNT_MOVES]; out->cache_hits = h[CNT_CACHE_HITS];
     return AZK_OK;
 }
 

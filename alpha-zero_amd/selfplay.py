@@ -41,7 +41,7 @@ class SelfPlayResult:
 
 def self_play_batch(game, evaluator, n_games, n_sims, size=None, seed=0, first_global_game=0, dirichlet=True,
                     alpha=0.03, noise_fn=None, uniform_fn=None, device=0, leaf_dtype="float32", engine=None,
-                    max_moves=None, sample_until=None, stats=None, replay=None):
+                    max_moves=None, sample_until=None, stats=None, replay=None, cache_entries=0):
     """Play n_games games to the end in one batch.
 
     evaluator(boards[n,F,R,C] CUDA) -> (logits [n,A], values [n] | [n,1]).
@@ -51,7 +51,7 @@ def self_play_batch(game, evaluator, n_games, n_sims, size=None, seed=0, first_g
     (that is how parity tests inject the reference's recorded np.random draws).
     """
     import torch
-    eng = engine or Engine(game, n_games, n_sims, size=size, device=device, leaf_dtype=leaf_dtype)
+    eng = engine or Engine(game, n_games, n_sims, size=size, device=device, leaf_dtype=leaf_dtype, cache_entries=cache_entries)
     assert eng.G == n_games
     G, A = eng.G, eng.action_dim
     eng.reset_games()
@@ -134,7 +134,7 @@ class SelfPlayRunner:
 
     def __init__(self, game, evaluator, n_games, n_sims, size=None, seed=0, first_global_game=0, dirichlet=True,
                  alpha=0.03, device=0, leaf_dtype="float32", recycle=True, on_records=None, kernel_timer=None,
-                 use_graph=False, n_split=1, replay=None):
+                 use_graph=False, n_split=1, replay=None, cache_entries=0):
         import torch
         self.replay = replay
         self.torch = torch
@@ -143,7 +143,8 @@ class SelfPlayRunner:
         assert n_games % n_split == 0
         self.n_split = n_split if use_graph else 1
         per = n_games // self.n_split
-        self.halves = [_Half(torch, Engine(game, per, n_sims, size=size, device=device, leaf_dtype=leaf_dtype), dirichlet)
+        self.halves = [_Half(torch, Engine(game, per, n_sims, size=size, device=device, leaf_dtype=leaf_dtype,
+                                           cache_entries=cache_entries), dirichlet)
                        for _ in range(self.n_split)]
         self.eng = self.halves[0].eng
         self.G = n_games
@@ -208,6 +209,8 @@ class SelfPlayRunner:
                 logits, values = self.evaluator(e.leaf_boards[:n])
                 logits = logits.to(torch.float32).contiguous()
                 values = values.to(torch.float32).reshape(-1).contiguous()
+            elif e.cache_entries:
+                logits, values = e._no_logits, e._no_values
             else:
                 logits = values = None
         if logits is not None:

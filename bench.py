@@ -87,6 +87,7 @@ def main():
     ap.add_argument("--nn-path", default="clsfold", choices=["clsfold", "cls", "full"])
     ap.add_argument("--no-graph", action="store_true", help="eager stepping with a host sync per simulation (n_leaf-sized batches)")
     ap.add_argument("--split", type=int, default=1, help="independent game groups stepped on separate streams inside the step graph")
+    ap.add_argument("--cache-entries", type=int, default=8192, help="per-game eval-cache entries (MCTS.cache); 0 = off")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="wall-clock budget of the CPU baseline leg (0 = skip)")
     ap.add_argument("--seed", type=int, default=0)
     args = ap.parse_args()
@@ -109,7 +110,7 @@ def main():
     kt = KernelTimer(stride=16)
     runner = SelfPlayRunner("gomoku", net, args.games, args.sims, size=args.size, seed=args.seed,
                             first_global_game=shard_range(args.games, rank)[0], device=local_rank, leaf_dtype="bfloat16",
-                            recycle=True, kernel_timer=kt, use_graph=not args.no_graph, n_split=args.split)
+                            recycle=True, kernel_timer=kt, use_graph=not args.no_graph, n_split=args.split, cache_entries=args.cache_entries)
     eng = runner.eng
 
     def sync_all():
@@ -174,6 +175,8 @@ def main():
                        "sims_per_move": args.sims, "net": f"ViT patch5 embed512 heads8 depth1 (ai/nn.py), random init seed 0, path={args.nn_path}",
                        "parallelism": f"games sharded over {world} GPU(s), no collectives on the generation path"},
             "sims_per_sec": sims_all / dt_max, "leaf_evals_per_sec": leaves_all / dt_max,
+            "eval_cache": {"entries_per_game": args.cache_entries, "hits_rank0": c.get("cache_hits", 0),
+                           "hit_rate_rank0": c.get("cache_hits", 0) / max(1, c.get("cache_hits", 0) + c["leaves_evaluated"])},
             "nn_tflops_executed": evals * flops / dt_max / 1e12, "nn_flops_per_board": flops, "nn_boards_evaluated": evals,
             "stepping": "eager+sync" if args.no_graph else f"hipGraph replay, {runner.n_split} game group(s) on separate streams (tree+gather+net per simulation, no host sync)",
             "mean_plies_per_game": mean_plies, "game_length_source": src, "games_finished_in_window": fin_window,

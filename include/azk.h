@@ -55,7 +55,9 @@ typedef struct {
     int32_t leaf_dtype;    /* AZK_LEAF_F32 | AZK_LEAF_BF16 */
     int32_t device;        /* HIP device ordinal */
     int32_t arena_nodes;   /* nodes per game; 0 = worst case 1 + max_sims * max_children */
-    int32_t reserved[8];
+    int32_t cache_entries; /* eval cache (MCTS.cache, ai/mcts.py:7,38-51): entries per game, power of two, 0 = off.  Exact keys
+                            * (the whole canonical position), so a hit returns precisely what the evaluator returned. */
+    int32_t reserved[7];
 } azk_config;
 
 /* device-side work counters; sums over all games since the last azk_reset_counters */
@@ -67,7 +69,8 @@ typedef struct {
     int64_t leaves_evaluated; /* leaf boards handed to the evaluator (mcts.py:46) */
     int64_t terminal_sims;    /* simulations that ended in mcts.py:25-32 */
     int64_t moves_played;
-    int64_t reserved[9];
+    int64_t cache_hits;       /* MCTS.matched (mcts.py:9,44): leaves served by the eval cache; leaves_evaluated counts the misses */
+    int64_t reserved[8];
 } azk_counters;
 
 int32_t azk_abi_version(void);

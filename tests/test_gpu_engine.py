@@ -369,3 +369,43 @@ def test_arena_overflow_is_an_error_not_ub(azk):
     eng.search(gpu_evaluator(49, "hash"), 50, None)
     with pytest.raises(azk.AzkError):
         eng.check_error()
+
+
+# ---------------------------------------------------------------------------------------------------
+# eval cache (MCTS.cache): transparent - same trees, same games - and it does hit
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", [3, 10, 13, 18, 22])
+def test_eval_cache_is_transparent_on_trees(azk, case):
+    m = next(x for x in _SMETA if x["case"] == case)
+    k = f"c{m['case']}_"
+    from oracle import az_oracle as ao
+    game, tree, cells, player, cnt = oracle_tree(ao, m, k, ao.softmax_det)
+    eng = azk.Engine(m["game"], 2, m["n_sims"], size=m["size"] or None, cache_entries=4096)
+    eng.set_positions(np.tile(cells, (2, 1)), [player] * 2, [len(_SZ[k + "actions"])] * 2)
+    noise = torch.from_numpy(np.tile(_SZ[k + "noise"], (2, 1))).to(dev()) if m["dirichlet"] else None
+    want = digest(tree.export())
+    for rep in range(2):                    # second search of the same position: (almost) everything comes from the cache
+        eng.reset_counters()
+        eng.search(gpu_evaluator(game.action_dim, m["variant"]), m["n_sims"], noise)
+        eng.check_error()
+        assert digest(eng.export_tree(0)) == want and digest(eng.export_tree(1)) == want
+        c = eng.counters()
+        assert c["leaves_evaluated"] + c["cache_hits"] == 2 * cnt.expansions
+        if rep == 1 and m["n_sims"] <= 400:
+            assert c["cache_hits"] > 0.8 * 2 * cnt.expansions
+    eng.close()
+
+
+def test_eval_cache_whole_games_identical(azk):
+    from selfplay import self_play_batch
+    A, G = 49, 24
+    ev = gpu_evaluator(A, "hash")
+    s0, s1 = {}, {}
+    plain = self_play_batch("gomoku", ev, G, 64, size=7, seed=9, stats=s0)
+    cached = self_play_batch("gomoku", ev, G, 64, size=7, seed=9, stats=s1, cache_entries=1024)
+    for a, b in zip(plain, cached):
+        assert a.cells == b.cells and a.winner == b.winner
+        assert np.stack(a.pis).tobytes() == np.stack(b.pis).tobytes() and a.qs == b.qs
+    assert s0["cache_hits"] == 0 and s1["cache_hits"] > 0
+    assert s1["leaves_evaluated"] + s1["cache_hits"] == s0["leaves_evaluated"]
+    assert s1["cache_hits"] / s0["leaves_evaluated"] > 0.15          # the reference sees 34-66 %
