@@ -10,8 +10,9 @@ games per GPU, policy-value net = the reference's training config (ai/nn.py Net(
 A STEP is one move of the whole resident batch: 2048 searches x 800 simulations (tree kernels + leaf
 compaction + network evaluation + expansion/backup), move selection, state advance, the per-move records
 (board, pi, q, action) copied to the host, and finished games restarted (continuous self-play).
-value = self-play games/sec = plies played in the timed region / mean plies per finished game / seconds
-(the steady-state completion rate; raw completions inside the window are reported next to it).
+value = self-play games/sec = games COMPLETED inside the timed region / seconds.  All games start in phase, so the
+default warm-up (40 moves, about two game lengths) lets the phases decorrelate before timing; the renewal estimate
+(plies per second / mean game length) is reported next to it and is used only when the window is too short to count.
 
 One JSON line on rank 0.  Extra objects:
   roofline      k_tree (PUCT scan + expand + backup), HBM-bound: algorithmic bytes per launch from the engine's
@@ -79,8 +80,8 @@ def cpu_baseline(n_sims, budget_s, mean_plies):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--games", type=int, default=2048, help="concurrent games per GPU")
     ap.add_argument("--sims", type=int, default=800)
     ap.add_argument("--size", type=int, default=15)
@@ -146,7 +147,11 @@ def main():
             mean_plies, src = finp_all / fin_all, f"{int(fin_all)} games finished in this run"
         else:
             mean_plies, src = 30.0, "no game finished in this run: assumed 30 plies"
-        games_per_s = plies_all / mean_plies / dt_max
+        est_games_per_s = plies_all / mean_plies / dt_max          # renewal estimate: plies per second / mean game length
+        if fin_window >= 0.25 * args.games * world:
+            games_per_s, value_src = fin_window / dt_max, "games completed inside the timed window / seconds"
+        else:   # window too short for completions to be meaningful (all games start in phase): fall back to the estimate
+            games_per_s, value_src = est_games_per_s, "plies in window / mean plies per finished game / seconds (window too short for a direct count)" 
         tree_ms = kt.mean_ms()
         launches = args.steps * args.sims * runner.n_split      # k_tree launches (one per game group per simulation)
         alg_bytes = algorithmic_bytes(c, A) / launches
@@ -179,6 +184,7 @@ def main():
                            "hit_rate_rank0": c.get("cache_hits", 0) / max(1, c.get("cache_hits", 0) + c["leaves_evaluated"])},
             "nn_tflops_executed": evals * flops / dt_max / 1e12, "nn_flops_per_board": flops, "nn_boards_evaluated": evals,
             "stepping": "eager+sync" if args.no_graph else f"hipGraph replay, {runner.n_split} game group(s) on separate streams (tree+gather+net per simulation, no host sync)",
+            "value_definition": value_src, "games_per_sec_renewal_estimate": est_games_per_s,
             "mean_plies_per_game": mean_plies, "game_length_source": src, "games_finished_in_window": fin_window,
             "plies_in_window": plies_all, "counters_rank0": c, "roofline": roof,
         }
