@@ -77,6 +77,13 @@ __global__ __launch_bounds__(256, 2) void k_embed(EmbedArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
+    // work item = (board, group of consecutive 16-token tiles): a board's tiles are spread over `groups` wavefronts so
+    // the chip stays busy when only part of the batch is live
+    const int tiles_per_leaf_ = (a.T + 15) >> 4;
+    const int groups = tiles_per_leaf_ >= 6 ? 3 : 1, tiles_per_group = (tiles_per_leaf_ + groups - 1) / groups;
+    const int nvalid = a.count ? min(a.n, *a.count) : a.n;
+    const int nitems = nvalid * groups;
+    if ((int)blockIdx.x * 4 >= nitems) return;                  // nothing for this workgroup: skip the weight staging too
 
     // ---- stage the weight in fragment order: fragment (acc, s) of lane l = wt[col(acc, l)][32 s + 8 (l>>4) .. +8] ----
     for (int f = tid; f < NACC * KS * 64; f += 256) {
@@ -95,9 +102,11 @@ __global__ __launch_bounds__(256, 2) void k_embed(EmbedArgs a) {
     const int nwaves = gridDim.x * 4;
 
 
-    // one wavefront owns one board: its bit string is built once, then the wave walks the board's 16-token tiles
-    const int nvalid = a.count ? min(a.n, *a.count) : a.n;
-    for (int leaf = blockIdx.x * 4 + wave; leaf < nvalid; leaf += nwaves) {
+    // the board's bit string is built once per item, then the wave walks its group of 16-token tiles
+    for (int item = blockIdx.x * 4 + wave; item < nitems; item += nwaves) {
+        const int leaf = item / groups, grp = item - leaf * groups;
+        const int tile_lo = grp * tiles_per_group;
+        const int tile_hi = min(tiles_per_leaf, tile_lo + tiles_per_group);
         unsigned wbits = 0;                             // lane i holds bits [32 (i-1), 32 i) of the board bit string (lane 0: zeros)
         if (!(a.ablate & 8)) {
             for (int q = 0; q * 64 < ncell; q++) {
@@ -110,7 +119,7 @@ __global__ __launch_bounds__(256, 2) void k_embed(EmbedArgs a) {
                 if ((lane - 1) >> 1 == q && lane >= 1) wbits = ((lane - 1) & 1) ? (unsigned)(m >> 32) : (unsigned)m;
             }
         }
-      for (int tile = 0; tile < tiles_per_leaf; tile++) {
+      for (int tile = tile_lo; tile < tile_hi; tile++) {
         // ---- this lane's token (A-fragment row l&15) and its patch bits ----
         const int t = tile * 16 + l15;
         unsigned long long plo = 0, phi = 0;
@@ -265,8 +274,9 @@ template <int NG, int KS, bool WX, bool WH, int NH>
 int launch_embed2(const EmbedArgs &a, hipStream_t st) {
     constexpr int NACC = 8 * NG;
     const int lds = NACC * KS * 64 * 16 + (NH > 0 ? NH : 2) * 128 * NG * 4;
-    long long blocks = ((long long)a.n + 3) / 4;
-    if (blocks > 512) blocks = 512;                    // 2 workgroups per CU resident (LDS + VGPR budget)
+    const int tiles = (a.T + 15) >> 4, groups = tiles >= 6 ? 3 : 1;
+    long long blocks = ((long long)a.n * groups + 3) / 4;       // one wavefront per (board, tile group); idle workgroups exit at once
+    if (blocks > 4096) blocks = 4096;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void *)k_embed<NG, KS, WX, WH, NH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return AZK_ERR_HIP;
@@ -519,43 +529,36 @@ __global__ __launch_bounds__(256) void k_cls_pool(ClsPoolArgs a) {
     constexpr int D = 64 * CPL;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.x * 4 + wave;                     // one wavefront per board, no workgroup barriers
+    const int b = blockIdx.x;                                // one workgroup (4 waves) per board: wave w takes tokens 8 (4 i + w) .. +8
     if (b >= (a.count ? min(a.n, *a.count) : a.n)) return;
-    float *aw = (float *)smem + (size_t)wave * a.Tp * NH;    // [Tp][NH] softmax weights of this wave's board
+    float *aw = (float *)smem;                               // [Tp][NH] softmax weights
+    float *zpart = aw + (size_t)a.Tp * NH;                   // [2][NH][D] partial sums handed between waves
     const float *sp = a.scores + (size_t)b * NH * a.Tp;
-    // ---- softmax over tokens, per head (scores are tiny: NH * T floats): all loads first, then the reductions ----
+    // ---- softmax over tokens: wave w handles heads w, w + 4 (scores are tiny: NH * T floats) ----
     if (!(a.ablate & 1)) {
-        float e[NH][4];
-#pragma unroll
-        for (int h = 0; h < NH; h++)
+        for (int h = wave; h < NH; h += 4) {
+            const float ch = a.c[h];
+            float e[4], mx = -3.0e38f;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const int t = lane + 64 * k;
-                e[h][k] = t < a.T ? sp[h * a.Tp + t] : -3.0e38f;
+                e[k] = t < a.T ? sp[h * a.Tp + t] + ch : -3.0e38f;
+                mx = fmaxf(mx, e[k]);
             }
-#pragma unroll
-        for (int h = 0; h < NH; h++) {
-            const float ch = a.c[h];
-            float mx = -3.0e38f;
-#pragma unroll
-            for (int k = 0; k < 4; k++) { e[h][k] += ch; mx = fmaxf(mx, e[h][k]); }
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
             float sum = 0.f;
 #pragma unroll
-            for (int k = 0; k < 4; k++) { e[h][k] = (lane + 64 * k) < a.T ? __expf(e[h][k] - mx) : 0.f; sum += e[h][k]; }
+            for (int k = 0; k < 4; k++) { e[k] = (lane + 64 * k) < a.T ? __expf(e[k] - mx) : 0.f; sum += e[k]; }
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
             const float inv = 1.0f / sum;
 #pragma unroll
-            for (int k = 0; k < 4; k++) { const int t = lane + 64 * k; if (t < a.Tp) aw[t * NH + h] = e[h][k] * inv; }
+            for (int k = 0; k < 4; k++) { const int t = lane + 64 * k; if (t < a.Tp) aw[t * NH + h] = e[k] * inv; }
         }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // ---- weighted token sum: each lane owns CPL columns; two 8-row register sets, one in flight while the other is
-    //      consumed (software pipelining: the wave always has 8-16 KB of loads outstanding) ----
+    __syncthreads();
+    // ---- weighted token sum: each lane owns CPL columns; 8-row register sets, two in flight per wave ----
     float zacc[NH][CPL];
 #pragma unroll
     for (int h = 0; h < NH; h++)
@@ -584,36 +587,64 @@ __global__ __launch_bounds__(256) void k_cls_pool(ClsPoolArgs a) {
         for (int k = 0; k < 8; k++) { const int t = t0 + k < a.T ? t0 + k : a.T - 1; load_row<CPL>(base + (size_t)t * D, x[k]); }
     };
     float xa[8][CPL], xb[8][CPL];
-    if (T > 0) fetch(xa, 0);
-    for (int t = 0; t < T; t += 16) {
-        if (t + 8 < T) fetch(xb, t + 8);
+    const int t_first = 8 * wave;                             // this wave's 8-token chunks: t_first, t_first + 32, ...
+    if (t_first < T) fetch(xa, t_first);
+    for (int t = t_first; t < T; t += 64) {
+        if (t + 32 < T) fetch(xb, t + 32);
         consume(xa, t);
-        if (t + 16 < T) fetch(xa, t + 16);
-        if (t + 8 < T) consume(xb, t + 8);
+        if (t + 64 < T) fetch(xa, t + 64);
+        if (t + 32 < T) consume(xb, t + 32);
     }
-    if (a.ablate & 4) return;
+    // ---- combine the four waves: 3,2 -> LDS ; 1,0 add theirs and 1 -> LDS ; 0 adds, packs, stores ----
+    if (!(a.ablate & 4)) {
+        if (wave >= 2) {
 #pragma unroll
-    for (int h = 0; h < NH; h++) {
-        unsigned short *dst = (unsigned short *)a.z + ((size_t)b * NH + h) * D + lane * CPL;
-        if (CPL == 8) {
-            *(uint4 *)dst = pack8(zacc[h]);
-        } else {
+            for (int h = 0; h < NH; h++)
 #pragma unroll
-            for (int q = 0; q < CPL; q++) dst[q] = __bfloat16_as_ushort(__float2bfloat16(zacc[h][q]));
+                for (int q = 0; q < CPL; q++) zpart[((wave - 2) * NH + h) * D + q * 64 + lane] = zacc[h][q];
+        }
+        __syncthreads();
+        if (wave < 2) {
+#pragma unroll
+            for (int h = 0; h < NH; h++)
+#pragma unroll
+                for (int q = 0; q < CPL; q++) zacc[h][q] += zpart[(wave * NH + h) * D + q * 64 + lane];
+        }
+        __syncthreads();
+        if (wave == 1) {
+#pragma unroll
+            for (int h = 0; h < NH; h++)
+#pragma unroll
+                for (int q = 0; q < CPL; q++) zpart[h * D + q * 64 + lane] = zacc[h][q];
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int h = 0; h < NH; h++) {
+#pragma unroll
+                for (int q = 0; q < CPL; q++) zacc[h][q] += zpart[h * D + q * 64 + lane];
+                unsigned short *dst = (unsigned short *)a.z + ((size_t)b * NH + h) * D + lane * CPL;
+                if (CPL == 8) {
+                    *(uint4 *)dst = pack8(zacc[h]);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < CPL; q++) dst[q] = __bfloat16_as_ushort(__float2bfloat16(zacc[h][q]));
+                }
+            }
         }
     }
 }
 
 template <int CPL, int NH>
 int launch_cls_pool(const ClsPoolArgs &a, hipStream_t st) {
-    const int lds = 4 * a.Tp * NH * 4;
+    const int lds = (a.Tp * NH + 2 * NH * 64 * CPL) * 4;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void *)k_cls_pool<CPL, NH>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess) return AZK_ERR_HIP;
         attr_set = true;
     }
     if (lds > 64 * 1024) return AZK_ERR_ARG;
-    k_cls_pool<CPL, NH><<<(a.n + 3) / 4, 256, lds, st>>>(a);
+    k_cls_pool<CPL, NH><<<a.n, 256, lds, st>>>(a);
     return hipGetLastError() == hipSuccess ? AZK_OK : AZK_ERR_HIP;
 }
 
