@@ -115,6 +115,7 @@ class PolicyValueNet:
         self.master = {k_: torch.as_tensor(v).detach().to(torch.float32).cpu().clone() for k_, v in w.items()}
         self.path = path
         self.fast_outputs = False   # True: logits may come back as a bf16 view (the caller converts while copying)
+        self.last_value_pre_tanh = False
         self.live_count = None      # optional int32 CUDA tensor: number of valid rows at the head of the batch (graph stepping)
         self.to(device, dtype)
 
@@ -134,6 +135,7 @@ class PolicyValueNet:
         self.scale = 1.0 / math.sqrt(D // H)
         self._hip = None
         self._fold = None
+        self._gelu_epilogue = False
         if self.device.type == "cuda" and self.dtype == torch.bfloat16:
             self._prepare_hip_embed()
             if self._hip is not None:
@@ -187,6 +189,16 @@ class PolicyValueNet:
             Wh[:A], bh[:A] = m["policy_head.weight"].to(dev), m["policy_head.bias"].to(dev)
             Wh[A], bh[A] = m["value_head.weight"].to(dev)[0], m["value_head.bias"].to(dev)[0]
             f["Wh"], f["bh"] = Wh.to(torch.bfloat16), bh.to(torch.bfloat16)
+            f["W0T"] = m["blocks.0.mlp.0.weight"].t().contiguous().to(dev, torch.bfloat16)
+            f["W3T"] = m["blocks.0.mlp.3.weight"].t().contiguous().to(dev, torch.bfloat16)
+            self._gelu_epilogue = False
+            try:    # exact-erf GELU fused into the GEMM when the BLAS backend offers it; checked against the unfused op
+                t = torch.randn(64, D, device=dev, dtype=torch.bfloat16)
+                a_ = torch._addmm_activation(self.w["blocks.0.mlp.0.bias"], t, f["W0T"], use_gelu=True)
+                b_ = F.gelu(F.linear(t, self.w["blocks.0.mlp.0.weight"], self.w["blocks.0.mlp.0.bias"]))
+                self._gelu_epilogue = bool(torch.allclose(a_.float(), b_.float(), rtol=2e-2, atol=2e-2))
+            except Exception:
+                self._gelu_epilogue = False
         self._fold = f
 
     def tail_fast(self, z):
@@ -195,12 +207,18 @@ class PolicyValueNet:
         n, A = z.shape[0], cfg.action_dim
         x1 = torch.addmm(f["bias1"], z.view(n, -1), f["Wcomb"])                                        # nn.py:54-56
         h = self._ln(x1, "blocks.0.norm2")
-        h = F.gelu(F.linear(h, w["blocks.0.mlp.0.weight"], w["blocks.0.mlp.0.bias"]))
-        x2 = torch.addmm(x1, h, w["blocks.0.mlp.3.weight"].t()) + w["blocks.0.mlp.3.bias"]            # nn.py:59-60
+        if self._gelu_epilogue:                                                                         # GELU in the GEMM epilogue (hipBLASLt)
+            h = torch._addmm_activation(w["blocks.0.mlp.0.bias"], h, f["W0T"], use_gelu=True)
+        else:
+            h = F.gelu(F.linear(h, w["blocks.0.mlp.0.weight"], w["blocks.0.mlp.0.bias"]))
+        x2 = torch.addmm(x1, h, f["W3T"]).add_(w["blocks.0.mlp.3.bias"])                               # nn.py:59-60
         out = F.linear(self._ln(x2, "norm"), f["Wh"], f["bh"])                                          # nn.py:78-83
         logits = out[:, :A]
-        # callers that copy into their own float32 buffers (the step graph) take the bf16 view and save a conversion kernel
-        return (logits if self.fast_outputs else logits.float()), torch.tanh(out[:, A:A + 1].float())
+        if self.fast_outputs:
+            # the step graph copies into its own float32 buffers (conversion folded into the copy); tanh runs there in place
+            self.last_value_pre_tanh = True
+            return logits, out[:, A:A + 1]
+        return logits.float(), torch.tanh(out[:, A:A + 1].float())
 
 
     def _prepare_hip_embed(self):
@@ -322,6 +340,7 @@ class PolicyValueNet:
     def forward(self, x, path=None):
         path = path or self.path
         x = x.to(self.device)
+        self.last_value_pre_tanh = False     # set by the one path that hands back the raw value column (fast_outputs)
         depth = self.cfg.depth
         if path == "clsfold":
             if self._fold is None:

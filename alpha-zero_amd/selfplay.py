@@ -234,6 +234,8 @@ class SelfPlayRunner:
         logits, values = self.evaluator(e.leaf_boards)
         h.logits_buf.copy_(logits)
         h.values_buf.copy_(values.reshape(-1))
+        if getattr(self.evaluator, "last_value_pre_tanh", False):
+            h.values_buf.tanh_()                       # the fast path hands back the raw value column (nn.py:83 tanh applied here)
 
     def _all_bodies(self):
         torch = self.torch

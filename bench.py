@@ -102,6 +102,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local_rank)
+    torch.set_num_threads(min(8, os.cpu_count() or 1))       # the host only launches kernels; N ranks must not each spawn 128 threads
 
     from pvnet import NetConfig, PolicyValueNet
     from selfplay import KernelTimer, SelfPlayRunner

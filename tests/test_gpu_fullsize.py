@@ -139,3 +139,22 @@ def test_same_seed_same_games_regardless_of_batch_split():
         part = lo[g] if g < 32 else hi[g - 32]
         assert whole[g].cells == part.cells and whole[g].winner == part.winner
         assert np.stack(whole[g].pis).tobytes() == np.stack(part.pis).tobytes()
+
+
+def test_config2_connect4_with_the_rectangular_vit():
+    """configs[1] with a real network: 256 Connect4 games x 200 sims through the bf16 ViT (6x7 tokens + cls; the
+    reference's Net is square-only, so this net is build-defined - 'parity unpinned' - and only sanity is checked)."""
+    from pvnet import NetConfig, PolicyValueNet
+    from selfplay import self_play_batch
+    cfg = NetConfig(6, 7, 3, 7, patch_size=5, embed_dim=256, num_heads=8, depth=1)
+    net = PolicyValueNet(cfg, seed=0, device="cuda", dtype=torch.bfloat16, path="clsfold")
+    assert net._hip is not None and net._fold is not None
+    ref = PolicyValueNet(cfg, weights=net.state_dict(), device="cuda", dtype=torch.float32, path="full")
+    x = (torch.rand(32, 3, 6, 7, device="cuda") < 0.2).float()
+    x[:, 1] *= 1 - x[:, 0]
+    torch.testing.assert_close(net(x.to(torch.bfloat16))[0], ref(x)[0], rtol=0, atol=5e-2)
+    stats = {}
+    res = self_play_batch("connect4", net, 256, 200, seed=4, leaf_dtype="bfloat16", stats=stats, cache_entries=1024)
+    assert all(r.winner in (0, 1, -1) and 7 <= len(r.cells) <= 42 for r in res)
+    assert all(abs(p.sum() - 1) < 1e-12 for r in res for p in r.pis)
+    assert stats["sims"] == 200 * sum(len(r.cells) for r in res) and stats["cache_hits"] > 0
