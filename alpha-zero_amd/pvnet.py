@@ -338,6 +338,10 @@ class PolicyValueNet:
 
     @torch.no_grad()
     def forward(self, x, path=None):
+        return self.forward_impl(x, path)
+
+    def forward_impl(self, x, path=None):
+        """The forward without the no_grad guard (the training step differentiates the plain 'full' path)."""
         path = path or self.path
         x = x.to(self.device)
         self.last_value_pre_tanh = False     # set by the one path that hands back the raw value column (fast_outputs)

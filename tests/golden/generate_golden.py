@@ -449,8 +449,50 @@ def gen_nn_small():
     return out
 
 
+# =================================================================================
+# 5. train step (train.py:85-123): loss, L2 quirk, Adam - small net, dropout 0 (deterministic)
+# =================================================================================
+def gen_train():
+    import json
+    out = {}
+    torch.manual_seed(3)
+    cfg = dict(img_size=7, patch_size=5, embed_dim=32, action_dim=49, num_heads=4, depth=2, channels=2)
+    net = RefNet(dropout=0.0, **cfg)
+    rng = np.random.RandomState(5)
+    B = 24
+    states = (rng.rand(B, 2, 7, 7) < 0.2).astype(np.float32)
+    states[:, 1] *= 1 - states[:, 0]
+    pis = rng.dirichlet([0.5] * 49, size=B)                       # float64, as the buffer holds them
+    zs = rng.choice([-1.0, 0.0, 1.0], size=B)
+    buf = ReplayBuffer(1000)
+    for b in range(B):
+        buf.add(states[b], pis[b], [float(zs[b])])
+    for name, t in net.state_dict().items():
+        out["init_" + name] = t.numpy().copy()
+    order = []
+    orig_choice = np.random.choice
+
+    def rec_choice(a, size=None, replace=True, p=None):
+        r = orig_choice(a, size=size, replace=replace, p=p)
+        order.append(np.array(r))
+        return r
+    np.random.choice = rec_choice
+    np.random.seed(11)
+    with contextlib.redirect_stdout(io.StringIO()):
+        losses = ref_train.train(net, B, buf, 3, 0.00025, "cpu")
+    np.random.choice = orig_choice
+    for name, t in net.state_dict().items():
+        out["final_" + name] = t.detach().numpy().copy()
+    out["states"], out["pis"], out["zs"] = states, pis, zs
+    out["batch_order"] = np.stack(order)
+    out["losses_after_3"] = np.array(losses, np.float64)          # (loss, policy_loss, value_loss, l2) of iteration 3
+    out["cfg_json"] = np.frombuffer(json.dumps(cfg).encode(), np.uint8)
+    print("train losses", losses)
+    return out
+
+
 def main():
-    which = sys.argv[1:] or ["rules", "search", "games", "nn"]
+    which = sys.argv[1:] or ["rules", "search", "games", "nn", "train"]
     print("python", sys.version.split()[0], "numpy", np.__version__, "torch", torch.__version__,
           "cpus", os.cpu_count(), "torch threads", torch.get_num_threads())
     if "rules" in which:
@@ -470,6 +512,8 @@ def main():
         np.savez_compressed(os.path.join(HERE, "games.npz"), **gen_games())
     if "nn" in which:
         np.savez_compressed(os.path.join(HERE, "nn_small.npz"), **gen_nn_small())
+    if "train" in which:
+        np.savez_compressed(os.path.join(HERE, "train_small.npz"), **gen_train())
     assert not os.path.exists(os.path.join(REF, "logs")), "reference tree was written to!"
     assert not os.path.exists(os.path.join(REF, "__pycache__"))
 

@@ -1,0 +1,89 @@
+"""Train step against the reference's train.train on a small deterministic net
+(tests/golden/train_small.npz), and the fused-bucket gradient all-reduce over gloo (world size 2).  CPU only."""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT, load_golden
+
+Z = load_golden("train_small.npz")
+
+
+def _setup():
+    from pvnet import NetConfig
+    c = json.loads(bytes(Z["cfg_json"]).decode())
+    cfg = NetConfig(c["img_size"], c["img_size"], c["channels"], c["action_dim"], c["patch_size"], c["embed_dim"], c["num_heads"], c["depth"])
+    init = {k[5:]: torch.from_numpy(Z[k]) for k in Z.files if k.startswith("init_")}
+    final = {k[6:]: Z[k] for k in Z.files if k.startswith("final_")}
+    return cfg, init, final
+
+
+def _batches():
+    states, pis, zs = torch.from_numpy(Z["states"]), torch.from_numpy(Z["pis"]), torch.from_numpy(Z["zs"])
+    for order in Z["batch_order"]:                       # the permutations ReplayBuffer.sample drew (replay_buffer.py:16)
+        idx = torch.from_numpy(order.astype(np.int64))
+        yield states[idx], pis[idx].float(), zs[idx].float()[:, None]
+
+
+def test_three_iterations_match_reference():
+    from trainer import Trainer
+    cfg, init, final = _setup()
+    tr = Trainer(cfg, init)
+    losses = tr.train(_batches(), lr=0.00025)
+    np.testing.assert_allclose(losses, Z["losses_after_3"], rtol=2e-5)          # loss, policy, value, l2 of iteration 3
+    sd = tr.state_dict()
+    D = cfg.embed_dim
+    for k, want in final.items():
+        got = sd[k].numpy()
+        if k.endswith("attn.in_proj_bias"):
+            # the key bias shifts every score of a query by the same amount, so softmax - and the loss - do not depend on
+            # it: its true gradient is 0 and Adam turns float rounding noise into +-lr steps.  Bounded by 3 steps * lr.
+            np.testing.assert_allclose(got[D:2 * D], want[D:2 * D], rtol=0, atol=3 * 0.00025 + 1e-6, err_msg=k)
+            got, want = np.delete(got, np.s_[D:2 * D]), np.delete(want, np.s_[D:2 * D])
+        np.testing.assert_allclose(got, want, rtol=0, atol=2e-6, err_msg=k)             # three Adam steps of 2.5e-4
+    # the L2 term really includes the LayerNorm weights and excludes every bias (train.py:104-107 + module naming)
+    l2 = sum(float((v.double() ** 2).sum()) for k, v in init.items() if "bias" not in k)
+    _, _, _, l2_0 = Trainer(cfg, init).loss_terms(*next(_batches()))
+    assert abs(float(l2_0) - l2) / l2 < 1e-5
+
+
+def _worker(rank, world, port, q):
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "alpha-zero_amd"), os.path.join(ROOT, "tests")]
+    from trainer import Trainer
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg, init, _ = _setup()
+    tr = Trainer(cfg, init)
+    shard = [(s[rank::world], p[rank::world], z[rank::world]) for s, p, z in _batches()]
+    losses = tr.train(shard, lr=0.00025, dist=dist)
+    if rank == 0:
+        q.put({k: v.numpy() for k, v in tr.state_dict().items()})
+    dist.destroy_process_group()
+
+
+def test_two_rank_allreduce_equals_single_process():
+    from trainer import Trainer
+    cfg, init, _ = _setup()
+    single = Trainer(cfg, init)
+    single.train(_batches(), lr=0.00025)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    sharded = q.get(timeout=180)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    cfg_D = cfg.embed_dim
+    for k, v in single.state_dict().items():
+        a, b = sharded[k], v.numpy()
+        if k.endswith("attn.in_proj_bias"):               # key-bias slice: zero-gradient noise, see above
+            a, b = np.delete(a, np.s_[cfg_D:2 * cfg_D]), np.delete(b, np.s_[cfg_D:2 * cfg_D])
+        np.testing.assert_allclose(a, b, rtol=0, atol=5e-6, err_msg=k)                    # mean of shard means == batch mean
