@@ -25,7 +25,7 @@ SYMBOLS = [
     "azk_get_counters", "azk_reset_counters", "azk_check_device_error", "azk_gen_noise",
     "azk_rules_legal_moves", "azk_rules_legal_mask", "azk_rules_apply_move", "azk_rules_undo_move",
     "azk_rules_check_winner", "azk_rules_canonical", "azk_softmax_rows",
-    "azk_step_tree", "azk_step_gather", "azk_recycle_finished", "azk_nn_patch_embed", "azk_nn_cls_attention", "azk_nn_patch_embed_scores", "azk_nn_cls_pool", "azk_debug_stamps", "azk_emit_finished",
+    "azk_step_tree", "azk_step_gather", "azk_recycle_finished", "azk_nn_patch_embed", "azk_nn_cls_attention", "azk_nn_patch_embed_scores", "azk_nn_cls_pool", "azk_debug_stamps", "azk_emit_finished", "azk_clear_cache",
 ]
 
 
@@ -96,6 +96,7 @@ def lib():
     L.azk_get_positions.argtypes = [vp, vp, vp, vp, vp]
     L.azk_get_counters.argtypes = [vp, C.POINTER(Counters), vp]
     L.azk_reset_counters.argtypes = [vp, vp]
+    L.azk_clear_cache.argtypes = [vp, vp]
     L.azk_emit_finished.argtypes = [vp, vp, vp, vp, i64, vp, vp, vp]
     L.azk_debug_stamps.argtypes = [vp, vp]
     L.azk_check_device_error.argtypes = [vp, vp]
@@ -318,6 +319,10 @@ class Engine:
 
     def reset_counters(self):
         self._chk(self.L.azk_reset_counters(self.h, _stream()))
+
+    def clear_cache(self):
+        """MCTS.cache.clear() - call when the evaluator's weights change."""
+        self._chk(self.L.azk_clear_cache(self.h, _stream()))
 
     def check_error(self):
         rc = self.L.azk_check_device_error(self.h, _stream())

@@ -1019,6 +1019,14 @@ int32_t azk_emit_finished(azk_engine *e, float *states_dev, double *pis_dev, flo
     return AZK_OK;
 }
 
+int32_t azk_clear_cache(azk_engine *e, void *stream) {
+    if (!e) return AZK_ERR_ARG;
+    const Dev &d = e->d;
+    if (!d.cache_entries) return AZK_OK;
+    HIPCHK(e, hipMemsetAsync(d.cache_key, 0xff, sizeof(unsigned long long) * (size_t)d.G * d.cache_entries * d.key_words, (hipStream_t)stream));
+    return AZK_OK;
+}
+
 int32_t azk_recycle_finished(azk_engine *e, int64_t *stats_dev, void *stream) {
     if (!e || !stats_dev) return AZK_ERR_ARG;
     k_recycle<<<(unsigned)((e->d.G + 255) / 256), 256, 0, (hipStream_t)stream>>>(e->d, (long long *)stats_dev);

@@ -134,6 +134,9 @@ int32_t azk_recycle_finished(azk_engine *e, int64_t *stats_dev, void *stream);
 int32_t azk_emit_finished(azk_engine *e, float *states_dev, double *pis_dev, float *zs_dev, int64_t capacity,
                           int64_t *cursor_dev, int32_t *game_base_dev, void *stream);
 
+/* MCTS.cache.clear() (main.py:55-57): must be called whenever the evaluator's weights change. */
+int32_t azk_clear_cache(azk_engine *e, void *stream);
+
 /* Root statistics after a search, for all G games (device outputs, any may be NULL):
  *   pi_dev float64 [G][A]   utils.get_probablity_distribution_of_children (utils.py:46-55)
  *   q_dev  float64 [G]      root.value / root.visit (gomoku.py:140)

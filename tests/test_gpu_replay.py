@@ -58,3 +58,21 @@ def test_rectangular_board_is_rejected():
     replay = azk.DeviceReplay(16, 3, 6, 7, 7)
     with pytest.raises(azk.AzkError):
         eng.emit_finished(replay)
+
+
+def test_collect_train_promote_loop():
+    """main.start_train_loop's shape end to end on one GPU: games -> device replay ring -> reference loss / Adam ->
+    new weights promoted, eval cache cleared, next collection runs with the new net."""
+    from pvnet import NetConfig, init_weights
+    from train_loop import train_loop
+    cfg = NetConfig(7, 7, 2, 49, patch_size=5, embed_dim=128, num_heads=4, depth=1)
+    w0 = init_weights(cfg, 0)
+    logs = []
+    w1, hist = train_loop("gomoku", cfg, w0, iterations=2, games_per_iteration=16, n_sims=32, batch_size=64, size=7,
+                          buffer_size=5000, cache_entries=512, log=logs.append)
+    assert len(hist) == 2 and hist[1]["games"] >= 32 and hist[1]["buffer"] > hist[0]["buffer"] > 64
+    assert all(np.isfinite(h["losses"]).all() for h in hist)
+    changed = sum(float((w1[k] - w0[k]).abs().max()) > 0 for k in w0)
+    assert changed >= len(w0) - 1
+    # policy loss starts near log(49) for a random net and the L2 term is the dominant, slowly shrinking part
+    assert 2.0 < hist[0]["losses"][1] < 6.0
