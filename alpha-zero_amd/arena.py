@@ -1,0 +1,55 @@
+"""Arena on the batched engine: test.compete / test.compare (test.py:60-140).
+
+compete: two agents alternate by side to move (model1 plays player 0); every move is a fresh-root search with the
+mover's model and iteration count (Dirichlet noise on, as Game.mcts's default); the move is sampled from the visit
+distribution while move_count < 20 when `sampling`, else the first most-visited child; returns the winner.
+compare: `iterations` games, the best model plays first in the first half and second in the second half; draws score
+0.5 each; optional early stopping at 55 %.  All games of a half run as one lock-step batch; the early-stopping rule
+is then applied to the outcomes in game order, which yields exactly what the sequential loop would return.
+"""
+import numpy as np
+
+from selfplay import self_play_batch
+
+
+def compete_batch(game, model1, model2, n_games, model1_mcts_iter=50, model2_mcts_iter=50, sampling=False, size=None,
+                  seed=0, first_global_game=0, device=0, leaf_dtype="float32", noise_fn=None, uniform_fn=None):
+    """n_games independent test.compete games at once -> (winners int array in {0, 1, -1}, final boards)."""
+    res = self_play_batch(game, (model1, model2), n_games, (model1_mcts_iter, model2_mcts_iter), size=size, seed=seed,
+                          first_global_game=first_global_game, device=device, leaf_dtype=leaf_dtype,
+                          noise_fn=noise_fn, uniform_fn=uniform_fn, sample_until=20 if sampling else 0)
+    winners = np.array([r.winner for r in res], np.int64)
+    return winners, res
+
+
+def score_like_reference(winners_first_half, winners_second_half, iterations, early_stopping):
+    """test.compare's bookkeeping (test.py:107-140) over outcomes given in game order.
+    Returns 1 / 0 on an early stop (accepted / rejected) else the contender's win rate."""
+    win_count = [0, 0, 0]                                      # best model's, contender's, draws
+    outcomes = list(winners_first_half) + list(winners_second_half)
+    for i, winner in enumerate(outcomes):
+        first = i < iterations // 2
+        if winner == 0:
+            win_count[0 if first else 1] += 1
+        elif winner == 1:
+            win_count[1 if first else 0] += 1
+        else:
+            win_count[0] += 0.5
+            win_count[1] += 0.5
+            win_count[2] += 1
+        if early_stopping:
+            if win_count[1] >= int(iterations * 0.55):
+                return 1
+            if win_count[1] + (iterations - (i + 1)) < int(iterations * 0.55):
+                return 0
+    return win_count[1] / iterations
+
+
+def compare(game, best_model, contender_model, best_model_mcts_iter, contender_model_mcts_iter, iterations, sampling,
+            early_stopping, size=None, seed=0, device=0, leaf_dtype="float32"):
+    half = iterations // 2
+    w1, _ = compete_batch(game, best_model, contender_model, half, best_model_mcts_iter, contender_model_mcts_iter,
+                          sampling, size, seed, 0, device, leaf_dtype) if half else (np.zeros(0, np.int64), None)
+    w2, _ = compete_batch(game, contender_model, best_model, iterations - half, contender_model_mcts_iter,
+                          best_model_mcts_iter, sampling, size, seed, half, device, leaf_dtype)
+    return score_like_reference(w1, w2, iterations, early_stopping)

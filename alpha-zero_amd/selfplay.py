@@ -51,7 +51,8 @@ def self_play_batch(game, evaluator, n_games, n_sims, size=None, seed=0, first_g
     (that is how parity tests inject the reference's recorded np.random draws).
     """
     import torch
-    eng = engine or Engine(game, n_games, n_sims, size=size, device=device, leaf_dtype=leaf_dtype, cache_entries=cache_entries)
+    max_sims = max(n_sims) if isinstance(n_sims, (tuple, list)) else n_sims
+    eng = engine or Engine(game, n_games, max_sims, size=size, device=device, leaf_dtype=leaf_dtype, cache_entries=cache_entries)
     assert eng.G == n_games
     G, A = eng.G, eng.action_dim
     eng.reset_games()
@@ -68,7 +69,10 @@ def self_play_batch(game, evaluator, n_games, n_sims, size=None, seed=0, first_g
             noise, uni = eng.gen_noise(seed, first_global_game, move, alpha, want_noise=dirichlet)
         if uniform_fn is not None:
             uni = torch.from_numpy(np.ascontiguousarray(uniform_fn(move), np.float64)).to(eng.device)
-        eng.search(evaluator, n_sims, noise if dirichlet else None)
+        # an (evaluator0, evaluator1) pair plays the two sides (test.compete, test.py:79-84); all games are at the same ply
+        ev = evaluator[move & 1] if isinstance(evaluator, (tuple, list)) else evaluator
+        ns = n_sims[move & 1] if isinstance(n_sims, (tuple, list)) else n_sims
+        eng.search(ev, ns, noise if dirichlet else None)
         pi, q, _ = eng.root_stats()
         cells_before, to_move, _ = eng.get_positions()
         chosen, winner, done = eng.advance(uni, su)

@@ -277,7 +277,7 @@ def mcts(game, tree, board, n_iter, evaluator=None, noise=None, cache=None, rand
 
 
 def self_play(game, evaluator, n_sims, noise_fn=None, uniform_fn=None, cache=None, randint=None,
-              counters=None, max_moves=None, time_budget=None):
+              counters=None, max_moves=None, time_budget=None, evaluator2=None, n_sims2=None, sample_until=None):
     """<Game>.self_play.  noise_fn(move_idx)->f64[A] supplies np.random.dirichlet's draw,
     uniform_fn(move_idx)->float the uniform consumed by np.random.choice.  Returns a dict with
     boards (raw, not canonical), cells played, pis, qs, winner."""
@@ -291,13 +291,17 @@ def self_play(game, evaluator, n_sims, noise_fn=None, uniform_fn=None, cache=Non
     while True:
         tree.reset(player, mc)
         noise = noise_fn(mc) if (evaluator is not None and noise_fn is not None) else None
-        mcts(game, tree, board, n_sims, evaluator, noise, cache, randint, counters)
+        ev_now = evaluator2 if (evaluator2 is not None and (mc & 1)) else evaluator       # test.compete: model1 / model2 by side
+        n_now = n_sims2 if (n_sims2 is not None and (mc & 1)) else n_sims
+        mcts(game, tree, board, n_now, ev_now, noise, cache, randint, counters)
         pi = tree.pi()
         pis.append(pi)
         boards.append(board.copy())
         qs.append(tree.root_value / tree.root_visit)
         if evaluator is not None:
             sample = (mc < 8) if game.name == "gomoku" else True        # gomoku.py:144 vs tictactoe.py:117
+            if sample_until is not None:
+                sample = mc < sample_until                              # test.compete: move_count < 20 when sampling
         else:
             sample = False
         if sample:
