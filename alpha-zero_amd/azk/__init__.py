@@ -439,7 +439,8 @@ def nn_cls_attention(xhat, m, c, num_heads):
     return z
 
 
-def nn_embed_scores_pool(boards, wt, cpos, ln_w, ln_b, m, c, rows, cols, ksize, embed_dim, num_heads, eps=1e-5, count=None):
+def nn_embed_scores_pool(boards, wt, cpos, ln_w, ln_b, m, c, rows, cols, ksize, embed_dim, num_heads, eps=1e-5, count=None,
+                         timers=None):
     """Depth-1 folded cls attention in two launches: azk_nn_patch_embed_scores (xhat + per-token head scores) then
     azk_nn_cls_pool (softmax + weighted token sum).  Returns z bf16 [n, H, D]."""
     torch = _torch()
@@ -452,12 +453,19 @@ def nn_embed_scores_pool(boards, wt, cpos, ln_w, ln_b, m, c, rows, cols, ksize, 
     # with a device-side count the rows past it are never written; every later op is row-wise, so they cannot leak
     z = torch.empty((n, num_heads, embed_dim), dtype=torch.bfloat16, device=boards.device)
     L = lib()
+    if timers is not None:
+        timers[0].start()
     rc = L.azk_nn_patch_embed_scores(_p(boards), 1 if boards.dtype == torch.float32 else 0, _p(wt), _p(cpos), _p(ln_w), _p(ln_b),
                                      _p(xh), _p(m), _p(sc), num_heads, n, C, rows, cols, ksize, wt.shape[1], embed_dim,
                                      float(eps), _p(count), _stream())
+    if timers is not None:
+        timers[0].stop()
+        timers[1].start()
     if rc != 0:
         raise AzkError(f"azk_nn_patch_embed_scores failed ({rc})")
     rc = L.azk_nn_cls_pool(_p(xh), _p(sc), _p(c), _p(z), n, T, embed_dim, num_heads, _p(count), _stream())
+    if timers is not None:
+        timers[1].stop()
     if rc != 0:
         raise AzkError(f"azk_nn_cls_pool failed ({rc})")
     return z

@@ -116,6 +116,7 @@ class PolicyValueNet:
         self.path = path
         self.fast_outputs = False   # True: logits may come back as a bf16 view (the caller converts while copying)
         self.last_value_pre_tanh = False
+        self.kernel_timers = None   # optional (embed_timer, pool_timer) with start()/stop(): HIP-event timing of the two kernels
         self.live_count = None      # optional int32 CUDA tensor: number of valid rows at the head of the batch (graph stepping)
         self.to(device, dtype)
 
@@ -359,7 +360,7 @@ class PolicyValueNet:
                         x = x.float()
                     z = azk.nn_embed_scores_pool(x.contiguous(), hp["wt"], hp["cpos"], hp["ln_w"], hp["ln_b"], f["m_n"], f["c_n"],
                                                  self.cfg.rows, self.cfg.cols, self.cfg.patch_size, self.cfg.embed_dim,
-                                                 self.cfg.num_heads, count=self.live_count)
+                                                 self.cfg.num_heads, count=self.live_count, timers=self.kernel_timers)
                     return self.tail_fast(z)
                 _, xhat = self.embed_hip(x, want_x=False, want_xhat=True)
             else:

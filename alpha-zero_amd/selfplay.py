@@ -235,6 +235,8 @@ class SelfPlayRunner:
         if hasattr(self.evaluator, "live_count"):
             self.evaluator.live_count = e.n_leaf
             self.evaluator.fast_outputs = True
+        if hasattr(self.evaluator, "kernel_timers"):
+            self.evaluator.kernel_timers = (timer.child("k_embed"), timer.child("k_cls_pool")) if timer is not None else None
         logits, values = self.evaluator(e.leaf_boards)
         h.logits_buf.copy_(logits)
         h.values_buf.copy_(values.reshape(-1))
@@ -332,6 +334,12 @@ class KernelTimer:
         self.torch, self.stride, self.max = torch, stride, max_samples
         self.pairs = []
         self.enabled = False
+        self.children = {}                       # named sub-timers sharing this timer's sampling decisions
+
+    def child(self, name):
+        if name not in self.children:
+            self.children[name] = KernelTimer(self.stride, self.max)
+        return self.children[name]
 
     def want(self, step):
         return self.enabled and step % self.stride == 0 and len(self.pairs) < self.max

@@ -170,6 +170,23 @@ def main():
                     "frac": gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "avg_launch_us": tree_ms * 1e3,
                     "algorithmic_bytes_per_launch": alg_bytes, "event_samples": len(kt.pairs)}
         from pvnet import flops_clsfold
+        # per-kernel rooflines (HBM-bound streaming kernels): algorithmic bytes per launch / HIP-event duration
+        live = leaves_all / max(1.0, launches * world / runner.n_split)       # boards the network kernels really process per launch
+        T_tok, Dm = cfg.tokens, cfg.embed_dim
+        kernels = []
+        if roof:
+            kernels.append(dict(roof))
+        for name, per_board in (("k_embed", T_tok * Dm * 2 + cfg.num_heads * 4 * ((T_tok + 15) // 16 * 16) + 2 * cfg.rows * cfg.cols * 2),
+                                ("k_cls_pool", T_tok * Dm * 2 + cfg.num_heads * Dm * 2 + cfg.num_heads * 4 * ((T_tok + 15) // 16 * 16))):
+            ch = kt.children.get(name)
+            ms = ch.mean_ms() if ch else None
+            if ms:
+                by = per_board * live
+                kernels.append({"kernel": name, "bound": "hbm", "achieved": by / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_launch_us": ms * 1e3, "algorithmic_bytes_per_launch": by,
+                                "traffic": None, "event_samples": len(ch.pairs),
+                                "note": f"{per_board} B per live board x {live:.0f} live boards per launch (device-side count)"})
+        dominant = max(kernels, key=lambda k: k["avg_launch_us"]) if kernels else None
         flops = {"cls": cfg.flops_cls(), "full": cfg.flops_full(), "clsfold": flops_clsfold(cfg)}[args.nn_path]
         evals = leaves_all if args.no_graph else sims_all      # graph mode evaluates the full fixed-size leaf buffer every step
         out = {
@@ -187,7 +204,7 @@ def main():
             "stepping": "eager+sync" if args.no_graph else f"hipGraph replay, {runner.n_split} game group(s) on separate streams (tree+gather+net per simulation, no host sync)",
             "value_definition": value_src, "games_per_sec_renewal_estimate": est_games_per_s,
             "mean_plies_per_game": mean_plies, "game_length_source": src, "games_finished_in_window": fin_window,
-            "plies_in_window": plies_all, "counters_rank0": c, "roofline": roof,
+            "plies_in_window": plies_all, "counters_rank0": c, "roofline": dominant, "roofline_puct": roof, "kernel_rooflines": kernels,
         }
         if args.cpu_seconds > 0 and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.sims, args.cpu_seconds, mean_plies)
