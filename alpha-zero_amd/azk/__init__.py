@@ -112,7 +112,7 @@ def lib():
     L.azk_step_tree.argtypes = [vp, vp, vp, vp]
     L.azk_step_gather.argtypes = [vp, vp, vp, vp]
     L.azk_recycle_finished.argtypes = [vp, vp, vp]
-    L.azk_nn_patch_embed_scores.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, C.c_float, vp, vp]
+    L.azk_nn_patch_embed_scores.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, C.c_float, vp, vp]
     L.azk_nn_cls_pool.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]
     L.azk_nn_cls_attention.argtypes = [vp, vp, vp, i32, vp, i32, i32, i32, i32, vp]
     L.azk_nn_patch_embed.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, C.c_float, vp]
@@ -439,10 +439,11 @@ def nn_cls_attention(xhat, m, c, num_heads):
     return z
 
 
-def nn_embed_scores_pool(boards, wt, cpos, ln_w, ln_b, m, c, rows, cols, ksize, embed_dim, num_heads, eps=1e-5, count=None,
-                         timers=None):
-    """Depth-1 folded cls attention in two launches: azk_nn_patch_embed_scores (xhat + per-token head scores) then
-    azk_nn_cls_pool (softmax + weighted token sum).  Returns z bf16 [n, H, D]."""
+def nn_embed_scores_pool(boards, wt_ext, cpos, score_cpos, score_msum, c, rows, cols, ksize, embed_dim, num_heads, eps=1e-5,
+                         count=None, timers=None):
+    """Depth-1 folded cls attention in two launches: azk_nn_patch_embed_scores (normalised tokens + per-token head scores,
+    the scores as 16 extra MFMA output columns: wt_ext [D+16, kp]) then azk_nn_cls_pool (softmax + weighted token sum).
+    Returns z bf16 [n, H, D]."""
     torch = _torch()
     assert boards.is_cuda and boards.is_contiguous() and boards.dtype in (torch.bfloat16, torch.float32)
     n, C = boards.shape[0], boards.shape[1]
@@ -455,9 +456,9 @@ def nn_embed_scores_pool(boards, wt, cpos, ln_w, ln_b, m, c, rows, cols, ksize, 
     L = lib()
     if timers is not None:
         timers[0].start()
-    rc = L.azk_nn_patch_embed_scores(_p(boards), 1 if boards.dtype == torch.float32 else 0, _p(wt), _p(cpos), _p(ln_w), _p(ln_b),
-                                     _p(xh), _p(m), _p(sc), num_heads, n, C, rows, cols, ksize, wt.shape[1], embed_dim,
-                                     float(eps), _p(count), _stream())
+    rc = L.azk_nn_patch_embed_scores(_p(boards), 1 if boards.dtype == torch.float32 else 0, _p(wt_ext), _p(cpos), None, None,
+                                     _p(xh), _p(score_cpos), _p(score_msum), _p(sc), num_heads, n, C, rows, cols, ksize,
+                                     wt_ext.shape[1], embed_dim, float(eps), _p(count), _stream())
     if timers is not None:
         timers[0].stop()
         timers[1].start()

@@ -33,8 +33,9 @@ struct EmbedArgs {
     const float *ln_w, *ln_b;  // [D] LayerNorm affine (used when xhat != nullptr)
     __hip_bfloat16 *x;         // [n][T][D] tokens (may be null)
     __hip_bfloat16 *xhat;      // [n][T][D] LayerNorm(tokens) (may be null)
-    const float *mtab;         // [NH][D] folded score vectors (scale * Wk_h^T q_h), or null
-    float *scores;             // [n][NH][Tp] (Tp = 16*ceil(T/16)) xhat_t . m_h, written when mtab != null
+    const float *mtab;         // scores variant: [T][16] per-token additive term of the 16 folded score columns (m'_h . cpos[t]), or null
+    const float *msum;         // scores variant: [16] sum_d m'_h[d]
+    float *scores;             // [n][NH][Tp] (Tp = 16*ceil(T/16)) xn_t . m'_h, written when mtab != null
     int nh;
     const int *count;          // optional device-side number of valid boards (<= n): rows beyond it are skipped
     int n, C, R, Cc, ksz, T;
@@ -68,11 +69,11 @@ __device__ __forceinline__ uint4 pack8(const float *v) {
 template <int NG, int KS, bool WANT_X, bool WANT_XHAT, int NH>
 __global__ __launch_bounds__(256, 2) void k_embed(EmbedArgs a) {
     constexpr int D = 128 * NG, KP = 32 * KS, NACC = 8 * NG;
+    constexpr int NTILE = NACC + (NH > 0 ? 1 : 0);     // NH > 0: one extra 16-column tile = the folded head-score columns
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint4 *bimg = (uint4 *)smem;                       // [NACC][KS][64 lanes] 16-byte B fragments
-    float *lnw = (float *)(smem + NACC * KS * 64 * 16);  // [D] LayerNorm weight, then [D] bias
+    uint4 *bimg = (uint4 *)smem;                       // [NTILE][KS][64 lanes] 16-byte B fragments
+    float *lnw = (float *)(smem + NTILE * KS * 64 * 16);  // [D] LayerNorm weight, then [D] bias (affine variant only)
     float *lnb = lnw + D;
-    float *mt = lnw;                                   // NH > 0: [NH][D] folded score vectors replace the affine tables
     constexpr bool AFFINE = WANT_XHAT && NH == 0;      // NH > 0 emits the plain normalised tokens (affine folded by the caller)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -86,15 +87,13 @@ __global__ __launch_bounds__(256, 2) void k_embed(EmbedArgs a) {
     if ((int)blockIdx.x * 4 >= nitems) return;                  // nothing for this workgroup: skip the weight staging too
 
     // ---- stage the weight in fragment order: fragment (acc, s) of lane l = wt[col(acc, l)][32 s + 8 (l>>4) .. +8] ----
-    for (int f = tid; f < NACC * KS * 64; f += 256) {
+    for (int f = tid; f < NTILE * KS * 64; f += 256) {
         const int l = f & 63, s = (f >> 6) % KS, acc = (f >> 6) / KS;
-        const int col = 128 * (acc >> 3) + 8 * (l & 15) + (acc & 7);
+        const int col = acc < NACC ? 128 * (acc >> 3) + 8 * (l & 15) + (acc & 7) : D + (l & 15);   // weight rows D..D+15: score columns
         bimg[f] = *(const uint4 *)(a.wt + (size_t)col * KP + 32 * s + 8 * (l >> 4));
     }
     if (AFFINE)
         for (int i = tid; i < D; i += 256) { lnw[i] = a.ln_w[i]; lnb[i] = a.ln_b[i]; }
-    if (NH > 0)
-        for (int i = tid; i < NH * D; i += 256) mt[i] = a.mtab[i];
     __syncthreads();
 
     const int RC = a.R * a.Cc, T = a.T, ksz = a.ksz, kk = ksz * ksz, pad = ksz / 2, ncell = a.C * RC;
@@ -167,6 +166,17 @@ __global__ __launch_bounds__(256, 2) void k_embed(EmbedArgs a) {
                 acc[g * 8 + 0][r4] = c0[0]; acc[g * 8 + 1][r4] = c0[1]; acc[g * 8 + 2][r4] = c0[2]; acc[g * 8 + 3][r4] = c0[3];
                 acc[g * 8 + 4][r4] = c1[0]; acc[g * 8 + 5][r4] = c1[1]; acc[g * 8 + 6][r4] = c1[2]; acc[g * 8 + 7][r4] = c1[3];
             }
+        f32x4 acce;                                                   // NH > 0: raw scores x_t . m'_h for head = lane&15, tokens 4 (lane>>4) + r
+        if (NH > 0) {
+#pragma unroll
+            for (int r4 = 0; r4 < 4; r4++) acce[r4] = a.mtab[(size_t)trow[r4] * 16 + l15];
+#pragma unroll
+            for (int s = 0; s < KS; s++) {
+                union { uint4 u; bf16x8 v; } bf;
+                bf.u = bimg[(NACC * KS + s) * 64 + lane];
+                acce = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[s], bf.v, acce, 0, 0, 0);
+            }
+        }
         // ---- MFMA: acc[n] (16 x 16) += A (16 x KP) * B (KP x 16) ----
         if (!(a.ablate & 4))
 #pragma unroll
@@ -224,47 +234,16 @@ __global__ __launch_bounds__(256, 2) void k_embed(EmbedArgs a) {
                         for (int q = 0; q < 8; q++) v[q] = (v[q] - mean[r4]) * rstd[r4];
                     }
                     if (ok) *(uint4 *)(a.xhat + orow + 128 * g + 8 * l15) = pack8(v);
-                    if (NH > 0) {
-#pragma unroll
-                        for (int q = 0; q < 8; q++) acc[g * 8 + q][r4] = v[q];      // keep xhat in place for the scores
-                    }
                 }
             }
         }
-        float sc[NH > 0 ? NH : 1][4];
-        if (NH > 0) {
-#pragma unroll
-            for (int h = 0; h < NH; h++) {
-#pragma unroll
-                for (int r4 = 0; r4 < 4; r4++) sc[h][r4] = 0.f;
-#pragma unroll
-                for (int g = 0; g < NG; g++) {
-                    const f32x4 m0 = *(const f32x4 *)(mt + h * D + 128 * g + 8 * l15), m1 = *(const f32x4 *)(mt + h * D + 128 * g + 8 * l15 + 4);
-#pragma unroll
-                    for (int r4 = 0; r4 < 4; r4++) {
-                        float p = sc[h][r4];
-#pragma unroll
-                        for (int q = 0; q < 4; q++) { p += acc[g * 8 + q][r4] * m0[q]; p += acc[g * 8 + q + 4][r4] * m1[q]; }
-                        sc[h][r4] = p;
-                    }
-                }
-            }
-        }
-        if (NH > 0) {
-            // reduce over the 16 lanes that share these 4 tokens, then lane (l15) stores scores (h = l15 >> 1, r4 = 2 (l15 & 1) + {0,1})
+        if (NH > 0 && l15 < NH) {
+            // xn = (x - mean) * rstd  =>  xn . m' = rstd * (x . m' - mean * sum(m'))
             const int Tp = tiles_per_leaf * 16;
+            const float ms = a.msum[l15];
 #pragma unroll
-            for (int h = 0; h < NH; h++)
-#pragma unroll
-                for (int r4 = 0; r4 < 4; r4++) {
-                    sc[h][r4] = row16_sum(sc[h][r4]);
-                }
-#pragma unroll
-            for (int h = 0; h < NH; h++)
-#pragma unroll
-                for (int r4 = 0; r4 < 4; r4++)
-                    if (l15 == h * 2 + (r4 >> 1) && NH * 2 <= 16)
-                        a.scores[((size_t)leaf * NH + h) * Tp + tile * 16 + 4 * l4 + r4] = sc[h][r4];
+            for (int r4 = 0; r4 < 4; r4++)
+                a.scores[((size_t)leaf * NH + l15) * Tp + tile * 16 + 4 * l4 + r4] = rstd[r4] * (acce[r4] - mean[r4] * ms);
         }
       }
     }
@@ -273,7 +252,7 @@ __global__ __launch_bounds__(256, 2) void k_embed(EmbedArgs a) {
 template <int NG, int KS, bool WX, bool WH, int NH>
 int launch_embed2(const EmbedArgs &a, hipStream_t st) {
     constexpr int NACC = 8 * NG;
-    const int lds = NACC * KS * 64 * 16 + (NH > 0 ? NH : 2) * 128 * NG * 4;
+    const int lds = (NACC + (NH > 0 ? 1 : 0)) * KS * 64 * 16 + (NH > 0 ? 0 : 2 * 128 * NG * 4);
     const int tiles = (a.T + 15) >> 4, groups = tiles >= 6 ? 3 : 1;
     long long blocks = ((long long)a.n * groups + 3) / 4;       // one wavefront per (board, tile group); idle workgroups exit at once
     if (blocks > 4096) blocks = 4096;
@@ -305,10 +284,10 @@ static int32_t patch_embed_impl(const void *boards_dev, int32_t boards_are_f32, 
                                 const float *cpos_dev, const float *ln_w_dev, const float *ln_b_dev,
                                 void *x_out_bf16_dev, void *xhat_out_bf16_dev, int32_t n, int32_t channels,
                                 int32_t rows, int32_t cols, int32_t ksize, int32_t kp, int32_t embed_dim,
-                                float ln_eps, const float *mtab_dev, float *scores_dev, int32_t num_heads,
+                                float ln_eps, const float *mtab_dev, const float *msum_dev, float *scores_dev, int32_t num_heads,
                                 const int32_t *n_valid_dev, void *stream) {
     if (!boards_dev || !wt_bf16_dev || !cpos_dev || (!x_out_bf16_dev && !xhat_out_bf16_dev)) return AZK_ERR_ARG;
-    if (xhat_out_bf16_dev && (!ln_w_dev || !ln_b_dev)) return AZK_ERR_ARG;
+    if (xhat_out_bf16_dev && !mtab_dev && (!ln_w_dev || !ln_b_dev)) return AZK_ERR_ARG;   // the scores variant has no affine
     if (n < 0 || channels < 1 || rows < 1 || cols < 1 || ksize < 1 || (ksize & 1) == 0 || ksize > 7) return AZK_ERR_ARG;
     if (kp < channels * ksize * ksize || kp % 32 != 0 || kp > 128) return AZK_ERR_ARG;
     if (channels * rows * cols > 62 * 32) return AZK_ERR_ARG;         // the board bit string lives in one wave's lanes
@@ -316,7 +295,7 @@ static int32_t patch_embed_impl(const void *boards_dev, int32_t boards_are_f32, 
     EmbedArgs a;
     a.boards = boards_dev; a.boards_f32 = boards_are_f32; a.wt = (const __hip_bfloat16 *)wt_bf16_dev; a.cpos = cpos_dev;
     a.ln_w = ln_w_dev; a.ln_b = ln_b_dev; a.x = (__hip_bfloat16 *)x_out_bf16_dev; a.xhat = (__hip_bfloat16 *)xhat_out_bf16_dev;
-    a.mtab = mtab_dev; a.scores = scores_dev; a.nh = num_heads; a.count = n_valid_dev;
+    a.mtab = mtab_dev; a.msum = msum_dev; a.scores = scores_dev; a.nh = num_heads; a.count = n_valid_dev;
     if ((mtab_dev != nullptr) != (scores_dev != nullptr)) return AZK_ERR_ARG;
     { const char *ab = getenv("AZK_EMBED_ABLATE"); a.ablate = ab ? atoi(ab) : 0; }
     a.n = n; a.C = channels; a.R = rows; a.Cc = cols; a.ksz = ksize; a.T = rows * cols + 1; a.eps = ln_eps;
@@ -336,19 +315,19 @@ extern "C" int32_t azk_nn_patch_embed(const void *boards_dev, int32_t boards_are
                                       int32_t rows, int32_t cols, int32_t ksize, int32_t kp, int32_t embed_dim,
                                       float ln_eps, void *stream) {
     return patch_embed_impl(boards_dev, boards_are_f32, wt_bf16_dev, cpos_dev, ln_w_dev, ln_b_dev, x_out_bf16_dev,
-                            xhat_out_bf16_dev, n, channels, rows, cols, ksize, kp, embed_dim, ln_eps, nullptr, nullptr, 0, nullptr, stream);
+                            xhat_out_bf16_dev, n, channels, rows, cols, ksize, kp, embed_dim, ln_eps, nullptr, nullptr, nullptr, 0, nullptr, stream);
 }
 
 extern "C" int32_t azk_nn_patch_embed_scores(const void *boards_dev, int32_t boards_are_f32, const void *wt_bf16_dev,
                                              const float *cpos_dev, const float *ln_w_dev, const float *ln_b_dev,
-                                             void *xhat_out_bf16_dev, const float *m_dev, float *scores_out_dev,
-                                             int32_t num_heads, int32_t n, int32_t channels, int32_t rows, int32_t cols,
+                                             void *xhat_out_bf16_dev, const float *score_cpos_dev, const float *score_msum_dev,
+                                             float *scores_out_dev, int32_t num_heads, int32_t n, int32_t channels, int32_t rows, int32_t cols,
                                              int32_t ksize, int32_t kp, int32_t embed_dim, float ln_eps,
                                              const int32_t *n_valid_dev, void *stream) {
-    if (!m_dev || !scores_out_dev) return AZK_ERR_ARG;
+    if (!score_cpos_dev || !score_msum_dev || !scores_out_dev) return AZK_ERR_ARG;
     return patch_embed_impl(boards_dev, boards_are_f32, wt_bf16_dev, cpos_dev, ln_w_dev, ln_b_dev, nullptr,
-                            xhat_out_bf16_dev, n, channels, rows, cols, ksize, kp, embed_dim, ln_eps, m_dev, scores_out_dev,
-                            num_heads, n_valid_dev, stream);
+                            xhat_out_bf16_dev, n, channels, rows, cols, ksize, kp, embed_dim, ln_eps, score_cpos_dev, score_msum_dev,
+                            scores_out_dev, num_heads, n_valid_dev, stream);
 }
 
 // =====================================================================================================

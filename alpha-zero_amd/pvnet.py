@@ -171,6 +171,20 @@ class PolicyValueNet:
             g, bta = self._hip["ln_w"], self._hip["ln_b"]
             f["m_n"] = (f["m"] * g).contiguous()
             f["c_n"] = (f["c"] + f["m"] @ bta).contiguous()
+            # the scores ride on the conv GEMM as 16 extra output columns: x . m' = (m'^T Wconv) . patch + m' . cpos
+            hp = self._hip
+            kreal = cfg.channels * cfg.patch_size ** 2
+            Wc = m["embedding.patch_embed.patch_embed.weight"].reshape(D, kreal).to(dev)
+            wt_ext = torch.zeros(D + 16, hp["wt"].shape[1], device=dev)
+            wt_ext[:D] = hp["wt"].float()
+            wt_ext[D:D + H, :kreal] = f["m_n"] @ Wc
+            f["wt_ext"] = wt_ext.to(torch.bfloat16).contiguous()
+            sc = torch.zeros(cfg.tokens, 16, device=dev)
+            sc[:, :H] = hp["cpos"] @ f["m_n"].t()
+            f["score_cpos"] = sc.contiguous()
+            ms = torch.zeros(16, device=dev)
+            ms[:H] = f["m_n"].sum(1)
+            f["score_msum"] = ms
             Wv = Wi[2 * D:].reshape(H, dh, D).to(dev)
             f["WvT_n"] = (Wv * g).transpose(1, 2).contiguous().to(torch.bfloat16)                      # [H, D, dh]
             f["bv_n"] = (bi[2 * D:].to(dev) + (Wv @ bta).reshape(-1)).to(torch.bfloat16)
@@ -358,7 +372,7 @@ class PolicyValueNet:
                 if self.cfg.num_heads in (4, 8):
                     if x.dtype not in (torch.bfloat16, torch.float32):
                         x = x.float()
-                    z = azk.nn_embed_scores_pool(x.contiguous(), hp["wt"], hp["cpos"], hp["ln_w"], hp["ln_b"], f["m_n"], f["c_n"],
+                    z = azk.nn_embed_scores_pool(x.contiguous(), f["wt_ext"], hp["cpos"], f["score_cpos"], f["score_msum"], f["c_n"],
                                                  self.cfg.rows, self.cfg.cols, self.cfg.patch_size, self.cfg.embed_dim,
                                                  self.cfg.num_heads, count=self.live_count, timers=self.kernel_timers)
                     return self.tail_fast(z)

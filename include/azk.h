@@ -232,8 +232,11 @@ int32_t azk_nn_cls_attention(const void *xhat_bf16_dev, const float *m_dev, cons
 
 /* Depth-1 fast path of the folded cls attention (the cls query is a constant of the weights, so m is shared):
  *   azk_nn_patch_embed_scores - writes xn = (tokens - mean) * rstd (LayerNorm WITHOUT the affine; the caller folds gamma/beta
- *       into m, c and the value projection; ln_w/ln_b are ignored) and, from the tile it holds in registers,
- *       scores_out[b][h][t] = xn[b][t][:] . m[h][:]  (float32 [n][H][Tp], Tp = 16*ceil(T/16))
+ *       into m', c and the value projection; ln_w/ln_b are ignored) and scores_out[b][h][t] = xn[b][t][:] . m'[h][:]
+ *       (float32 [n][H][Tp], Tp = 16*ceil(T/16)).  The scores ride on the matrix cores: wt_bf16_dev has 16 extra rows
+ *       [D .. D+16) holding m'_h^T Wconv (heads >= H zero), so x . m' comes out of the same MFMA chain as 16 extra output
+ *       columns; score_cpos_dev float32 [T][16] = m'_h . cpos[t] is their additive term, score_msum_dev float32 [16] =
+ *       sum_d m'_h[d], and xn . m' = rstd * (x . m' - mean * sum(m')).
  *   azk_nn_cls_pool - a = softmax_t(scores + c[h]);  z[b][h][:] = sum_t a[h][t] * xhat[b][t][:]  ([n][H][D] bf16):
  *       one streaming pass over xhat with no cross-lane reductions (HBM-read-bound).
  * n_valid_dev (optional, device int32): only the first min(n, *n_valid_dev) boards are processed - lets a captured
@@ -241,8 +244,8 @@ int32_t azk_nn_cls_attention(const void *xhat_bf16_dev, const float *m_dev, cons
  * Heads: 8 or 4 (and 2*H <= 16). */
 int32_t azk_nn_patch_embed_scores(const void *boards_dev, int32_t boards_are_f32, const void *wt_bf16_dev,
                                   const float *cpos_dev, const float *ln_w_dev, const float *ln_b_dev,
-                                  void *xhat_out_bf16_dev, const float *m_dev, float *scores_out_dev,
-                                  int32_t num_heads, int32_t n, int32_t channels, int32_t rows, int32_t cols,
+                                  void *xhat_out_bf16_dev, const float *score_cpos_dev, const float *score_msum_dev,
+                                  float *scores_out_dev, int32_t num_heads, int32_t n, int32_t channels, int32_t rows, int32_t cols,
                                   int32_t ksize, int32_t kp, int32_t embed_dim, float ln_eps,
                                   const int32_t *n_valid_dev, void *stream);
 int32_t azk_nn_cls_pool(const void *xhat_bf16_dev, const float *scores_dev, const float *c_dev, void *z_out_bf16_dev,

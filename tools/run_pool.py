@@ -35,4 +35,4 @@ def timeit(name, fn):
 timeit("cls_pool", lambda: L.azk_nn_cls_pool(p(xh), p(sc), p(f["c"]), p(z), n, T, D, H, None, st()))
 timeit("cls_attention(v1)", lambda: azk.nn_cls_attention(xh, f["m"], f["c"], H))
 timeit("embed xhat only", lambda: net.embed_hip(x, False, True))
-timeit("embed+scores+pool", lambda: azk.nn_embed_scores_pool(x, hp["wt"], hp["cpos"], hp["ln_w"], hp["ln_b"], f["m_n"], f["c_n"], 15, 15, 5, 512, 8))
+timeit("embed+scores+pool", lambda: azk.nn_embed_scores_pool(x, f["wt_ext"], hp["cpos"], f["score_cpos"], f["score_msum"], f["c_n"], 15, 15, 5, 512, 8))
