@@ -17,6 +17,7 @@
 #include <hip/hip_bf16.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <type_traits>
 
 #include "azk.h"
 
@@ -545,9 +546,24 @@ __global__ __launch_bounds__(256) void k_cls_pool(ClsPoolArgs a) {
         for (int q = 0; q < CPL; q++) zacc[h][q] = 0.f;
     const unsigned short *base = (const unsigned short *)a.xhat + (size_t)b * a.T * D + lane * CPL;
     const int T = (a.ablate & 2) ? 0 : a.T;
-    auto consume = [&](const float (&x)[8][CPL], int t0) {
+    // raw rows stay in registers exactly as loaded (no conversion at fetch time, so nothing waits on a load until its row
+    // is consumed and a whole 8-row set stays in flight behind the one being used)
+    typedef typename std::conditional<CPL == 8, uint4, typename std::conditional<CPL == 4, uint2, unsigned>::type>::type raw_t;
+    auto consume = [&](const raw_t (&x)[8], int t0) {
 #pragma unroll
         for (int k = 0; k < 8; k++) {
+            float xv[CPL];
+            if constexpr (CPL == 8) {
+                xv[0] = __uint_as_float(x[k].x << 16); xv[1] = __uint_as_float(x[k].x & 0xffff0000u);
+                xv[2] = __uint_as_float(x[k].y << 16); xv[3] = __uint_as_float(x[k].y & 0xffff0000u);
+                xv[4] = __uint_as_float(x[k].z << 16); xv[5] = __uint_as_float(x[k].z & 0xffff0000u);
+                xv[6] = __uint_as_float(x[k].w << 16); xv[7] = __uint_as_float(x[k].w & 0xffff0000u);
+            } else if constexpr (CPL == 4) {
+                xv[0] = __uint_as_float(x[k].x << 16); xv[1] = __uint_as_float(x[k].x & 0xffff0000u);
+                xv[2] = __uint_as_float(x[k].y << 16); xv[3] = __uint_as_float(x[k].y & 0xffff0000u);
+            } else {
+                xv[0] = __uint_as_float(x[k] << 16); xv[1] = __uint_as_float(x[k] & 0xffff0000u);
+            }
             float w[NH];
 #pragma unroll
             for (int h = 0; h < NH; h += 4) {
@@ -557,15 +573,15 @@ __global__ __launch_bounds__(256) void k_cls_pool(ClsPoolArgs a) {
 #pragma unroll
             for (int h = 0; h < NH; h++)
 #pragma unroll
-                for (int q = 0; q < CPL; q++) zacc[h][q] += w[h] * x[k][q];
+                for (int q = 0; q < CPL; q++) zacc[h][q] += w[h] * xv[q];
         }
     };
     // rows past T are clamped to the last row; their weights aw[t >= T] are exactly 0 (Tp padding), so they add nothing
-    auto fetch = [&](float (&x)[8][CPL], int t0) {
+    auto fetch = [&](raw_t (&x)[8], int t0) {
 #pragma unroll
-        for (int k = 0; k < 8; k++) { const int t = t0 + k < a.T ? t0 + k : a.T - 1; load_row<CPL>(base + (size_t)t * D, x[k]); }
+        for (int k = 0; k < 8; k++) { const int t = t0 + k < a.T ? t0 + k : a.T - 1; x[k] = *(const raw_t *)(base + (size_t)t * D); }
     };
-    float xa[8][CPL], xb[8][CPL];
+    raw_t xa[8], xb[8];
     const int t_first = 8 * wave;                             // this wave's 8-token chunks: t_first, t_first + 32, ...
     if (t_first < T) fetch(xa, t_first);
     for (int t = t_first; t < T; t += 64) {
