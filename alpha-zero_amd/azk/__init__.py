@@ -25,7 +25,7 @@ SYMBOLS = [
     "azk_get_counters", "azk_reset_counters", "azk_check_device_error", "azk_gen_noise",
     "azk_rules_legal_moves", "azk_rules_legal_mask", "azk_rules_apply_move", "azk_rules_undo_move",
     "azk_rules_check_winner", "azk_rules_canonical", "azk_softmax_rows",
-    "azk_step_tree", "azk_step_gather", "azk_recycle_finished", "azk_nn_patch_embed", "azk_nn_cls_attention", "azk_nn_patch_embed_scores", "azk_nn_cls_pool", "azk_debug_stamps", "azk_emit_finished", "azk_clear_cache",
+    "azk_step_tree", "azk_step_gather", "azk_recycle_finished", "azk_nn_patch_embed", "azk_nn_cls_attention", "azk_nn_patch_embed_scores", "azk_nn_cls_pool", "azk_debug_stamps", "azk_emit_finished", "azk_clear_cache", "azk_nn_heads_finalize",
 ]
 
 
@@ -113,6 +113,7 @@ def lib():
     L.azk_step_gather.argtypes = [vp, vp, vp, vp]
     L.azk_recycle_finished.argtypes = [vp, vp, vp]
     L.azk_nn_patch_embed_scores.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, C.c_float, vp, vp]
+    L.azk_nn_heads_finalize.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp]
     L.azk_nn_cls_pool.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]
     L.azk_nn_cls_attention.argtypes = [vp, vp, vp, i32, vp, i32, i32, i32, i32, vp]
     L.azk_nn_patch_embed.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, C.c_float, vp]
@@ -493,3 +494,13 @@ class DeviceReplay:
         n = self.size()
         idx = self.torch.randperm(n, device=self.states.device)[:batch_size]
         return self.states[idx], self.pis[idx].float(), self.zs[idx][:, None]
+
+
+def nn_heads_finalize(heads, action_dim, logits_out, values_out, count=None):
+    """heads bf16 [n, ld] (merged policy/value GEMM) -> logits_out f32 [n, A], values_out f32 [n] = tanh(raw), one launch."""
+    torch = _torch()
+    assert heads.dtype == torch.bfloat16 and heads.is_contiguous() and logits_out.dtype == torch.float32 and values_out.dtype == torch.float32
+    rc = lib().azk_nn_heads_finalize(_p(heads), heads.shape[1], int(action_dim), heads.shape[0], _p(logits_out), _p(values_out),
+                                     _p(count), _stream())
+    if rc != 0:
+        raise AzkError(f"azk_nn_heads_finalize failed ({rc})")

@@ -278,29 +278,34 @@ __device__ int azk_valid_moves(const uint8_t *b, const GameDesc &g, int16_t *mov
     uint16_t *tab = ms.tabA, *other = ms.tabB;
     unsigned mask = 7;
     int fill = 0, pos = 0;
-    while (pos < m) {
+    // the keys of one table generation are inserted as ONE ordered batch: [re-insertions in old-table order] + [new
+    // candidates up to the next resize threshold]
+    int nlist = 0;                                                 // re-insertions waiting in moves[0 .. nlist)
+    while (pos < m || nlist > 0) {
         const int thr = (int)((mask * 3u + 4u) / 5u);             // smallest fill with fill*5 >= mask*3
         int cnt = m - pos;
-        if (cnt > thr - fill) cnt = thr - fill;
-        insert_batch(tab, mask, ms.ord + pos, cnt);
-        fill += cnt; pos += cnt;
+        if (cnt > thr - (fill + nlist)) cnt = thr - (fill + nlist);
+        if (cnt < 0) cnt = 0;
+        for (int i = lane; i < cnt; i += AZK_WAVE) moves[nlist + i] = ms.ord[pos + i];
+        __syncthreads();
+        insert_batch(tab, mask, moves, nlist + cnt);
+        fill += nlist + cnt; pos += cnt; nlist = 0;
         if ((unsigned)fill * 5u >= mask * 3u) {                   // set_table_resize(so, used * 4)
             unsigned newsize = 8;
             const unsigned minused = (unsigned)fill * 4u;
             while (newsize <= minused) newsize <<= 1;
-            int n2 = 0;                                           // old table in slot order = re-insertion order
-            for (unsigned base = 0; base <= mask; base += AZK_WAVE) {
+            for (unsigned base = 0; base <= mask; base += AZK_WAVE) {   // old table in slot order = re-insertion order
                 const unsigned i = base + lane;
                 const uint16_t kv = i <= mask ? tab[i] : (uint16_t)0;
                 const unsigned long long bm = __ballot(kv != 0);
-                if (kv) moves[n2 + __popcll(bm & ((1ull << lane) - 1ull))] = (int16_t)kv;   // `moves` doubles as the scratch list
-                n2 += __popcll(bm);
+                if (kv) moves[nlist + __popcll(bm & ((1ull << lane) - 1ull))] = (int16_t)kv;   // `moves` doubles as the scratch list
+                nlist += __popcll(bm);
                 if (i <= mask) tab[i] = 0;
             }
             __syncthreads();
-            insert_batch(other, newsize - 1, moves, n2);
             uint16_t *tmp = tab; tab = other; other = tmp;
             mask = newsize - 1;
+            fill = 0;                                             // the new table is empty until the batch above re-inserts
         }
     }
     if (dbgv) s3 = clock64();

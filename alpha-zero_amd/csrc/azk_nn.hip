@@ -660,3 +660,32 @@ extern "C" int32_t azk_nn_cls_pool(const void *xhat_bf16_dev, const float *score
 #undef CASE
     return AZK_ERR_ARG;
 }
+
+
+// =====================================================================================================
+// k_heads_finalize: the merged policy/value head GEMM output [n][ld] (bf16; columns [0, A) logits, column A the raw
+// value) -> logits float32 [n][A] and values float32 [n] = tanh(raw) (nn.py:82-83), one launch instead of three.
+// =====================================================================================================
+namespace {
+__global__ void k_heads_finalize(const unsigned short *__restrict__ out, int ld, int A, int n, float *__restrict__ logits,
+                                 float *__restrict__ values, const int *count) {
+    const int nvalid = count ? min(n, *count) : n;
+    const long long total = (long long)nvalid * (A + 1);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int row = (int)(i / (A + 1)), col = (int)(i - (long long)row * (A + 1));
+        const float v = __uint_as_float((unsigned)out[(size_t)row * ld + col] << 16);
+        if (col < A) logits[(size_t)row * A + col] = v;
+        else values[row] = tanhf(v);
+    }
+}
+}  // namespace
+
+extern "C" int32_t azk_nn_heads_finalize(const void *heads_bf16_dev, int32_t ld, int32_t action_dim, int32_t n,
+                                         float *logits_out_dev, float *values_out_dev, const int32_t *n_valid_dev,
+                                         void *stream) {
+    if (!heads_bf16_dev || !logits_out_dev || !values_out_dev || ld < action_dim + 1 || n < 0) return AZK_ERR_ARG;
+    if (n == 0) return AZK_OK;
+    k_heads_finalize<<<1024, 256, 0, (hipStream_t)stream>>>((const unsigned short *)heads_bf16_dev, ld, action_dim, n, logits_out_dev,
+                                                           values_out_dev, n_valid_dev);
+    return hipGetLastError() == hipSuccess ? AZK_OK : AZK_ERR_HIP;
+}

@@ -116,6 +116,7 @@ class PolicyValueNet:
         self.path = path
         self.fast_outputs = False   # True: logits may come back as a bf16 view (the caller converts while copying)
         self.last_value_pre_tanh = False
+        self.out_buffers = None     # optional (logits f32 [n,A], values f32 [n]) the fast tail writes into directly
         self.kernel_timers = None   # optional (embed_timer, pool_timer) with start()/stop(): HIP-event timing of the two kernels
         self.live_count = None      # optional int32 CUDA tensor: number of valid rows at the head of the batch (graph stepping)
         self.to(device, dtype)
@@ -228,11 +229,13 @@ class PolicyValueNet:
             h = F.gelu(F.linear(h, w["blocks.0.mlp.0.weight"], w["blocks.0.mlp.0.bias"]))
         x2 = torch.addmm(x1, h, f["W3T"]).add_(w["blocks.0.mlp.3.bias"])                               # nn.py:59-60
         out = F.linear(self._ln(x2, "norm"), f["Wh"], f["bh"])                                          # nn.py:78-83
+        if self.out_buffers is not None:
+            # the step graph's own float32 buffers: conversion, slicing and tanh in one launch (azk_nn_heads_finalize)
+            import azk
+            lb, vb = self.out_buffers
+            azk.nn_heads_finalize(out, A, lb, vb, count=self.live_count)
+            return lb, vb
         logits = out[:, :A]
-        if self.fast_outputs:
-            # the step graph copies into its own float32 buffers (conversion folded into the copy); tanh runs there in place
-            self.last_value_pre_tanh = True
-            return logits, out[:, A:A + 1]
         return logits.float(), torch.tanh(out[:, A:A + 1].float())
 
 

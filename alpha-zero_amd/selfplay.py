@@ -237,11 +237,14 @@ class SelfPlayRunner:
             self.evaluator.fast_outputs = True
         if hasattr(self.evaluator, "kernel_timers"):
             self.evaluator.kernel_timers = (timer.child("k_embed"), timer.child("k_cls_pool")) if timer is not None else None
+        if hasattr(self.evaluator, "out_buffers"):
+            self.evaluator.out_buffers = (h.logits_buf, h.values_buf)
         logits, values = self.evaluator(e.leaf_boards)
-        h.logits_buf.copy_(logits)
-        h.values_buf.copy_(values.reshape(-1))
-        if getattr(self.evaluator, "last_value_pre_tanh", False):
-            h.values_buf.tanh_()                       # the fast path hands back the raw value column (nn.py:83 tanh applied here)
+        if logits.data_ptr() != h.logits_buf.data_ptr():        # evaluators that do not write the step buffers themselves
+            h.logits_buf.copy_(logits)
+            h.values_buf.copy_(values.reshape(-1))
+        if hasattr(self.evaluator, "out_buffers"):
+            self.evaluator.out_buffers = None
 
     def _all_bodies(self):
         torch = self.torch

@@ -252,6 +252,11 @@ int32_t azk_nn_cls_pool(const void *xhat_bf16_dev, const float *scores_dev, cons
                         int32_t n, int32_t tokens, int32_t embed_dim, int32_t num_heads, const int32_t *n_valid_dev,
                         void *stream);
 
+/* Merged policy/value head output (bf16 [n][ld]: columns [0, A) logits, column A the raw value) -> float32 logits [n][A]
+ * and values [n] = tanh(raw) (nn.py:82-83) in one launch; n_valid_dev as above. */
+int32_t azk_nn_heads_finalize(const void *heads_bf16_dev, int32_t ld, int32_t action_dim, int32_t n, float *logits_out_dev,
+                              float *values_out_dev, const int32_t *n_valid_dev, void *stream);
+
 /* float32 softmax exactly as the engine applies it to logits (test hook; [n][A] -> [n][A]) */
 int32_t azk_softmax_rows(const float *logits_dev, int32_t n, int32_t action_dim, float *out_dev, void *stream);
 
