@@ -25,7 +25,7 @@ SYMBOLS = [
     "azk_get_counters", "azk_reset_counters", "azk_check_device_error", "azk_gen_noise",
     "azk_rules_legal_moves", "azk_rules_legal_mask", "azk_rules_apply_move", "azk_rules_undo_move",
     "azk_rules_check_winner", "azk_rules_canonical", "azk_softmax_rows",
-    "azk_step_tree", "azk_step_gather", "azk_recycle_finished", "azk_nn_patch_embed", "azk_nn_cls_attention", "azk_nn_patch_embed_scores", "azk_nn_cls_pool", "azk_debug_stamps", "azk_emit_finished", "azk_clear_cache", "azk_nn_heads_finalize",
+    "azk_step_tree", "azk_step_gather", "azk_recycle_finished", "azk_nn_patch_embed", "azk_nn_cls_attention", "azk_nn_patch_embed_scores", "azk_nn_cls_pool", "azk_debug_stamps", "azk_emit_finished", "azk_clear_cache", "azk_nn_heads_finalize", "azk_nn_layernorm_rows",
 ]
 
 
@@ -113,6 +113,7 @@ def lib():
     L.azk_step_gather.argtypes = [vp, vp, vp, vp]
     L.azk_recycle_finished.argtypes = [vp, vp, vp]
     L.azk_nn_patch_embed_scores.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, C.c_float, vp, vp]
+    L.azk_nn_layernorm_rows.argtypes = [vp, vp, vp, C.c_float, vp, vp, i32, i32, vp, vp]
     L.azk_nn_heads_finalize.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp]
     L.azk_nn_cls_pool.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]
     L.azk_nn_cls_attention.argtypes = [vp, vp, vp, i32, vp, i32, i32, i32, i32, vp]
@@ -504,3 +505,14 @@ def nn_heads_finalize(heads, action_dim, logits_out, values_out, count=None):
                                      _p(count), _stream())
     if rc != 0:
         raise AzkError(f"azk_nn_heads_finalize failed ({rc})")
+
+
+def nn_layernorm_rows(x, w, b, eps=1e-5, add_bias=None, count=None):
+    """LayerNorm over the rows of bf16 x [n, D] -> new bf16 tensor; with add_bias, x becomes x + add_bias in place."""
+    torch = _torch()
+    assert x.dtype == torch.bfloat16 and x.is_contiguous() and w.dtype == torch.float32 and b.dtype == torch.float32
+    y = torch.empty_like(x)
+    rc = lib().azk_nn_layernorm_rows(_p(x), _p(w), _p(b), float(eps), _p(y), _p(add_bias), x.shape[0], x.shape[1], _p(count), _stream())
+    if rc != 0:
+        raise AzkError(f"azk_nn_layernorm_rows failed ({rc})")
+    return y

@@ -689,3 +689,80 @@ extern "C" int32_t azk_nn_heads_finalize(const void *heads_bf16_dev, int32_t ld,
                                                            values_out_dev, n_valid_dev);
     return hipGetLastError() == hipSuccess ? AZK_OK : AZK_ERR_HIP;
 }
+
+
+// =====================================================================================================
+// k_ln_rows: LayerNorm over the rows of a bf16 matrix [n][D] (nn.LayerNorm: biased variance, eps inside the sqrt,
+// fp32 statistics), one wave per row, 16-byte loads/stores; optionally also writes x + add_bias back in place (the
+// residual operand of the following GEMM, nn.py:59-60: the mlp.3 bias joins the residual before the product is added).
+// =====================================================================================================
+namespace {
+__device__ __forceinline__ float wave64_sum(float v) {
+    v = row16_sum(v);
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+
+template <int VPL>   // values per lane: D = 64 * VPL
+__global__ __launch_bounds__(256) void k_ln_rows(unsigned short *__restrict__ x, const float *__restrict__ w, const float *__restrict__ b,
+                                                 float eps, unsigned short *__restrict__ y, const float *__restrict__ add_bias, int n,
+                                                 const int *count) {
+    constexpr int D = 64 * VPL;
+    const int nvalid = count ? min(n, *count) : n;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= nvalid) return;
+    unsigned short *xr = x + (size_t)row * D + lane * VPL;
+    float v[VPL];
+    if constexpr (VPL == 8) {
+        const uint4 raw = *(const uint4 *)xr;
+        const unsigned u[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+        for (int q = 0; q < 4; q++) { v[2 * q] = __uint_as_float(u[q] << 16); v[2 * q + 1] = __uint_as_float(u[q] & 0xffff0000u); }
+    } else {
+#pragma unroll
+        for (int q = 0; q < VPL; q++) v[q] = __uint_as_float((unsigned)xr[q] << 16);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < VPL; q++) s += v[q];
+    const float mean = wave64_sum(s) * (1.0f / D);
+    float ss = 0.f;
+#pragma unroll
+    for (int q = 0; q < VPL; q++) { const float d = v[q] - mean; ss += d * d; }
+    const float rstd = rsqrtf(wave64_sum(ss) * (1.0f / D) + eps);
+    float o[VPL], r[VPL];
+#pragma unroll
+    for (int q = 0; q < VPL; q++) {
+        o[q] = (v[q] - mean) * rstd * w[lane * VPL + q] + b[lane * VPL + q];
+        if (add_bias) r[q] = v[q] + add_bias[lane * VPL + q];
+    }
+    unsigned short *yr = y + (size_t)row * D + lane * VPL;
+    if constexpr (VPL == 8) {
+        *(uint4 *)yr = pack8(o);
+        if (add_bias) *(uint4 *)xr = pack8(r);
+    } else {
+#pragma unroll
+        for (int q = 0; q < VPL; q++) {
+            yr[q] = __builtin_bit_cast(unsigned short, (__bf16)o[q]);
+            if (add_bias) xr[q] = __builtin_bit_cast(unsigned short, (__bf16)r[q]);
+        }
+    }
+}
+}  // namespace
+
+extern "C" int32_t azk_nn_layernorm_rows(void *x_bf16_dev, const float *w_dev, const float *b_dev, float eps, void *y_bf16_dev,
+                                         const float *add_bias_dev, int32_t n, int32_t embed_dim, const int32_t *n_valid_dev,
+                                         void *stream) {
+    if (!x_bf16_dev || !w_dev || !b_dev || !y_bf16_dev || n < 0) return AZK_ERR_ARG;
+    if (embed_dim != 128 && embed_dim != 256 && embed_dim != 512) return AZK_ERR_ARG;
+    if (n == 0) return AZK_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((n + 3) / 4), block(256);
+    unsigned short *x = (unsigned short *)x_bf16_dev, *y = (unsigned short *)y_bf16_dev;
+    if (embed_dim == 512) k_ln_rows<8><<<grid, block, 0, st>>>(x, w_dev, b_dev, eps, y, add_bias_dev, n, n_valid_dev);
+    else if (embed_dim == 256) k_ln_rows<4><<<grid, block, 0, st>>>(x, w_dev, b_dev, eps, y, add_bias_dev, n, n_valid_dev);
+    else k_ln_rows<2><<<grid, block, 0, st>>>(x, w_dev, b_dev, eps, y, add_bias_dev, n, n_valid_dev);
+    return hipGetLastError() == hipSuccess ? AZK_OK : AZK_ERR_HIP;
+}

@@ -207,6 +207,9 @@ class PolicyValueNet:
             f["Wh"], f["bh"] = Wh.to(torch.bfloat16), bh.to(torch.bfloat16)
             f["W0T"] = m["blocks.0.mlp.0.weight"].t().contiguous().to(dev, torch.bfloat16)
             f["W3T"] = m["blocks.0.mlp.3.weight"].t().contiguous().to(dev, torch.bfloat16)
+            for k_, src in (("ln2_w", b + "norm2.weight"), ("ln2_b", b + "norm2.bias"), ("lnf_w", "norm.weight"),
+                            ("lnf_b", "norm.bias"), ("b3", b + "mlp.3.bias")):
+                f[k_] = m[src].to(dev, torch.float32).contiguous()
             self._gelu_epilogue = False
             try:    # exact-erf GELU fused into the GEMM when the BLAS backend offers it; checked against the unfused op
                 t = torch.randn(64, D, device=dev, dtype=torch.bfloat16)
@@ -221,17 +224,18 @@ class PolicyValueNet:
         """depth-1 cls row after the pooled tokens zn [n, H, D]: composed projection, MLP, final norm, merged heads."""
         w, cfg, f = self.w, self.cfg, self._fold
         n, A = z.shape[0], cfg.action_dim
+        import azk
         x1 = torch.addmm(f["bias1"], z.view(n, -1), f["Wcomb"])                                        # nn.py:54-56
-        h = self._ln(x1, "blocks.0.norm2")
+        # norm2(x1) and, in the same pass, x1 += mlp.3 bias (the residual the last MLP GEMM accumulates onto)
+        h = azk.nn_layernorm_rows(x1, f["ln2_w"], f["ln2_b"], 1e-5, add_bias=f["b3"], count=self.live_count)
         if self._gelu_epilogue:                                                                         # GELU in the GEMM epilogue (hipBLASLt)
             h = torch._addmm_activation(w["blocks.0.mlp.0.bias"], h, f["W0T"], use_gelu=True)
         else:
             h = F.gelu(F.linear(h, w["blocks.0.mlp.0.weight"], w["blocks.0.mlp.0.bias"]))
-        x2 = torch.addmm(x1, h, f["W3T"]).add_(w["blocks.0.mlp.3.bias"])                               # nn.py:59-60
-        out = F.linear(self._ln(x2, "norm"), f["Wh"], f["bh"])                                          # nn.py:78-83
+        x2 = x1.addmm_(h, f["W3T"])                                                                    # nn.py:59-60 (in place: no copy)
+        out = F.linear(azk.nn_layernorm_rows(x2, f["lnf_w"], f["lnf_b"], 1e-5, count=self.live_count), f["Wh"], f["bh"])   # nn.py:78-83
         if self.out_buffers is not None:
             # the step graph's own float32 buffers: conversion, slicing and tanh in one launch (azk_nn_heads_finalize)
-            import azk
             lb, vb = self.out_buffers
             azk.nn_heads_finalize(out, A, lb, vb, count=self.live_count)
             return lb, vb
@@ -371,7 +375,6 @@ class PolicyValueNet:
             if depth == 1:
                 import azk
                 hp, f = self._hip, self._fold
-                x0 = hp["cpos"][0].to(self.dtype).expand(x.shape[0], -1)
                 if self.cfg.num_heads in (4, 8):
                     if x.dtype not in (torch.bfloat16, torch.float32):
                         x = x.float()
@@ -379,6 +382,7 @@ class PolicyValueNet:
                                                  self.cfg.rows, self.cfg.cols, self.cfg.patch_size, self.cfg.embed_dim,
                                                  self.cfg.num_heads, count=self.live_count, timers=self.kernel_timers)
                     return self.tail_fast(z)
+                x0 = hp["cpos"][0].to(self.dtype).expand(x.shape[0], -1)
                 _, xhat = self.embed_hip(x, want_x=False, want_xhat=True)
             else:
                 t = self.embed(x)

@@ -252,6 +252,13 @@ int32_t azk_nn_cls_pool(const void *xhat_bf16_dev, const float *scores_dev, cons
                         int32_t n, int32_t tokens, int32_t embed_dim, int32_t num_heads, const int32_t *n_valid_dev,
                         void *stream);
 
+/* nn.LayerNorm over the rows of a bf16 matrix [n][embed_dim] (norm2 / norm of nn.py:41-42,78; fp32 statistics) -> y;
+ * with add_bias_dev != NULL the rows of x are also replaced by x + add_bias (the residual the next GEMM accumulates
+ * onto, nn.py:59-60).  embed_dim in {128, 256, 512}. */
+int32_t azk_nn_layernorm_rows(void *x_bf16_dev, const float *w_dev, const float *b_dev, float eps, void *y_bf16_dev,
+                              const float *add_bias_dev, int32_t n, int32_t embed_dim, const int32_t *n_valid_dev,
+                              void *stream);
+
 /* Merged policy/value head output (bf16 [n][ld]: columns [0, A) logits, column A the raw value) -> float32 logits [n][A]
  * and values [n] = tanh(raw) (nn.py:82-83) in one launch; n_valid_dev as above. */
 int32_t azk_nn_heads_finalize(const void *heads_bf16_dev, int32_t ld, int32_t action_dim, int32_t n, float *logits_out_dev,

@@ -98,3 +98,41 @@ def test_cls_attention_kernel_vs_torch():
         s = torch.einsum("ntd,nhd->nht", xf, mm) + cc[:, :, None]
         ref = torch.einsum("nht,ntd->nhd", torch.softmax(s, dim=2), xf)
         torch.testing.assert_close(z, ref, rtol=1e-2, atol=1e-2)     # output rounded to bf16; fp32 accumulation inside
+
+
+@pytest.mark.parametrize("D", [128, 256, 512])
+def test_layernorm_rows_and_heads_finalize_vs_torch_fp32(D):
+    """azk_nn_layernorm_rows / azk_nn_heads_finalize against the plain fp32 ops on the same bf16 inputs.
+    Tolerance: outputs are rounded once to bf16 (2^-8 relative) -> 1e-2 absolute on O(1) values."""
+    import azk
+    torch.manual_seed(D)
+    n = 301
+    x = (torch.randn(n, D, device="cuda") * 1.7 + 0.3).to(torch.bfloat16)
+    w = torch.randn(D, device="cuda") * 0.5 + 1.0
+    b = torch.randn(D, device="cuda") * 0.2
+    add = torch.randn(D, device="cuda") * 0.3
+    ref = F.layer_norm(x.float(), (D,), w, b, 1e-5)
+    x_in = x.clone()
+    y = azk.nn_layernorm_rows(x_in, w, b, 1e-5)
+    assert torch.equal(x_in, x)                                   # no add_bias: input untouched
+    assert (y.float() - ref).abs().max().item() < 3e-2
+    assert (y.float() - ref).abs().mean().item() < 3e-3
+    y2 = azk.nn_layernorm_rows(x_in, w, b, 1e-5, add_bias=add)
+    assert torch.equal(y2, y)
+    assert torch.equal(x_in, (x.float() + add).to(torch.bfloat16))
+    # device-side row count: rows beyond it are left alone
+    cnt = torch.tensor([100], dtype=torch.int32, device="cuda")
+    x3 = x.clone()
+    y3 = torch.full_like(x, 7.0)
+    rc = azk.lib().azk_nn_layernorm_rows(x3.data_ptr(), w.data_ptr(), b.data_ptr(), 1e-5, y3.data_ptr(), add.data_ptr(), n, D,
+                                         cnt.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    assert torch.equal(y3[:100], y[:100]) and bool((y3[100:] == 7.0).all()) and torch.equal(x3[100:], x[100:])
+
+    A = 225
+    heads = torch.randn(n, 232, device="cuda").to(torch.bfloat16)
+    lo = torch.zeros(n, A, device="cuda")
+    vo = torch.zeros(n, device="cuda")
+    azk.nn_heads_finalize(heads, A, lo, vo)
+    assert torch.equal(lo, heads[:, :A].float())
+    assert (vo - torch.tanh(heads[:, A].float())).abs().max().item() < 1e-6
