@@ -44,9 +44,26 @@ class MCTS:
     @staticmethod
     def mcts(model, board, root, Game, mcts_iterations, dirichlet=True):
         if model is None:
-            raise NotImplementedError("vanilla (model=None) rollouts are not on the GPU path; "
-                                      "the network-guided search (model given) is")
+            MCTS.mcts_vanilla(board, root, Game, mcts_iterations)
+            return
         MCTS.mcts_batch(model, [board], [root], Game, mcts_iterations, dirichlet)
+
+    @staticmethod
+    def mcts_vanilla(board, root, Game, mcts_iterations):
+        """model=None (mcts.py:57-79): UCB1 walk, expansion without priors, uniform-random rollouts - all inside the
+        engine.  The rollouts draw np.random.randint from the GLOBAL np.random stream in the reference; here the
+        global MT19937 state is handed to the device generator and written back afterwards, so a seeded caller gets
+        the reference's draws and finds np.random exactly where the reference would have left it."""
+        import azk
+        eng = _engine(Game, 1, mcts_iterations)
+        eng.set_positions(_cells(board).reshape(1, -1), [root.currentPlayer], [root.move_count])
+        st = np.random.get_state()
+        eng.vanilla_set_rng(azk.mt_state_from_numpy(st)[None])
+        eng.vanilla_search(mcts_iterations, chunk=64 if Game.rows * Game.cols > 64 else None)
+        eng.check_error()
+        np.random.set_state(azk.mt_state_to_numpy(eng.vanilla_get_rng()[0], st))
+        MCTS.mcts_count += mcts_iterations
+        MCTS._materialise(eng, [root], Game, prior_none=True)
 
     @staticmethod
     def mcts_batch(model, boards, roots, Game, mcts_iterations, dirichlet=True, noise=None):
@@ -68,17 +85,21 @@ class MCTS:
         eng.search(evaluator, mcts_iterations, nz)
         eng.check_error()
         MCTS.mcts_count += mcts_iterations * G
+        MCTS._materialise(eng, roots, Game, f32_prior=not dirichlet)
+
+    @staticmethod
+    def _materialise(eng, roots, Game, f32_prior=False, prior_none=False):
         _, q, rv = eng.root_stats()
         q, rv = q.cpu().numpy(), rv.cpu().numpy()
         for g, root in enumerate(roots):
             ch = eng.root_children(g)
             root.visit = int(rv[g])
             root.value = float(eng.export_tree(g, cap=1)["value"][0])      # W of the root, exact
-            f32_prior = not dirichlet
             root.children = []
             for cell, n, w, p in zip(ch["cell"], ch["visit"], ch["value"], ch["prior"]):
+                prior = 0.0 if prior_none else (np.float32(p) if f32_prior else np.float64(p))   # node.py:21 default prior
                 node = Node(root, (int(cell) // Game.cols, int(cell) % Game.cols), 1 - root.currentPlayer,
-                            root.move_count + 1, np.float32(p) if f32_prior else np.float64(p))
+                            root.move_count + 1, prior)
                 node.visit = int(n)
                 node.value = float(w)
                 root.children.append(node)

@@ -26,6 +26,7 @@ SYMBOLS = [
     "azk_rules_legal_moves", "azk_rules_legal_mask", "azk_rules_apply_move", "azk_rules_undo_move",
     "azk_rules_check_winner", "azk_rules_canonical", "azk_softmax_rows",
     "azk_step_tree", "azk_step_gather", "azk_recycle_finished", "azk_nn_patch_embed", "azk_nn_cls_attention", "azk_nn_patch_embed_scores", "azk_nn_cls_pool", "azk_debug_stamps", "azk_emit_finished", "azk_clear_cache", "azk_nn_heads_finalize", "azk_nn_layernorm_rows",
+    "azk_vanilla_set_rng", "azk_vanilla_get_rng", "azk_vanilla_search",
 ]
 
 
@@ -110,6 +111,9 @@ def lib():
     L.azk_rules_canonical.argtypes = [i32, i32, i32, vp, i32, vp, vp, vp]
     L.azk_softmax_rows.argtypes = [vp, i32, i32, vp, vp]
     L.azk_step_tree.argtypes = [vp, vp, vp, vp]
+    L.azk_vanilla_set_rng.argtypes = [vp, i32, i32, vp, vp]
+    L.azk_vanilla_get_rng.argtypes = [vp, i32, i32, vp, vp]
+    L.azk_vanilla_search.argtypes = [vp, i32, vp]
     L.azk_step_gather.argtypes = [vp, vp, vp, vp]
     L.azk_recycle_finished.argtypes = [vp, vp, vp]
     L.azk_nn_patch_embed_scores.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, C.c_float, vp, vp]
@@ -278,6 +282,30 @@ class Engine:
                 logits = values = None
         if logits is not None:
             self.step_expand_backup(logits, values)
+
+    # ---- vanilla mode (model=None) ----------------------------------------------------------------
+    def vanilla_set_rng(self, states, first=0):
+        """states: uint32 [count, 625] = MT19937 key + position per game (np.random.get_state()[1:3])."""
+        st = np.ascontiguousarray(states, np.uint32).reshape(-1, 625)
+        self._chk(self.L.azk_vanilla_set_rng(self.h, first, len(st), _np(st), _stream()))
+
+    def vanilla_get_rng(self, first=0, count=None):
+        count = self.G - first if count is None else count
+        st = np.empty((count, 625), np.uint32)
+        self._chk(self.L.azk_vanilla_get_rng(self.h, first, count, _np(st), _stream()))
+        return st
+
+    def vanilla_search(self, n_sims, chunk=None):
+        """MCTS.mcts(None, ...) for all G games: begin a search and run n_sims whole simulations (UCB1 walk, expansion,
+        random rollout, backup) on the device; `chunk` bounds the simulations per launch."""
+        assert n_sims <= self.max_sims
+        self.begin_search(None)
+        chunk = n_sims if not chunk else int(chunk)
+        done = 0
+        while done < n_sims:
+            k = min(chunk, n_sims - done)
+            self._chk(self.L.azk_vanilla_search(self.h, k, _stream()))
+            done += k
 
     def root_stats(self):
         self._chk(self.L.azk_root_stats(self.h, _p(self.pi), _p(self.q), _p(self.root_visit), _stream()))
@@ -516,3 +544,19 @@ def nn_layernorm_rows(x, w, b, eps=1e-5, add_bias=None, count=None):
     if rc != 0:
         raise AzkError(f"azk_nn_layernorm_rows failed ({rc})")
     return y
+
+
+def mt_state_from_numpy(state=None):
+    """np.random.get_state() (or a RandomState's) -> the uint32[625] an engine game takes (key + position)."""
+    st = np.random.get_state() if state is None else state
+    assert st[0] == "MT19937"
+    out = np.empty(625, np.uint32)
+    out[:624] = st[1]
+    out[624] = st[2]
+    return out
+
+
+def mt_state_to_numpy(words, template=None):
+    """uint32[625] read back from the engine -> a tuple for np.random.set_state (Gaussian cache fields from `template`)."""
+    t = np.random.get_state() if template is None else template
+    return ("MT19937", np.asarray(words[:624], np.uint32), int(words[624]), t[3], t[4])

@@ -393,6 +393,177 @@ __global__ __launch_bounds__(AZK_WAVE) void k_gather(Dev d, void *__restrict__ l
     }
 }
 
+
+// ================================================================================================
+// Vanilla mode (model=None): mcts.py:57-59 (expand with no priors, rollout), MCTS.simulate mcts.py:62-79, UCB1 of
+// utils.py:29-44 mode 'normal'.  No evaluator => a whole simulation (and n_sims of them) runs inside one launch.
+// Random numbers: np.random.randint(len(valid_moves)) of the legacy global RandomState = MT19937 (randomkit) + numpy's
+// masked rejection (random_bounded_uint64_fill, use_masked) - reproduced here on a per-game MT19937 state so that a
+// search seeded with np.random.get_state() consumes the very same stream as the reference.
+// ================================================================================================
+__device__ void mt_twist(uint32_t *mt) {                          // all lanes; mt[624] in LDS (mt19937_gen)
+    const int lane = azk_lane();
+    auto phase = [&](int k0, int k1) {                            // every read of the phase happens before its writes
+        uint32_t nv[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int k = k0 + lane + AZK_WAVE * q;
+            if (k < k1) {
+                const uint32_t y = (mt[k] & 0x80000000u) | (mt[k + 1] & 0x7fffffffu);
+                const int src = k + 397 < 624 ? k + 397 : k - 227;
+                nv[q] = mt[src] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int k = k0 + lane + AZK_WAVE * q;
+            if (k < k1) mt[k] = nv[q];
+        }
+        __syncthreads();
+    };
+    phase(0, 227);        // sources mt[k+397]: old words
+    phase(227, 454);      // sources mt[k-227] in [0, 227): already new
+    phase(454, 623);      // sources in [227, 396): already new
+    if (lane == 0) {
+        const uint32_t y = (mt[623] & 0x80000000u) | (mt[0] & 0x7fffffffu);
+        mt[623] = mt[396] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ uint32_t mt_next(uint32_t *mt, int &pos) {   // wave-uniform
+    if (pos >= 624) { mt_twist(mt); pos = 0; }
+    uint32_t y = mt[pos++];
+    y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
+    return y;
+}
+
+// np.random.randint(n): range 0 draws nothing; otherwise 32-bit draws & (smallest 2^k - 1 >= n - 1) until <= n - 1
+__device__ __forceinline__ int np_randint(uint32_t *mt, int &pos, int n) {
+    if (n <= 1) return 0;
+    const uint32_t rng = (uint32_t)(n - 1);
+    uint32_t mask = rng;
+    mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+    uint32_t v;
+    do { v = mt_next(mt, pos) & mask; } while (v > rng);
+    return (int)v;
+}
+
+__global__ __launch_bounds__(AZK_WAVE) void k_vanilla(Dev d, int n_sims, uint32_t *__restrict__ rng_state,
+                                                       const double *__restrict__ lntab, int lntab_n) {
+    const int g = blockIdx.x, lane = azk_lane();
+    const GameDesc &gd = d.g;
+    const int rc = gd.rc;
+    const size_t base = (size_t)g * (size_t)d.cap;
+    LdsView L = carve(gd, d.path_cap, d.table_size);
+    uint32_t *mt = (uint32_t *)(azk_smem + d.lds_bytes);
+    if (uniform_i32(d.done[g]) != 0) return;
+    uint32_t *gs = rng_state + (size_t)g * 625;
+    for (int i = lane; i < 624; i += AZK_WAVE) mt[i] = gs[i];
+    int pos = uniform_i32((int)gs[624]);
+    const int root_player = uniform_i32(d.to_move[g]), root_mc = uniform_i32(d.move_count[g]);
+    __syncthreads();
+    for (int sim = 0; sim < n_sims; sim++) {
+        for (int i = lane; i < rc; i += AZK_WAVE) L.board[i] = d.cells[(size_t)g * d.rc_pad + i];
+        if (lane == 0) L.path[0] = 0;
+        __syncthreads();
+        int node = 0, depth = 0, node_cell = -1, scanned = 0;
+        int fc = uniform_i32(d.first_child[base]);
+        int Np = uniform_i32(d.N[base]);
+        uint32_t nmeta = (uint32_t)uniform_i32((int)d.meta[base]);
+        for (;;) {                                                    // mcts.py:20-23 with node.select('normal')
+            const int nch = meta_nch(nmeta);
+            if (nch <= 0) break;
+            if (Np < 1 || Np >= lntab_n) { if (lane == 0) atomicExch(d.err, AZK_ERR_STATE); return; }
+            const double l2 = 2.0 * lntab[Np];                        // 2 * math.log(node.visit)
+            double bu = 0.0;
+            int best = 0x7fffffff, bN = 0, bfc = -1;
+            uint32_t bmeta = 0;
+            for (int i = lane; i < nch; i += AZK_WAVE) {
+                const size_t ci = base + fc + i;
+                const int Nc = d.N[ci];
+                const double Wc = d.W[ci];
+                double u = sqrt(l2 / (double)(Nc + 1));               // utils.py:36,43
+                if (Nc != 0) u = Wc / (double)Nc + u;
+                if (best == 0x7fffffff || u > bu) { bu = u; best = i; bN = Nc; bmeta = d.meta[ci]; bfc = d.first_child[ci]; }
+            }
+            wave_argmax_first<double>(bu, best);
+            best = uniform_i32(best);
+            const int wl = best & 63;
+            scanned += nch;
+            const int child = fc + best;
+            Np = uniform_i32(__shfl(bN, wl)); nmeta = (uint32_t)uniform_i32(__shfl((int)bmeta, wl)); fc = uniform_i32(__shfl(bfc, wl));
+            const int cellc = meta_cell(nmeta);
+            const int mover = (root_player + depth) & 1;
+            depth++;
+            node = child;
+            node_cell = cellc;
+            if (lane == 0) {
+                L.path[depth] = node;
+                if (gd.kind == AZK_KIND_C4) L.board[cellc] |= (uint8_t)(1 << mover);
+                else if (L.board[cellc] == 0) L.board[cellc] = (uint8_t)(1 << mover);
+            }
+            if (depth + 1 >= d.path_cap) break;
+        }
+        __syncthreads();
+        const int node_player = (root_player + depth) & 1;
+        const int node_mc = root_mc + depth;
+        int term = -1;
+        if (depth > 0) {                                              // mcts.py:25-32
+            const int w = azk_check_winner(L.board, gd, 1 - node_player, node_cell);
+            if (w != -1) term = 1;
+            else if (node_mc == gd.state_dim) term = 0;
+        }
+        if (lane == 0) {
+            d.counters[(size_t)CNT_SIMS * d.G + g] += 1;
+            d.counters[(size_t)CNT_SCANNED * d.G + g] += scanned;
+            d.counters[(size_t)CNT_TRACE * d.G + g] += depth + 1;
+        }
+        double result;
+        if (term >= 0) {
+            result = (double)term;
+            if (lane == 0) d.counters[(size_t)CNT_TERMINAL * d.G + g] += 1;
+        } else {
+            const int nv = azk_valid_moves(L.board, gd, L.moves, L.ms);   // mcts.py:34
+            const int afc = uniform_i32(d.arena_top[g]);
+            if (afc + nv > d.cap) { if (lane == 0) atomicExch(d.err, AZK_ERR_ARENA_FULL); return; }
+            for (int i = lane; i < nv; i += AZK_WAVE) {               // node.expand(valid_moves, None, Game): node.py:50-59
+                const size_t idx = base + afc + i;
+                d.N[idx] = 0; d.W[idx] = 0.0; d.P[idx] = 0.f; d.meta[idx] = meta_pack(L.moves[i], 0);
+                d.first_child[idx] = -1;
+            }
+            if (lane == 0) {
+                d.first_child[base + node] = afc;
+                d.meta[base + node] = (d.meta[base + node] & 0xffff0000u) | (uint32_t)nv;
+                d.arena_top[g] = afc + nv;
+                d.counters[(size_t)CNT_CREATED * d.G + g] += nv;
+            }
+            // MCTS.simulate (mcts.py:62-79): the walk board is this simulation's private copy already
+            int cur = node_player, mc = node_mc, winner = -1, n = nv;
+            while (winner == -1 && mc < gd.state_dim) {
+                if (mc != node_mc) n = azk_valid_moves(L.board, gd, L.moves, L.ms);   // first ply: the list computed above
+                const int r = np_randint(mt, pos, n);
+                const int cellc = uniform_i32((int)L.moves[r]);
+                __syncthreads();
+                if (lane == 0) {
+                    if (gd.kind == AZK_KIND_C4) L.board[cellc] |= (uint8_t)(1 << cur);
+                    else if (L.board[cellc] == 0) L.board[cellc] = (uint8_t)(1 << cur);
+                }
+                __syncthreads();
+                winner = azk_check_winner(L.board, gd, cur, cellc);   // check_winner(sim_board, 1 - current_player, action)
+                cur ^= 1;
+                mc++;
+            }
+            result = winner != -1 ? (winner == (1 - node_player) ? 1.0 : -1.0) : 0.0;
+        }
+        backup_path(d, base, L.path, depth, result);
+        __syncthreads();
+    }
+    for (int i = lane; i < 624; i += AZK_WAVE) gs[i] = mt[i];
+    if (lane == 0) gs[624] = (uint32_t)pos;
+}
+
 // A leaf that missed the eval cache claims its entry's key at selection and fills logits/value at expansion; if the search
 // is abandoned in between (new search, reset, recycle) the half-written entry must not survive.
 __device__ __forceinline__ void drop_pending_cache_claim(const Dev &d, int g) {
@@ -810,6 +981,9 @@ struct azk_engine {
     long long *counter_sums = nullptr;   // device [CNT_N]
     int *n_leaf_scratch = nullptr;
     void *leaf_scratch = nullptr;        // used when the caller passes no leaf buffer
+    uint32_t *vanilla_rng = nullptr;     // [G][625] MT19937 key + position (vanilla mode), allocated on first use
+    double *lntab = nullptr;             // [lntab_n] math.log(N), from the host libm (the reference's math.log)
+    int lntab_n = 0;
 };
 
 #define HIPCHK(e, call)                                                                 \
@@ -1001,6 +1175,60 @@ int32_t azk_step_tree(azk_engine *e, const float *logits_dev, const float *value
 int32_t azk_step_gather(azk_engine *e, void *leaf_boards_dev, int32_t *n_leaf_dev, void *stream) {
     if (!e || !leaf_boards_dev || !n_leaf_dev) return AZK_ERR_ARG;
     k_gather<<<e->d.G, AZK_WAVE, 0, (hipStream_t)stream>>>(e->d, leaf_boards_dev, n_leaf_dev);
+    HIPCHK(e, hipGetLastError());
+    return AZK_OK;
+}
+
+
+static int32_t vanilla_prepare(azk_engine *e) {
+    if (e->vanilla_rng) return AZK_OK;
+    const size_t G = e->d.G;
+    HIPCHK(e, dalloc(e, &e->vanilla_rng, G * 625));
+    e->lntab_n = e->cfg.max_sims + 2;
+    HIPCHK(e, dalloc(e, &e->lntab, (size_t)e->lntab_n));
+    std::vector<double> t(e->lntab_n, 0.0);
+    for (int i = 1; i < e->lntab_n; i++) t[i] = log((double)i);
+    HIPCHK(e, hipMemcpy(e->lntab, t.data(), sizeof(double) * t.size(), hipMemcpyHostToDevice));
+    std::vector<uint32_t> st(G * 625);
+    for (size_t g = 0; g < G; g++) {                                  // default streams: init_genrand(5489 + game)
+        uint32_t *m = st.data() + g * 625;
+        m[0] = 5489u + (uint32_t)g;
+        for (int i = 1; i < 624; i++) m[i] = 1812433253u * (m[i - 1] ^ (m[i - 1] >> 30)) + (uint32_t)i;
+        m[624] = 624;
+    }
+    HIPCHK(e, hipMemcpy(e->vanilla_rng, st.data(), sizeof(uint32_t) * st.size(), hipMemcpyHostToDevice));
+    return AZK_OK;
+}
+
+int32_t azk_vanilla_set_rng(azk_engine *e, int32_t first, int32_t count, const uint32_t *mt_states_host, void *stream) {
+    if (!e || !mt_states_host || first < 0 || count < 1 || first + count > e->d.G) { if (e) e->err = "azk_vanilla_set_rng: bad argument"; return AZK_ERR_ARG; }
+    for (int i = 0; i < count; i++)
+        if (mt_states_host[(size_t)i * 625 + 624] > 624u) { e->err = "azk_vanilla_set_rng: position must be in [0, 624]"; return AZK_ERR_ARG; }
+    int32_t rc = vanilla_prepare(e);
+    if (rc != AZK_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(e, hipMemcpyAsync(e->vanilla_rng + (size_t)first * 625, mt_states_host, sizeof(uint32_t) * 625 * (size_t)count, hipMemcpyHostToDevice, st));
+    HIPCHK(e, hipStreamSynchronize(st));
+    return AZK_OK;
+}
+
+int32_t azk_vanilla_get_rng(azk_engine *e, int32_t first, int32_t count, uint32_t *mt_states_host, void *stream) {
+    if (!e || !mt_states_host || first < 0 || count < 1 || first + count > e->d.G) { if (e) e->err = "azk_vanilla_get_rng: bad argument"; return AZK_ERR_ARG; }
+    int32_t rc = vanilla_prepare(e);
+    if (rc != AZK_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(e, hipMemcpyAsync(mt_states_host, e->vanilla_rng + (size_t)first * 625, sizeof(uint32_t) * 625 * (size_t)count, hipMemcpyDeviceToHost, st));
+    HIPCHK(e, hipStreamSynchronize(st));
+    return AZK_OK;
+}
+
+int32_t azk_vanilla_search(azk_engine *e, int32_t n_sims, void *stream) {
+    if (!e || n_sims < 0) { if (e) e->err = "azk_vanilla_search: bad argument"; return AZK_ERR_ARG; }
+    int32_t rc = vanilla_prepare(e);
+    if (rc != AZK_OK) return rc;
+    if (n_sims == 0) return AZK_OK;
+    const Dev &d = e->d;
+    k_vanilla<<<d.G, AZK_WAVE, d.lds_bytes + 625 * 4, (hipStream_t)stream>>>(d, n_sims, e->vanilla_rng, e->lntab, e->lntab_n);
     HIPCHK(e, hipGetLastError());
     return AZK_OK;
 }

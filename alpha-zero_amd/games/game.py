@@ -115,9 +115,18 @@ class Game:
         from selfplay import self_play_batch
         cls = type(self)
         if model is None:
-            raise NotImplementedError("vanilla (model=None) self-play is not on the GPU path")
-        seed = int(np.random.randint(0, 2 ** 31 - 1))
-        res = self_play_batch(cls.engine_name, model, 1, mcts_iter, size=cls._size(), seed=seed)[0]
+            # vanilla MCTS: the rollouts consume the global np.random stream exactly as the reference does (the MT19937
+            # state travels to the device generator and back), moves are max_visit_child (tictactoe.py:117, gomoku.py:146)
+            import azk
+            eng = azk.Engine(cls.engine_name, 1, mcts_iter, size=cls._size())
+            st = np.random.get_state()
+            res = self_play_batch(cls.engine_name, None, 1, mcts_iter, size=cls._size(), engine=eng,
+                                  vanilla_rng=azk.mt_state_from_numpy(st)[None])[0]
+            np.random.set_state(azk.mt_state_to_numpy(eng.vanilla_get_rng()[0], st))
+            eng.close()
+        else:
+            seed = int(np.random.randint(0, 2 ** 31 - 1))
+            res = self_play_batch(cls.engine_name, model, 1, mcts_iter, size=cls._size(), seed=seed)[0]
         self.board = res.boards[-1].copy()
         last = res.actions[-1]
         cls.make_move(self.board, (len(res.boards) - 1) % 2, last)

@@ -41,7 +41,7 @@ class SelfPlayResult:
 
 def self_play_batch(game, evaluator, n_games, n_sims, size=None, seed=0, first_global_game=0, dirichlet=True,
                     alpha=0.03, noise_fn=None, uniform_fn=None, device=0, leaf_dtype="float32", engine=None,
-                    max_moves=None, sample_until=None, stats=None, replay=None, cache_entries=0):
+                    max_moves=None, sample_until=None, stats=None, replay=None, cache_entries=0, vanilla_rng=None):
     """Play n_games games to the end in one batch.
 
     evaluator(boards[n,F,R,C] CUDA) -> (logits [n,A], values [n] | [n,1]).
@@ -49,6 +49,10 @@ def self_play_batch(game, evaluator, n_games, n_sims, size=None, seed=0, first_g
     keyed by (seed, first_global_game + g, move) - independent of how games are sharded over GPUs.
     noise_fn(move_idx) -> float64 [G, A] and uniform_fn(move_idx) -> float64 [G] (numpy) override it
     (that is how parity tests inject the reference's recorded np.random draws).
+    An evaluator of None plays vanilla MCTS (random rollouts on the device, mcts.py:57-79) - for a whole game
+    (self_play(None, n): greedy moves, tictactoe.py:117 / gomoku.py:146) or for one side of an (ev0, ev1) pair
+    (test.compare(Game, None, model, ...), main.py:76).  vanilla_rng: uint32 [G, 625] MT19937 states (default: one
+    np.random.RandomState per global game index derived from `seed`).
     """
     import torch
     max_sims = max(n_sims) if isinstance(n_sims, (tuple, list)) else n_sims
@@ -59,6 +63,16 @@ def self_play_batch(game, evaluator, n_games, n_sims, size=None, seed=0, first_g
     results = [SelfPlayResult() for _ in range(G)]
     active = np.ones(G, bool)
     su = SAMPLE_UNTIL[game] if sample_until is None else sample_until
+    evs = list(evaluator) if isinstance(evaluator, (tuple, list)) else [evaluator]
+    if any(e is None for e in evs):
+        if vanilla_rng is None:
+            from azk import mt_state_from_numpy
+            vanilla_rng = np.stack([mt_state_from_numpy(np.random.RandomState(
+                (int(seed) * 2654435761 + first_global_game + g) % (1 << 32)).get_state()) for g in range(G)])
+        eng.vanilla_set_rng(vanilla_rng)
+        if evaluator is None and sample_until is None:
+            su = 0                                                # model=None: max_visit_child every move
+    vanilla_chunk = 64 if eng.rows * eng.cols > 64 else None     # bounds one launch's run time on the big boards
     move = 0
     while active.any():
         if noise_fn is not None:
@@ -72,7 +86,10 @@ def self_play_batch(game, evaluator, n_games, n_sims, size=None, seed=0, first_g
         # an (evaluator0, evaluator1) pair plays the two sides (test.compete, test.py:79-84); all games are at the same ply
         ev = evaluator[move & 1] if isinstance(evaluator, (tuple, list)) else evaluator
         ns = n_sims[move & 1] if isinstance(n_sims, (tuple, list)) else n_sims
-        eng.search(ev, ns, noise if dirichlet else None)
+        if ev is None:
+            eng.vanilla_search(ns, chunk=vanilla_chunk)
+        else:
+            eng.search(ev, ns, noise if dirichlet else None)
         pi, q, _ = eng.root_stats()
         cells_before, to_move, _ = eng.get_positions()
         chosen, winner, done = eng.advance(uni, su)

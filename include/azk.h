@@ -252,6 +252,18 @@ int32_t azk_nn_cls_pool(const void *xhat_bf16_dev, const float *scores_dev, cons
                         int32_t n, int32_t tokens, int32_t embed_dim, int32_t num_heads, const int32_t *n_valid_dev,
                         void *stream);
 
+/* ---- vanilla mode: MCTS.mcts(model=None, ...) (mcts.py:57-59), MCTS.simulate (mcts.py:62-79), UCB1 of
+ * utils.py:29-44 mode 'normal'.  A search is azk_begin_search(e, NULL) followed by azk_vanilla_search calls summing to
+ * n simulations (each launch runs its simulations - select, expand, random rollout, backup - entirely on the device);
+ * results are read with azk_root_stats / azk_root_children / azk_export_tree / azk_advance as in network mode.
+ * Random numbers: np.random.randint of the legacy global RandomState, i.e. MT19937 + numpy's masked rejection, on one
+ * MT19937 state per game: 625 uint32 = the 624 key words and the position, the layout of np.random.get_state()[1:3].
+ * Seeding a game with the caller's np.random state makes the search consume exactly the reference's stream; the state
+ * read back is what np.random.set_state() needs afterwards.  Default states: init_genrand(5489 + game). */
+int32_t azk_vanilla_set_rng(azk_engine *e, int32_t first, int32_t count, const uint32_t *mt_states_host, void *stream);
+int32_t azk_vanilla_get_rng(azk_engine *e, int32_t first, int32_t count, uint32_t *mt_states_host, void *stream);  /* synchronises */
+int32_t azk_vanilla_search(azk_engine *e, int32_t n_sims, void *stream);
+
 /* nn.LayerNorm over the rows of a bf16 matrix [n][embed_dim] (norm2 / norm of nn.py:41-42,78; fp32 statistics) -> y;
  * with add_bias_dev != NULL the rows of x are also replaced by x + add_bias (the residual the next GEMM accumulates
  * onto, nn.py:59-60).  embed_dim in {128, 256, 512}. */

@@ -102,3 +102,58 @@ def test_gomoku_self_play_returns_the_reference_tuple():
     assert all(abs(p.sum() - 1) < 1e-12 for p in pis) and actions[1] == (3, 3)
     for i in range(1, len(boards)):                                 # raw boards, one more stone each ply
         assert boards[i].sum() == i
+
+
+@pytest.mark.parametrize("gi", [6, 7])
+def test_vanilla_self_play_like_a_reference_caller(gi):
+    """np.random.seed(s); Game().self_play(None, n) - the reference's own vanilla call (config 1 of BASELINE.json) -
+    returns the reference's game bit for bit AND leaves np.random where the reference leaves it."""
+    from games import Connect4, TicTacToe
+    z = load_golden("games.npz")
+    m = next(x for x in golden_meta(z) if x["game"] == gi)
+    Game = {"tictactoe": TicTacToe, "connect4": Connect4}[m["name"]]
+    k = f"g{gi}_"
+    np.random.seed(m["seed"])
+    boards, pis, winner = Game().self_play(None, m["n_sims"])
+    assert winner == m["winner"] and len(boards) == m["n_moves"]
+    assert np.stack(pis).tobytes() == z[k + "pis"].tobytes()
+    got_cells = np.stack([(b[0] + 2 * b[1]).astype(np.int8).reshape(-1) for b in boards])
+    assert np.array_equal(got_cells, z[k + "board_cells"])
+    after = np.random.randint(1 << 30)
+    rs = np.random.RandomState(m["seed"])
+    for n, val in z[k + "randints"]:
+        assert rs.randint(int(n)) == val
+    assert after == rs.randint(1 << 30)
+    if gi == 6:     # SURVEY 8(c): first-move pi of the seed-0 TicTacToe 25-sim vanilla game observed on the reference
+        np.testing.assert_allclose(pis[0], [.1667, .125, .0417, .0417, .375, .0417, .0417, .0833, .0833], atol=5e-5)
+
+
+def test_vanilla_mcts_mcts_reference_signature():
+    """MCTS.mcts(None, board, root, Game, n): root mutated like the reference's (children order, visit, value, prior 0)."""
+    from ai import MCTS, Node
+    from games import Gomoku
+    from oracle import az_oracle as ao
+    Gomoku.rows = Gomoku.cols = 7
+    Gomoku.action_dim = Gomoku.state_dim = 49
+    g = Gomoku()
+    player = 0
+    for mv in [(3, 3), (2, 4), (4, 4), (3, 5)]:
+        player = Gomoku.make_move(g.board, player, mv)
+    before = g.board.copy()
+    og = ao.OracleGame("gomoku", 7)
+    tree = ao.OracleTree(og, cap=1 + 90 * 49)
+    tree.reset(player, 4)
+    rs = np.random.RandomState(21)
+    ob = before.copy()
+    ao.mcts(og, tree, ob, 90, None, None, None, lambda n: int(rs.randint(n)))
+    np.random.seed(21)
+    root = Node(None, None, player, 4)
+    MCTS.mcts(None, g.board, root, Gomoku, 90)
+    assert np.array_equal(g.board, before)
+    want = tree.root_children()
+    assert [og.cell(c.prevAction) for c in root.children] == want["cell"].tolist()
+    assert [c.visit for c in root.children] == want["visit"].tolist()
+    assert [c.value for c in root.children] == want["value"].tolist()
+    assert all(c.prior == 0.0 for c in root.children)
+    assert root.visit == 90 and root.value == tree.root_value
+    assert np.random.randint(1 << 30) == rs.randint(1 << 30)

@@ -56,3 +56,17 @@ def test_self_play_bit_exact(m):
         assert out["qs"].tobytes() == _Z[k + "qs"].tobytes()
     assert ui[0] == len(uniforms) and ri[0] == len(randints)
     assert (cnt.mcts_count, cnt.matched, cnt.evals) == (m["mcts_count"], m["matched"], m["evals"])
+
+
+@pytest.mark.parametrize("m", [x for x in _META if not x["variant"]], ids=lambda m: f"g{m['game']}-{m['name']}")
+def test_vanilla_games_consume_only_the_seeded_randint_stream(m):
+    """The vanilla games are a pure function of np.random.seed(seed): RandomState(seed).randint replays the recorded
+    draws one for one, so the seed (not the draw tape) is enough to pin the GPU's own MT19937 + masked-rejection path."""
+    k = f"g{m['game']}_"
+    rs = np.random.RandomState(m["seed"])
+    for n, val in _Z[k + "randints"]:
+        assert rs.randint(int(n)) == val
+    game = ao.OracleGame(m["name"], m["size"] or None)
+    rs = np.random.RandomState(m["seed"])
+    out = ao.self_play(game, None, m["n_sims"], randint=lambda n: int(rs.randint(n)))
+    assert out["winner"] == m["winner"] and out["pis"].tobytes() == _Z[k + "pis"].tobytes()
