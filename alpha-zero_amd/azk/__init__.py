@@ -26,7 +26,7 @@ SYMBOLS = [
     "azk_rules_legal_moves", "azk_rules_legal_mask", "azk_rules_apply_move", "azk_rules_undo_move",
     "azk_rules_check_winner", "azk_rules_canonical", "azk_softmax_rows",
     "azk_step_tree", "azk_step_gather", "azk_recycle_finished", "azk_nn_patch_embed", "azk_nn_cls_attention", "azk_nn_patch_embed_scores", "azk_nn_cls_pool", "azk_debug_stamps", "azk_emit_finished", "azk_clear_cache", "azk_nn_heads_finalize", "azk_nn_layernorm_rows",
-    "azk_vanilla_set_rng", "azk_vanilla_get_rng", "azk_vanilla_search",
+    "azk_vanilla_set_rng", "azk_vanilla_get_rng", "azk_vanilla_search", "azk_nn_embed_pool",
 ]
 
 
@@ -117,6 +117,7 @@ def lib():
     L.azk_step_gather.argtypes = [vp, vp, vp, vp]
     L.azk_recycle_finished.argtypes = [vp, vp, vp]
     L.azk_nn_patch_embed_scores.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, C.c_float, vp, vp]
+    L.azk_nn_embed_pool.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, C.c_float, vp, vp]
     L.azk_nn_layernorm_rows.argtypes = [vp, vp, vp, C.c_float, vp, vp, i32, i32, vp, vp]
     L.azk_nn_heads_finalize.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp]
     L.azk_nn_cls_pool.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]
@@ -499,6 +500,29 @@ def nn_embed_scores_pool(boards, wt_ext, cpos, score_cpos, score_msum, c, rows, 
         timers[1].stop()
     if rc != 0:
         raise AzkError(f"azk_nn_cls_pool failed ({rc})")
+    return z
+
+
+def nn_embed_pool(boards, wt_ext, cpos_frag, score_frag, score_msum, score_ref, rows, cols, ksize, embed_dim, num_heads,
+                  eps=1e-5, count=None, timers=None):
+    """Depth-1 folded cls attention in ONE launch (azk_nn_embed_pool): boards -> z bf16 [n, H, D]; tokens never reach HBM.
+    cpos_frag / score_frag: per-token constants padded to whole 16-token tiles, in accumulator order (include/azk.h);
+    score_ref: [16] static softmax reference per head or None (running maximum)."""
+    torch = _torch()
+    assert boards.is_cuda and boards.is_contiguous() and boards.dtype in (torch.bfloat16, torch.float32)
+    Tp = (rows * cols + 1 + 15) // 16 * 16
+    assert cpos_frag.numel() == Tp * embed_dim and score_frag.numel() == Tp * 16 and cpos_frag.is_contiguous() and score_frag.is_contiguous()
+    n, C = boards.shape[0], boards.shape[1]
+    z = torch.empty((n, num_heads, embed_dim), dtype=torch.bfloat16, device=boards.device)
+    if timers is not None:
+        timers[0].start()
+    rc = lib().azk_nn_embed_pool(_p(boards), 1 if boards.dtype == torch.float32 else 0, _p(wt_ext), _p(cpos_frag),
+                                 _p(score_frag), _p(score_msum), _p(score_ref), _p(z), num_heads, n, C, rows, cols, ksize,
+                                 wt_ext.shape[1], embed_dim, float(eps), _p(count), _stream())
+    if timers is not None:
+        timers[0].stop()
+    if rc != 0:
+        raise AzkError(f"azk_nn_embed_pool failed ({rc})")
     return z
 
 

@@ -766,3 +766,286 @@ extern "C" int32_t azk_nn_layernorm_rows(void *x_bf16_dev, const float *w_dev, c
     else k_ln_rows<2><<<grid, block, 0, st>>>(x, w_dev, b_dev, eps, y, add_bias_dev, n, n_valid_dev);
     return hipGetLastError() == hipSuccess ? AZK_OK : AZK_ERR_HIP;
 }
+
+
+// =====================================================================================================
+// k_embed_pool: patch embedding + LayerNorm1 + folded cls attention (scores, softmax over tokens, weighted token sum)
+// in ONE kernel - the normalised tokens never leave the CU (nn.py:13-36, 52-56 restricted to the cls query).
+//   One workgroup (4 waves) per board; wave w owns the 128 output columns [128 w, 128 w + 128) of every 16-token tile
+//   (8 MFMA accumulators) and recomputes the 16 extra columns (heads' raw scores, and column 15 = the row mean).  Per tile:
+//     x tile (MFMA 16x16x32; accumulators start at bias + positional embedding; A fragments = a 256-entry LDS table
+//     indexed by 8 patch bits)
+//     -> per-row sum of squares over the wave's columns -> LDS -> one barrier -> LayerNorm statistics of the full row
+//     -> scores s[t][h] = rstd_t (x_t . m'_h - mean_t sum(m'_h)); weights w = exp(s - ref_h): ref_h is either a static
+//        upper bound (|s| <= sqrt(D) |m'_h|, used when it cannot underflow) or the running maximum (online softmax)
+//     -> Z[h][cols] += sum_t w[t][h] xn[t][cols] as MFMA 16x16x16: the A operand (weights: head = lane&15, tokens
+//        4 (lane>>4) + r) and the B operand (normalised tile: column = lane&15, same tokens) are exactly the C/D layout
+//        the score and x accumulators already have, so nothing moves between lanes.
+//   Output z[b][h][:] = Z[h][:] / L[h]  ([n][H][D] bf16).  No HBM traffic besides the board, the (L2-resident) constants
+//   and 8 KB of output per board.  The per-token constants are padded to whole tiles by the caller: padding rows of
+//   cpos are 0 and padding rows of the score columns are -1e30, which makes their softmax weight exactly 0.
+// =====================================================================================================
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+
+// four floats -> the 4 x bf16 operand of v_mfma_f32_16x16x16_bf16 with two v_cvt_pk_bf16_f32
+__device__ __forceinline__ s16x4 pack4_bf16(f32x2 lo, f32x2 hi) {
+    const u32x2 p = {__builtin_bit_cast(unsigned, __builtin_convertvector(lo, bf16x2)), __builtin_bit_cast(unsigned, __builtin_convertvector(hi, bf16x2))};
+    return __builtin_bit_cast(s16x4, p);
+}
+
+struct EmbedPoolArgs {
+    const void *boards;
+    int boards_f32;
+    const __hip_bfloat16 *wt;   // [D + 16][KP]: conv weight rows, then the 16 extra rows (head scores; row 15 = column mean)
+    const float *cpos;          // accumulator order [tiles][4 waves][8][64 lanes][4 rows]: cpos[16 tile + 4 (lane>>4) + r][128 wave + 8 (lane&15) + q], rows >= T zero
+    const float *mtab;          // accumulator order [tiles][64 lanes][4 rows]: score constants [16 tile + 4 (lane>>4) + r][lane&15]; rows >= T: -1e30 in the head columns
+    const float *msum;          // [16]
+    const float *sref;          // [16] static per-head reference (upper bound of the scores) or null = running maximum
+    __hip_bfloat16 *z;          // [n][NH][D]
+    const int *count;
+    int n, C, R, Cc, ksz, T;
+    float eps;
+};
+
+template <int KS, int NH, bool STATIC_REF>
+__global__ __launch_bounds__(256, 2) void k_embed_pool(EmbedPoolArgs a) {
+    constexpr int D = 512, KP = 32 * KS, NACC = 32, NTILE = NACC + 1;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint4 *bimg = (uint4 *)smem;                                  // [NTILE][KS][64] 16-byte B fragments
+    float *part = (float *)(smem + NTILE * KS * 64 * 16);         // [2 parities][16 rows][4 waves] partial sums of squares
+    uint4 *alut = (uint4 *)(smem + NTILE * KS * 64 * 16 + 512);   // [256] A fragment of 8 patch bits (bit q -> bf16 1.0 in slot q)
+    uint4 *pbits = alut + 256;                                    // [Tp] patch bits per token (<= 128 bits)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int nvalid = a.count ? min(a.n, *a.count) : a.n;
+    if ((int)blockIdx.x >= nvalid) return;
+
+    for (int f = tid; f < NTILE * KS * 64; f += 256) {
+        const int l = f & 63, s = (f >> 6) % KS, acc = (f >> 6) / KS;
+        const int col = acc < NACC ? 128 * (acc >> 3) + 8 * (l & 15) + (acc & 7) : D + (l & 15);
+        bimg[f] = *(const uint4 *)(a.wt + (size_t)col * KP + 32 * s + 8 * (l >> 4));
+    }
+    {
+        unsigned r[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) r[i] = (((tid >> (2 * i)) & 1) ? 0x3F80u : 0u) | (((tid >> (2 * i + 1)) & 1) ? 0x3F800000u : 0u);
+        alut[tid] = make_uint4(r[0], r[1], r[2], r[3]);
+    }
+    __syncthreads();
+
+    const int RC = a.R * a.Cc, T = a.T, ksz = a.ksz, kk = ksz * ksz, pad = ksz / 2, ncell = a.C * RC;
+    const int tiles = (T + 15) >> 4;
+    const float msum = a.msum[l15];
+    const float sref = STATIC_REF ? a.sref[l15] : 0.f;
+    const bool headlane = l15 < NH;
+    const f32x4 *cbase = (const f32x4 *)a.cpos + (size_t)wave * 8 * 64 + lane;
+    const f32x4 *mbase = (const f32x4 *)a.mtab + lane;
+    int par = 0;
+
+    for (int leaf = blockIdx.x; leaf < nvalid; leaf += gridDim.x) {
+        unsigned wbits = 0;                             // lane i holds bits [32 (i-1), 32 i) of the board bit string (lane 0: zeros)
+        for (int q = 0; q * 64 < ncell; q++) {
+            const int e = q * 64 + lane;
+            bool on = false;
+            if (e < ncell)
+                on = a.boards_f32 ? ((const float *)a.boards)[(size_t)leaf * ncell + e] != 0.0f
+                                  : (((const unsigned short *)a.boards)[(size_t)leaf * ncell + e] & 0x7fff) != 0;
+            const unsigned long long m = __ballot(on);
+            if ((lane - 1) >> 1 == q && lane >= 1) wbits = ((lane - 1) & 1) ? (unsigned)(m >> 32) : (unsigned)m;
+        }
+        // ---- patch bits of every token, once per board: token = wave * 64 + lane (+ 256 per round) ----
+        for (int t0 = 0; t0 < tiles * 16; t0 += 256) {
+            const int t = t0 + wave * 64 + lane;
+            unsigned long long plo = 0, phi = 0;
+            const int j = t - 1, r = j / a.Cc, c = j - r * a.Cc;
+            const bool live = t >= 1 && t < T;
+            unsigned colmask = 0;
+            for (int kx = 0; kx < ksz; kx++) { const int cc = c + kx - pad; if (cc >= 0 && cc < a.Cc) colmask |= 1u << kx; }
+            for (int ch = 0; ch < a.C; ch++)
+                for (int ky = 0; ky < ksz; ky++) {
+                    const int rr = r + ky - pad;
+                    // every lane takes part in the shuffles; dead rows contribute zero bits
+                    int off = 32 + ch * RC + (rr < 0 ? 0 : (rr >= a.R ? a.R - 1 : rr)) * a.Cc + (c - pad);
+                    if (!live) off = 32;
+                    const int wi = off >> 5, sh = off & 31;
+                    const unsigned lo = __shfl(wbits, wi), hi = __shfl(wbits, wi + 1);
+                    unsigned bits = __funnelshift_r(lo, hi, sh) & colmask;
+                    if (!live || rr < 0 || rr >= a.R) bits = 0;
+                    const int p0 = ch * kk + ky * ksz;
+                    if (p0 < 64) { plo |= (unsigned long long)bits << p0; if (p0 + ksz > 64) phi |= (unsigned long long)bits >> (64 - p0); }
+                    else phi |= (unsigned long long)bits << (p0 - 64);
+                }
+            if (t < tiles * 16) pbits[t] = make_uint4((unsigned)plo, (unsigned)(plo >> 32), (unsigned)phi, (unsigned)(phi >> 32));
+        }
+        __syncthreads();
+        f32x4 Z[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) Z[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float M = -INFINITY, L = 0.f;                   // per head (lane&15 < NH); L is this lane>>4 group's share
+
+        const f32x4 *cp = cbase;
+        const f32x4 *mp = mbase;
+        for (int tile = 0; tile < tiles; tile++, cp += 4 * 8 * 64, mp += 64) {
+            // ---- accumulators: rows 4 (lane>>4) + r4, columns 128 wave + 8 (lane&15) + q; the constants are stored in
+            //      this very order, so each accumulator is one 16-byte load, 1 KB contiguous per wave ----
+            f32x4 acc[8], acce = *mp;
+#pragma unroll
+            for (int q = 0; q < 8; q++) acc[q] = cp[q * 64];
+            // ---- A fragments: 8 patch bits of this lane's token (row lane&15) per k-step -> table ----
+            const uint4 pb = pbits[tile * 16 + l15];
+            const unsigned pw[4] = {pb.x, pb.y, pb.z, pb.w};
+            bf16x8 afrag[KS];
+#pragma unroll
+            for (int s = 0; s < KS; s++) {
+                union { uint4 u; bf16x8 v; } af;
+                af.u = alut[(pw[s] >> (8 * l4)) & 0xffu];
+                afrag[s] = af.v;
+            }
+#pragma unroll
+            for (int s = 0; s < KS; s++) {
+                union { uint4 u; bf16x8 v; } bf;
+                bf.u = bimg[(NACC * KS + s) * 64 + lane];
+                acce = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[s], bf.v, acce, 0, 0, 0);
+            }
+#pragma unroll
+            for (int s = 0; s < KS; s++)
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    union { uint4 u; bf16x8 v; } bf;
+                    bf.u = bimg[((8 * wave + q) * KS + s) * 64 + lane];
+                    acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[s], bf.v, acc[q], 0, 0, 0);
+                }
+            // ---- LayerNorm statistics of the full rows.  The mean is GEMM column 15 of the extra tile; only the sum of
+            //      squares needs this wave's 128 columns -> LDS -> all four waves ----
+            float mean[4];
+#pragma unroll
+            for (int r4 = 0; r4 < 4; r4++) mean[r4] = __shfl(acce[r4], (lane & 48) | 15);
+            f32x2 q01 = {0.f, 0.f}, q23 = {0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const f32x2 lo = {acc[q][0], acc[q][1]}, hi = {acc[q][2], acc[q][3]};
+                q01 = __builtin_elementwise_fma(lo, lo, q01);
+                q23 = __builtin_elementwise_fma(hi, hi, q23);
+            }
+            const float pss[4] = {row16_sum(q01[0]), row16_sum(q01[1]), row16_sum(q23[0]), row16_sum(q23[1])};
+            if (l15 == 0) {
+#pragma unroll
+                for (int r4 = 0; r4 < 4; r4++) part[(par * 16 + 4 * l4 + r4) * 4 + wave] = pss[r4];
+            }
+            __syncthreads();
+            float rstd[4], shift[4];
+#pragma unroll
+            for (int r4 = 0; r4 < 4; r4++) {
+                const f32x4 p = *(const f32x4 *)(part + (par * 16 + 4 * l4 + r4) * 4);
+                const float s2 = (p[0] + p[1]) + (p[2] + p[3]);
+                const float var = fmaxf(s2 * (1.0f / (float)D) - mean[r4] * mean[r4], 0.f);
+                rstd[r4] = __builtin_amdgcn_rsqf(var + a.eps);
+                shift[r4] = -mean[r4] * rstd[r4];
+            }
+            par ^= 1;
+            // ---- scores (head = lane&15, tokens 4 (lane>>4) + r4) and softmax weights; lanes >= NH carry harmless finite
+            //      values into rows of Z that are never stored ----
+            float sc[4], w[4];
+#pragma unroll
+            for (int r4 = 0; r4 < 4; r4++) sc[r4] = rstd[r4] * (acce[r4] - mean[r4] * msum);
+            if (STATIC_REF) {
+#pragma unroll
+                for (int r4 = 0; r4 < 4; r4++) w[r4] = __expf(sc[r4] - sref);
+            } else {
+                float tmax = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
+                tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
+                tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+                const float Mn = fmaxf(M, tmax);
+                const float f = __expf(M - Mn);                       // M = -inf on the first tile: f = 0 (Z and L are 0)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; r4++) w[r4] = __expf(sc[r4] - Mn);
+                L *= f;
+                M = Mn;
+                if (__ballot(headlane && f != 1.0f) != 0ull) {        // some head's running maximum moved: rescale its Z rows
+                    float fr[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) fr[j] = l4 < 2 ? __shfl(f, 4 * l4 + j) : 1.0f;   // rows of Z = heads 4 (lane>>4) + j
+#pragma unroll
+                    for (int q = 0; q < 8; q++)
+#pragma unroll
+                        for (int j = 0; j < 4; j++) Z[q][j] *= fr[j];
+                }
+            }
+            L += (w[0] + w[1]) + (w[2] + w[3]);
+            // ---- Z += W^T Xn : A = weights (bf16), B = normalised tile (bf16), both already in operand layout ----
+            const s16x4 wa = pack4_bf16(f32x2{w[0], w[1]}, f32x2{w[2], w[3]});
+            const f32x2 r01 = {rstd[0], rstd[1]}, r23 = {rstd[2], rstd[3]}, h01 = {shift[0], shift[1]}, h23 = {shift[2], shift[3]};
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const f32x2 lo = {acc[q][0], acc[q][1]}, hi = {acc[q][2], acc[q][3]};
+                const f32x2 vlo = __builtin_elementwise_fma(lo, r01, h01), vhi = __builtin_elementwise_fma(hi, r23, h23);   // (x - mean) * rstd
+                Z[q] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wa, pack4_bf16(vlo, vhi), Z[q], 0, 0, 0);
+            }
+        }
+        // ---- z[b][h][:] = Z[h][:] / L[h] ----
+        float Lt = L + __shfl_xor(L, 16);
+        Lt += __shfl_xor(Lt, 32);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int head = 4 * l4 + j;
+            const float Lh = __shfl(Lt, head & 15);
+            if (head < NH) {
+                const float inv = 1.0f / Lh;
+                float v[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) v[q] = Z[q][j] * inv;
+                *(uint4 *)(a.z + ((size_t)leaf * NH + head) * D + 128 * wave + 8 * l15) = pack8(v);
+            }
+        }
+    }
+}
+
+template <int KS, int NH, bool SR>
+int launch_embed_pool2(const EmbedPoolArgs &a, hipStream_t st) {
+    const int lds = 33 * KS * 64 * 16 + 512 + 256 * 16 + ((a.T + 15) / 16) * 16 * 16;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void *)k_embed_pool<KS, NH, SR>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return AZK_ERR_HIP;
+        attr_set = true;
+    }
+    const int blocks = a.n < 512 ? a.n : 512;                      // two resident workgroups per CU, each walks its boards
+    k_embed_pool<KS, NH, SR><<<blocks, 256, lds, st>>>(a);
+    return hipGetLastError() == hipSuccess ? AZK_OK : AZK_ERR_HIP;
+}
+
+template <int KS, int NH>
+int launch_embed_pool(const EmbedPoolArgs &a, hipStream_t st) {
+    return a.sref ? launch_embed_pool2<KS, NH, true>(a, st) : launch_embed_pool2<KS, NH, false>(a, st);
+}
+}  // namespace
+
+extern "C" int32_t azk_nn_embed_pool(const void *boards_dev, int32_t boards_are_f32, const void *wt_ext_bf16_dev,
+                                     const float *cpos_frag_dev, const float *score_frag_dev, const float *score_msum_dev,
+                                     const float *score_ref_dev, void *z_out_bf16_dev, int32_t num_heads, int32_t n,
+                                     int32_t channels, int32_t rows, int32_t cols, int32_t ksize, int32_t kp, int32_t embed_dim,
+                                     float ln_eps, const int32_t *n_valid_dev, void *stream) {
+    if (!boards_dev || !wt_ext_bf16_dev || !cpos_frag_dev || !score_frag_dev || !score_msum_dev || !z_out_bf16_dev) return AZK_ERR_ARG;
+    if (n < 0 || channels < 1 || rows < 1 || cols < 1 || ksize < 1 || (ksize & 1) == 0 || ksize > 7) return AZK_ERR_ARG;
+    if (kp < channels * ksize * ksize || kp % 32 != 0 || kp > 96) return AZK_ERR_ARG;
+    if (channels * rows * cols > 62 * 32 || embed_dim != 512) return AZK_ERR_ARG;      // one column group per wave, four waves
+    if (num_heads != 8 && num_heads != 4) return AZK_ERR_ARG;
+    if (n == 0) return AZK_OK;
+    EmbedPoolArgs a;
+    a.boards = boards_dev; a.boards_f32 = boards_are_f32; a.wt = (const __hip_bfloat16 *)wt_ext_bf16_dev; a.cpos = cpos_frag_dev;
+    a.mtab = score_frag_dev; a.msum = score_msum_dev; a.sref = score_ref_dev; a.z = (__hip_bfloat16 *)z_out_bf16_dev;
+    a.count = n_valid_dev;
+    a.n = n; a.C = channels; a.R = rows; a.Cc = cols; a.ksz = ksize; a.T = rows * cols + 1; a.eps = ln_eps;
+    hipStream_t st = (hipStream_t)stream;
+    const int ks = kp / 32;
+#define CASE(KS_, NH_) if (ks == KS_ && num_heads == NH_) return launch_embed_pool<KS_, NH_>(a, st)
+    CASE(2, 8); CASE(1, 8); CASE(3, 8); CASE(2, 4); CASE(1, 4); CASE(3, 4);
+#undef CASE
+    return AZK_ERR_ARG;
+}

@@ -117,6 +117,7 @@ class PolicyValueNet:
         self.fast_outputs = False   # True: logits may come back as a bf16 view (the caller converts while copying)
         self.last_value_pre_tanh = False
         self.out_buffers = None     # optional (logits f32 [n,A], values f32 [n]) the fast tail writes into directly
+        self.fused_embed_pool = False   # set by _prepare_folded when azk_nn_embed_pool covers this configuration
         self.kernel_timers = None   # optional (embed_timer, pool_timer) with start()/stop(): HIP-event timing of the two kernels
         self.live_count = None      # optional int32 CUDA tensor: number of valid rows at the head of the batch (graph stepping)
         self.to(device, dtype)
@@ -179,13 +180,34 @@ class PolicyValueNet:
             wt_ext = torch.zeros(D + 16, hp["wt"].shape[1], device=dev)
             wt_ext[:D] = hp["wt"].float()
             wt_ext[D:D + H, :kreal] = f["m_n"] @ Wc
+            wt_ext[D + 15] = hp["wt"].float().mean(0)            # column 15: the row mean (1/D) sum_d x[t][d] as a GEMM output
             f["wt_ext"] = wt_ext.to(torch.bfloat16).contiguous()
             sc = torch.zeros(cfg.tokens, 16, device=dev)
             sc[:, :H] = hp["cpos"] @ f["m_n"].t()
+            sc[:, 15] = hp["cpos"].mean(1)
             f["score_cpos"] = sc.contiguous()
             ms = torch.zeros(16, device=dev)
             ms[:H] = f["m_n"].sum(1)
             f["score_msum"] = ms
+            # operands of the fused kernel (azk_nn_embed_pool): per-token constants padded to whole 16-token tiles
+            Tp = (cfg.tokens + 15) // 16 * 16
+            cp = torch.zeros(Tp, D, device=dev)
+            cp[:cfg.tokens] = hp["cpos"]
+            scp = torch.zeros(Tp, 16, device=dev)
+            scp[:cfg.tokens] = sc
+            scp[cfg.tokens:, :H] = -1e30                           # padding tokens: softmax weight exactly 0
+            # ... stored in the kernel's accumulator order (one 16-byte load per accumulator, 1 KB contiguous per wave):
+            #   cpos_frag [tile][wave][q][lane = 16 l4 + l15][r] = cpos[16 tile + 4 l4 + r][128 wave + 8 l15 + q]
+            #   score_frag [tile][lane][r]                        = score constants [16 tile + 4 l4 + r][l15]
+            nt = Tp // 16
+            f["cpos_frag"] = cp.view(nt, 4, 4, D // 128, 16, 8).permute(0, 3, 5, 1, 4, 2).contiguous()
+            f["score_frag"] = scp.view(nt, 4, 4, 16).permute(0, 1, 3, 2).contiguous()
+            # |xn . m'| <= |xn| |m'| <= sqrt(D) |m'|: a static softmax reference, usable while exp(-2 bound) is a normal float
+            bound = math.sqrt(D) * f["m_n"].norm(dim=1)
+            ref = torch.zeros(16, device=dev)
+            ref[:H] = bound
+            f["score_ref"] = ref if float(bound.max()) <= 40.0 else None
+            self.fused_embed_pool = D == 512 and H in (4, 8) and hp["wt"].shape[1] <= 96
             Wv = Wi[2 * D:].reshape(H, dh, D).to(dev)
             f["WvT_n"] = (Wv * g).transpose(1, 2).contiguous().to(torch.bfloat16)                      # [H, D, dh]
             f["bv_n"] = (bi[2 * D:].to(dev) + (Wv @ bta).reshape(-1)).to(torch.bfloat16)
@@ -378,9 +400,15 @@ class PolicyValueNet:
                 if self.cfg.num_heads in (4, 8):
                     if x.dtype not in (torch.bfloat16, torch.float32):
                         x = x.float()
-                    z = azk.nn_embed_scores_pool(x.contiguous(), f["wt_ext"], hp["cpos"], f["score_cpos"], f["score_msum"], f["c_n"],
-                                                 self.cfg.rows, self.cfg.cols, self.cfg.patch_size, self.cfg.embed_dim,
-                                                 self.cfg.num_heads, count=self.live_count, timers=self.kernel_timers)
+                    if self.fused_embed_pool:
+                        # one launch: the normalised tokens never reach HBM (azk_nn_embed_pool)
+                        z = azk.nn_embed_pool(x.contiguous(), f["wt_ext"], f["cpos_frag"], f["score_frag"], f["score_msum"],
+                                              f["score_ref"], self.cfg.rows, self.cfg.cols, self.cfg.patch_size, self.cfg.embed_dim,
+                                              self.cfg.num_heads, count=self.live_count, timers=self.kernel_timers)
+                    else:
+                        z = azk.nn_embed_scores_pool(x.contiguous(), f["wt_ext"], hp["cpos"], f["score_cpos"], f["score_msum"], f["c_n"],
+                                                     self.cfg.rows, self.cfg.cols, self.cfg.patch_size, self.cfg.embed_dim,
+                                                     self.cfg.num_heads, count=self.live_count, timers=self.kernel_timers)
                     return self.tail_fast(z)
                 x0 = hp["cpos"][0].to(self.dtype).expand(x.shape[0], -1)
                 _, xhat = self.embed_hip(x, want_x=False, want_xhat=True)

@@ -253,7 +253,12 @@ class SelfPlayRunner:
             self.evaluator.live_count = e.n_leaf
             self.evaluator.fast_outputs = True
         if hasattr(self.evaluator, "kernel_timers"):
-            self.evaluator.kernel_timers = (timer.child("k_embed"), timer.child("k_cls_pool")) if timer is not None else None
+            if timer is None:
+                self.evaluator.kernel_timers = None
+            elif getattr(self.evaluator, "fused_embed_pool", False):
+                self.evaluator.kernel_timers = (timer.child("k_embed_pool"),)
+            else:
+                self.evaluator.kernel_timers = (timer.child("k_embed"), timer.child("k_cls_pool"))
         if hasattr(self.evaluator, "out_buffers"):
             self.evaluator.out_buffers = (h.logits_buf, h.values_buf)
         logits, values = self.evaluator(e.leaf_boards)

@@ -31,6 +31,7 @@ for p in (ROOT, os.path.join(ROOT, "alpha-zero_amd"), os.path.join(ROOT, "tests"
     if p not in sys.path:
         sys.path.insert(0, p)
 
+MFMA_BF16_PEAK_TFLOPS = 2500.0      # dense bf16 MFMA peak, MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 BF16_PEAK_TFLOPS = 2500.0      # dense bf16 MFMA
 
@@ -186,6 +187,17 @@ def main():
                                 "frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_launch_us": ms * 1e3, "algorithmic_bytes_per_launch": by,
                                 "traffic": None, "event_samples": len(ch.pairs),
                                 "note": f"{per_board} B per live board x {live:.0f} live boards per launch (device-side count)"})
+        ch = kt.children.get("k_embed_pool")            # fused embedding + cls pooling: on-chip, priced against the dense bf16 MFMA peak
+        ms = ch.mean_ms() if ch else None
+        if ms:
+            kreal = cfg.channels * cfg.patch_size ** 2
+            per_board = 2 * (T_tok - 1) * Dm * kreal + 2 * T_tok * 16 * kreal + 2 * T_tok * cfg.num_heads * Dm
+            fl = per_board * live
+            kernels.append({"kernel": "k_embed_pool", "bound": "mfma", "achieved": fl / (ms * 1e-3) / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS,
+                            "unit": "TFLOP/s", "frac": fl / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, "avg_launch_us": ms * 1e3,
+                            "algorithmic_flops_per_launch": fl, "traffic": None, "event_samples": len(ch.pairs),
+                            "note": f"{per_board} flop per live board (conv + score columns + weighted token sum) x {live:.0f} live boards per launch; "
+                                    "HBM traffic is 9 KB per board (board in, z out): the kernel is bound by VALU/MFMA issue and LDS, not HBM"})
         dominant = max(kernels, key=lambda k: k["avg_launch_us"]) if kernels else None
         flops = {"cls": cfg.flops_cls(), "full": cfg.flops_full(), "clsfold": flops_clsfold(cfg)}[args.nn_path]
         evals = leaves_all if args.no_graph else sims_all      # graph mode evaluates the full fixed-size leaf buffer every step

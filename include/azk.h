@@ -252,6 +252,23 @@ int32_t azk_nn_cls_pool(const void *xhat_bf16_dev, const float *scores_dev, cons
                         int32_t n, int32_t tokens, int32_t embed_dim, int32_t num_heads, const int32_t *n_valid_dev,
                         void *stream);
 
+/* azk_nn_embed_pool - the two calls above fused: the normalised tokens stay on the CU (one workgroup per board, the
+ * LayerNorm statistics cross its four waves through LDS, softmax over the tokens, the weighted token sum as a second
+ * MFMA on the tile while it is still in registers).  Operands as azk_nn_patch_embed_scores, with the per-token constants
+ * padded to whole 16-token tiles (Tp = 16 ceil(T/16) rows; cpos padding rows 0, score-constant padding rows -1e30 in the
+ * head columns and 0 elsewhere) and stored in the kernel's accumulator order:
+ *   cpos_frag_dev  [Tp/16][4][8][64][4]: [tile][w][q][lane][r] = cpos[16 tile + 4 (lane>>4) + r][128 w + 8 (lane&15) + q]
+ *   score_frag_dev [Tp/16][64][4]:       [tile][lane][r]       = score_cpos[16 tile + 4 (lane>>4) + r][lane&15]
+ * Column 15 of the extra weight rows / score constants is the row mean ((1/D) sum_d W[d][k], (1/D) sum_d cpos[t][d]).  score_ref_dev [16] (optional): per-head upper bound of
+ * the scores (sqrt(D) |m'_h|) used as the softmax reference when 2*bound cannot underflow exp(); NULL = running maximum.
+ * The constant c[h] of azk_nn_cls_pool drops out of a softmax over tokens.  embed_dim 512, heads 8 or 4.
+ * z_out [n][H][512] bf16. */
+int32_t azk_nn_embed_pool(const void *boards_dev, int32_t boards_are_f32, const void *wt_ext_bf16_dev,
+                          const float *cpos_frag_dev, const float *score_frag_dev, const float *score_msum_dev,
+                          const float *score_ref_dev, void *z_out_bf16_dev, int32_t num_heads, int32_t n, int32_t channels,
+                          int32_t rows, int32_t cols, int32_t ksize, int32_t kp, int32_t embed_dim, float ln_eps,
+                          const int32_t *n_valid_dev, void *stream);
+
 /* ---- vanilla mode: MCTS.mcts(model=None, ...) (mcts.py:57-59), MCTS.simulate (mcts.py:62-79), UCB1 of
  * utils.py:29-44 mode 'normal'.  A search is azk_begin_search(e, NULL) followed by azk_vanilla_search calls summing to
  * n simulations (each launch runs its simulations - select, expand, random rollout, backup - entirely on the device);

@@ -136,3 +136,42 @@ def test_layernorm_rows_and_heads_finalize_vs_torch_fp32(D):
     azk.nn_heads_finalize(heads, A, lo, vo)
     assert torch.equal(lo, heads[:, :A].float())
     assert (vo - torch.tanh(heads[:, A].float())).abs().max().item() < 1e-6
+
+
+@pytest.mark.parametrize("static_ref", [True, False])
+def test_fused_embed_pool_vs_torch_fp32(static_ref):
+    """azk_nn_embed_pool (embedding + LayerNorm1 + folded cls attention in one launch) against the same computation in plain
+    fp32 PyTorch on the operands the kernel sees (bf16-rounded weights): z = softmax_t(xn . m') @ xn.
+    Tolerance: xn and the softmax weights are rounded to bf16 for the second MFMA, z to bf16 on output: 1e-2 absolute
+    (values are O(0.1)); the two-launch path is checked against the same reference at 6e-2 (its bf16 token round trip)."""
+    import azk
+    cfg = NetConfig(15, 15, 2, 225, 5, 512, 8, 1)
+    net = PolicyValueNet(cfg, seed=5, device="cuda", dtype=torch.bfloat16, path="clsfold")
+    assert net.fused_embed_pool
+    f, hp = net._fold, net._hip
+    n = 300
+    x = random_boards(n, 2, 15, 15, 9).cuda().to(torch.bfloat16).contiguous()
+    x[0] = 0                                                        # empty board: every token but cls sees a zero patch
+    cols = F.unfold(x.float(), kernel_size=5, padding=2).transpose(1, 2)
+    W = f["wt_ext"][:512, :50].float()
+    tok = torch.cat([torch.zeros(n, 1, 512, device="cuda"), cols @ W.t()], 1) + hp["cpos"]
+    xn = F.layer_norm(tok, (512,))
+    ref = torch.einsum("bth,btd->bhd", torch.softmax(xn @ f["m_n"].t(), 1), xn)
+    assert f["score_ref"] is not None
+    cnt = torch.tensor([257], dtype=torch.int32, device="cuda")
+    z = azk.nn_embed_pool(x, f["wt_ext"], f["cpos_frag"], f["score_frag"], f["score_msum"], f["score_ref"] if static_ref else None,
+                          15, 15, 5, 512, 8)
+    err = (z.float() - ref).abs()
+    assert err.max().item() < 1e-2 and err.mean().item() < 1e-3, (err.max().item(), err.mean().item())
+    z2 = torch.full_like(z, 3.0)
+    rc = azk.lib().azk_nn_embed_pool(x.data_ptr(), 0, f["wt_ext"].data_ptr(), f["cpos_frag"].data_ptr(), f["score_frag"].data_ptr(),
+                                     f["score_msum"].data_ptr(), f["score_ref"].data_ptr() if static_ref else None, z2.data_ptr(), 8, n, 2, 15, 15, 5,
+                                     64, 512, 1e-5, cnt.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    assert torch.equal(z2[:257], z[:257]) and bool((z2[257:] == 3.0).all())       # device-side count respected
+    two = azk.nn_embed_scores_pool(x, f["wt_ext"], hp["cpos"], f["score_cpos"], f["score_msum"], f["c_n"], 15, 15, 5, 512, 8)
+    assert (two.float() - ref).abs().max().item() < 6e-2
+    # float32 boards give the same bits as bf16 boards
+    zf = azk.nn_embed_pool(x.float().contiguous(), f["wt_ext"], f["cpos_frag"], f["score_frag"], f["score_msum"],
+                           f["score_ref"] if static_ref else None, 15, 15, 5, 512, 8)
+    assert torch.equal(zf, z)
