@@ -27,6 +27,7 @@ SYMBOLS = [
     "azk_rules_check_winner", "azk_rules_canonical", "azk_softmax_rows",
     "azk_step_tree", "azk_step_gather", "azk_recycle_finished", "azk_nn_patch_embed", "azk_nn_cls_attention", "azk_nn_patch_embed_scores", "azk_nn_cls_pool", "azk_debug_stamps", "azk_emit_finished", "azk_clear_cache", "azk_nn_heads_finalize", "azk_nn_layernorm_rows",
     "azk_vanilla_set_rng", "azk_vanilla_get_rng", "azk_vanilla_search", "azk_nn_embed_pool",
+    "azk_nn_gemm_rows", "azk_nn_layernorm_sum", "azk_nn_heads_finalize_sum",
 ]
 
 
@@ -118,6 +119,9 @@ def lib():
     L.azk_recycle_finished.argtypes = [vp, vp, vp]
     L.azk_nn_patch_embed_scores.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, C.c_float, vp, vp]
     L.azk_nn_embed_pool.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, C.c_float, vp, vp]
+    L.azk_nn_gemm_rows.argtypes = [vp, i32, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]
+    L.azk_nn_layernorm_sum.argtypes = [vp, i32, i32, vp, vp, vp, vp, C.c_float, vp, vp, vp, i32, i32, vp, vp]
+    L.azk_nn_heads_finalize_sum.argtypes = [vp, i32, i32, i32, vp, i32, i32, vp, vp, vp, vp]
     L.azk_nn_layernorm_rows.argtypes = [vp, vp, vp, C.c_float, vp, vp, i32, i32, vp, vp]
     L.azk_nn_heads_finalize.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp]
     L.azk_nn_cls_pool.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]
@@ -584,3 +588,44 @@ def mt_state_to_numpy(words, template=None):
     """uint32[625] read back from the engine -> a tuple for np.random.set_state (Gaussian cache fields from `template`)."""
     t = np.random.get_state() if template is None else template
     return ("MT19937", np.asarray(words[:624], np.uint32), int(words[624]), t[3], t[4])
+
+
+def pack_linear_weight(w):
+    """nn.Linear weight [n_out, k] (any float dtype, any device) -> bf16 tensor in azk_nn_gemm_rows' fragment order
+    (n_out padded with zero rows to a multiple of 64; k must be a multiple of 32)."""
+    torch = _torch()
+    n_out, k = w.shape
+    assert k % 32 == 0
+    npad = (n_out + 63) // 64 * 64
+    wp = torch.zeros(npad, k, dtype=torch.float32, device=w.device)
+    wp[:n_out] = w.float()
+    # [g, l15, c, s, l4, i] -> [g, s, c, l4, l15, i]
+    return wp.view(npad // 64, 16, 4, k // 32, 4, 8).permute(0, 3, 2, 4, 1, 5).contiguous().to(torch.bfloat16)
+
+
+def nn_gemm_rows(a, w_packed, n_out, ksplit=1, partials=None, bias=None, gelu_out=None, count=None):
+    """a bf16 [m, k] (row stride = a.stride(0)) times a packed weight: float32 partial planes [ksplit, m, n_out] or
+    bf16 GELU(a W^T + bias)."""
+    torch = _torch()
+    assert a.dtype == torch.bfloat16 and a.stride(1) == 1
+    m, k = a.shape
+    rc = lib().azk_nn_gemm_rows(_p(a), a.stride(0), _p(w_packed), m, int(n_out), k, int(ksplit), _p(partials), _p(bias), _p(gelu_out),
+                                _p(count), _stream())
+    if rc != 0:
+        raise AzkError(f"azk_nn_gemm_rows failed ({rc})")
+
+
+def nn_layernorm_sum(partials, w, b, y, bias=None, resid=None, add_bias=None, x_out=None, eps=1e-5, count=None):
+    nsplit, m, d = partials.shape
+    rc = lib().azk_nn_layernorm_sum(_p(partials), nsplit, m, _p(bias), _p(resid), _p(w), _p(b), float(eps), _p(y), _p(add_bias), _p(x_out),
+                                    y.shape[0], d, _p(count), _stream())
+    if rc != 0:
+        raise AzkError(f"azk_nn_layernorm_sum failed ({rc})")
+
+
+def nn_heads_finalize_sum(partials, bias, action_dim, logits_out, values_out, count=None):
+    nsplit, m, ld = partials.shape
+    rc = lib().azk_nn_heads_finalize_sum(_p(partials), nsplit, m, ld, _p(bias), int(action_dim), logits_out.shape[0], _p(logits_out),
+                                         _p(values_out), _p(count), _stream())
+    if rc != 0:
+        raise AzkError(f"azk_nn_heads_finalize_sum failed ({rc})")

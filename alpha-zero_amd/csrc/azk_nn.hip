@@ -1049,3 +1049,213 @@ extern "C" int32_t azk_nn_embed_pool(const void *boards_dev, int32_t boards_are_
 #undef CASE
     return AZK_ERR_ARG;
 }
+
+
+// =====================================================================================================
+// cls-row tail (nn.py:54-60, 78-83 for the one row the heads read): small-M GEMMs with a device-side row count.
+//   k_gemm_rows: C[M][N] = A[M][K] (bf16, row-major) x W^T, W packed in MFMA B-fragment order (one 16-byte load per
+//   fragment, 1 KB contiguous per wave); wave tile 64 rows x 64 columns (16 accumulators), no LDS: the four waves of a
+//   workgroup take neighbouring column groups of the same rows, so their A fragments hit in L1.  The K dimension can be
+//   split over `ksplit` waves; partial sums go to separate float32 planes that the next (row-wise) kernel adds up - no
+//   atomics, deterministic.  Rows at or beyond *n_valid are never touched.
+//   Packed weight: Wp[N/64][K/32][4][64 lanes][8] with element = W[64 g + 4 (lane&15) + c][32 s + 8 (lane>>4) + i], so a
+//   lane's four accumulators of a row are four consecutive output columns (16-byte float / 8-byte bf16 stores).
+// =====================================================================================================
+namespace {
+
+struct GemmArgs {
+    const unsigned short *A;   // [M][lda] bf16
+    int lda;
+    const uint4 *Wp;           // packed weight
+    int M, N, K, ksplit;
+    const int *count;
+    float *P;                  // mode 0: [ksplit][M][N] float32 partial sums
+    const float *bias;         // mode 1: [N]
+    unsigned short *out;       // mode 1: [M][N] bf16 = gelu(A W^T + bias)
+};
+
+template <int MODE, int RT, int KU>   // RT = 16-row tiles per wave (wave tile 16 RT rows x 64 columns); KU = k-steps whose fragments
+                                     // are all requested before the first MFMA of the batch (latency hiding)
+__global__ __launch_bounds__(256, 2) void k_gemm_rows(GemmArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, l4 = lane >> 4;
+    const int nvalid = a.count ? min(a.M, *a.count) : a.M;
+    const int rtiles = (nvalid + 16 * RT - 1) / (16 * RT), ngroups = a.N >> 6, ksteps = a.K >> 5;
+    const int nitems = rtiles * ngroups * a.ksplit;
+    const int nks = ksteps / a.ksplit;
+    for (int item = blockIdx.x * 4 + wave; item < nitems; item += gridDim.x * 4) {
+        const int ng = item % ngroups, r = item / ngroups, rt = r % rtiles, s = r / rtiles;
+        const int ks0 = s * nks;
+        f32x4 acc[RT][4];
+#pragma unroll
+        for (int i = 0; i < RT; i++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) acc[i][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const unsigned short *ap[RT];
+#pragma unroll
+        for (int i = 0; i < RT; i++) {
+            const int row = min(16 * RT * rt + 16 * i + l15, nvalid - 1);
+            ap[i] = a.A + (size_t)row * a.lda + 32 * ks0 + 8 * l4;
+        }
+        const uint4 *bp = a.Wp + ((size_t)ng * ksteps + ks0) * 4 * 64 + lane;
+        for (int kb = 0; kb < nks; kb += KU) {
+            union { uint4 u; bf16x8 v; } af[KU][RT], bf[KU][4];
+#pragma unroll
+            for (int u = 0; u < KU; u++) {
+                const int ks = kb + u;                                // nks is a multiple of KU (checked by the host)
+#pragma unroll
+                for (int i = 0; i < RT; i++) af[u][i].u = *(const uint4 *)(ap[i] + 32 * ks);
+#pragma unroll
+                for (int c = 0; c < 4; c++) bf[u][c].u = bp[(ks * 4 + c) * 64];
+            }
+            __builtin_amdgcn_sched_barrier(0);        // every load of the batch is issued before its first MFMA
+#pragma unroll
+            for (int u = 0; u < KU; u++) {
+#pragma unroll
+                for (int i = 0; i < RT; i++)
+#pragma unroll
+                    for (int c = 0; c < 4; c++) acc[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u][i].v, bf[u][c].v, acc[i][c], 0, 0, 0);
+            }
+        }
+        const int col0 = 64 * ng + 4 * l15;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (MODE == 1) bv = *(const f32x4 *)(a.bias + col0);
+#pragma unroll
+        for (int i = 0; i < RT; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int row = 16 * RT * rt + 16 * i + 4 * l4 + j;
+                if (row >= nvalid) continue;
+                f32x4 v = {acc[i][0][j], acc[i][1][j], acc[i][2][j], acc[i][3][j]};
+                if (MODE == 0) {
+                    *(f32x4 *)(a.P + ((size_t)s * a.M + row) * a.N + col0) = v;
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; c++) { const float x = v[c] + bv[c]; v[c] = 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }   // nn.GELU (exact)
+                    union { bf16x4 b; uint2 u; } o;
+                    o.b = __builtin_convertvector(v, bf16x4);
+                    *(uint2 *)(a.out + (size_t)row * a.N + col0) = o.u;
+                }
+            }
+    }
+}
+
+// x = sum_s P[s][row][:] (+ bias) (+ resid[row][:]);  y = LayerNorm(x) (bf16);  optionally xout = x + add_bias (bf16)
+template <int VPL>
+__global__ __launch_bounds__(256) void k_ln_sum(const float *__restrict__ P, int nsplit, int M, const float *__restrict__ bias,
+                                                const unsigned short *__restrict__ resid, const float *__restrict__ w,
+                                                const float *__restrict__ b, float eps, unsigned short *__restrict__ y,
+                                                const float *__restrict__ add_bias, unsigned short *__restrict__ xout, int n,
+                                                const int *count) {
+    constexpr int D = 64 * VPL;
+    const int nvalid = count ? min(n, *count) : n;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= nvalid) return;
+    float v[VPL];
+#pragma unroll
+    for (int q = 0; q < VPL; q++) v[q] = bias ? bias[lane * VPL + q] : 0.f;
+    for (int s0 = 0; s0 < nsplit; s0 += 4) {                          // four planes' loads in flight together
+        f32x4 t[4][VPL / 4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const float *p = P + ((size_t)min(s0 + u, nsplit - 1) * M + row) * D + lane * VPL;
+#pragma unroll
+            for (int q = 0; q < VPL / 4; q++) t[u][q] = *(const f32x4 *)(p + 4 * q);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (s0 + u >= nsplit) break;
+#pragma unroll
+            for (int q = 0; q < VPL / 4; q++) { v[4 * q] += t[u][q][0]; v[4 * q + 1] += t[u][q][1]; v[4 * q + 2] += t[u][q][2]; v[4 * q + 3] += t[u][q][3]; }
+        }
+    }
+    if (resid) {
+        const unsigned short *rr = resid + (size_t)row * D + lane * VPL;
+#pragma unroll
+        for (int q = 0; q < VPL; q++) v[q] += __uint_as_float((unsigned)rr[q] << 16);
+    }
+    float s1 = 0.f;
+#pragma unroll
+    for (int q = 0; q < VPL; q++) s1 += v[q];
+    const float mean = wave64_sum(s1) * (1.0f / D);
+    float ss = 0.f;
+#pragma unroll
+    for (int q = 0; q < VPL; q++) { const float d = v[q] - mean; ss += d * d; }
+    const float rstd = rsqrtf(wave64_sum(ss) * (1.0f / D) + eps);
+    float o[VPL], r[VPL];
+#pragma unroll
+    for (int q = 0; q < VPL; q++) {
+        o[q] = (v[q] - mean) * rstd * w[lane * VPL + q] + b[lane * VPL + q];
+        r[q] = v[q] + (add_bias ? add_bias[lane * VPL + q] : 0.f);
+    }
+    if constexpr (VPL == 8) {
+        *(uint4 *)(y + (size_t)row * D + lane * VPL) = pack8(o);
+        if (xout) *(uint4 *)(xout + (size_t)row * D + lane * VPL) = pack8(r);
+    } else {
+#pragma unroll
+        for (int q = 0; q < VPL; q++) {
+            y[(size_t)row * D + lane * VPL + q] = __builtin_bit_cast(unsigned short, (__bf16)o[q]);
+            if (xout) xout[(size_t)row * D + lane * VPL + q] = __builtin_bit_cast(unsigned short, (__bf16)r[q]);
+        }
+    }
+}
+
+// logits[row][a] = sum_s P[s][row][a] + bias[a] (a < A);  values[row] = tanh(sum_s P[s][row][A] + bias[A])   (nn.py:82-83)
+__global__ void k_heads_finalize_sum(const float *__restrict__ P, int nsplit, int M, int ld, const float *__restrict__ bias, int A, int n,
+                                     float *__restrict__ logits, float *__restrict__ values, const int *count) {
+    const int nvalid = count ? min(n, *count) : n;
+    const long long total = (long long)nvalid * (A + 1);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int row = (int)(i / (A + 1)), col = (int)(i - (long long)row * (A + 1));
+        float v = bias[col];
+        for (int s = 0; s < nsplit; s++) v += P[((size_t)s * M + row) * ld + col];
+        if (col < A) logits[(size_t)row * A + col] = v;
+        else values[row] = tanhf(v);
+    }
+}
+}  // namespace
+
+extern "C" int32_t azk_nn_gemm_rows(const void *a_bf16_dev, int32_t lda, const void *w_packed_dev, int32_t m, int32_t n_out,
+                                    int32_t k, int32_t ksplit, float *partials_out_dev, const float *bias_dev,
+                                    void *gelu_out_bf16_dev, const int32_t *n_valid_dev, void *stream) {
+    if (!a_bf16_dev || !w_packed_dev || m < 0 || n_out < 64 || (n_out & 63) || k < 32 || (k & 31) || ksplit < 1) return AZK_ERR_ARG;
+    if ((k / 32) % (4 * ksplit) != 0 || lda < k || (lda & 7)) return AZK_ERR_ARG;     // k-steps per split: a multiple of the batch of 4
+    if ((partials_out_dev != nullptr) == (gelu_out_bf16_dev != nullptr)) return AZK_ERR_ARG;
+    if (gelu_out_bf16_dev && (!bias_dev || ksplit != 1)) return AZK_ERR_ARG;
+    if (m == 0) return AZK_OK;
+    GemmArgs a;
+    a.A = (const unsigned short *)a_bf16_dev; a.lda = lda; a.Wp = (const uint4 *)w_packed_dev; a.M = m; a.N = n_out; a.K = k;
+    a.ksplit = ksplit; a.count = n_valid_dev; a.P = partials_out_dev; a.bias = bias_dev; a.out = (unsigned short *)gelu_out_bf16_dev;
+    const long long items = (long long)((m + 31) / 32) * (n_out / 64) * ksplit;      // 32-row x 64-column wave tiles
+    const unsigned blocks = (unsigned)((items + 3) / 4 < 4096 ? (items + 3) / 4 : 4096);
+    hipStream_t st = (hipStream_t)stream;
+    if (partials_out_dev) k_gemm_rows<0, 2, 4><<<blocks, 256, 0, st>>>(a);
+    else k_gemm_rows<1, 2, 4><<<blocks, 256, 0, st>>>(a);
+    return hipGetLastError() == hipSuccess ? AZK_OK : AZK_ERR_HIP;
+}
+
+extern "C" int32_t azk_nn_layernorm_sum(const float *partials_dev, int32_t nsplit, int32_t m_stride, const float *bias_dev,
+                                        const void *resid_bf16_dev, const float *w_dev, const float *b_dev, float eps,
+                                        void *y_bf16_dev, const float *add_bias_dev, void *x_out_bf16_dev, int32_t n,
+                                        int32_t embed_dim, const int32_t *n_valid_dev, void *stream) {
+    if (!partials_dev || nsplit < 1 || !w_dev || !b_dev || !y_bf16_dev || n < 0 || m_stride < n) return AZK_ERR_ARG;
+    if (embed_dim != 256 && embed_dim != 512) return AZK_ERR_ARG;
+    if (n == 0) return AZK_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((n + 3) / 4), block(256);
+    const unsigned short *rs = (const unsigned short *)resid_bf16_dev;
+    unsigned short *y = (unsigned short *)y_bf16_dev, *xo = (unsigned short *)x_out_bf16_dev;
+    if (embed_dim == 512) k_ln_sum<8><<<grid, block, 0, st>>>(partials_dev, nsplit, m_stride, bias_dev, rs, w_dev, b_dev, eps, y, add_bias_dev, xo, n, n_valid_dev);
+    else k_ln_sum<4><<<grid, block, 0, st>>>(partials_dev, nsplit, m_stride, bias_dev, rs, w_dev, b_dev, eps, y, add_bias_dev, xo, n, n_valid_dev);
+    return hipGetLastError() == hipSuccess ? AZK_OK : AZK_ERR_HIP;
+}
+
+extern "C" int32_t azk_nn_heads_finalize_sum(const float *partials_dev, int32_t nsplit, int32_t m_stride, int32_t ld,
+                                             const float *bias_dev, int32_t action_dim, int32_t n, float *logits_out_dev,
+                                             float *values_out_dev, const int32_t *n_valid_dev, void *stream) {
+    if (!partials_dev || nsplit < 1 || !bias_dev || !logits_out_dev || !values_out_dev || ld < action_dim + 1 || n < 0 || m_stride < n) return AZK_ERR_ARG;
+    if (n == 0) return AZK_OK;
+    k_heads_finalize_sum<<<1024, 256, 0, (hipStream_t)stream>>>(partials_dev, nsplit, m_stride, ld, bias_dev, action_dim, n, logits_out_dev,
+                                                               values_out_dev, n_valid_dev);
+    return hipGetLastError() == hipSuccess ? AZK_OK : AZK_ERR_HIP;
+}

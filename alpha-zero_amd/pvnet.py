@@ -117,6 +117,9 @@ class PolicyValueNet:
         self.fast_outputs = False   # True: logits may come back as a bf16 view (the caller converts while copying)
         self.last_value_pre_tanh = False
         self.out_buffers = None     # optional (logits f32 [n,A], values f32 [n]) the fast tail writes into directly
+        self.hip_tail = False           # set by _prepare_folded when the hand-written tail kernels cover this configuration
+        self.use_hip_tail = False       # True: the cls-row tail on azk_nn_gemm_rows (every launch honours the live count; measured
+                                        # 87 us vs 82 us for the hipBLASLt tail at 2048 rows / 1150 live, so the library GEMMs stay the default)
         self.fused_embed_pool = False   # set by _prepare_folded when azk_nn_embed_pool covers this configuration
         self.kernel_timers = None   # optional (embed_timer, pool_timer) with start()/stop(): HIP-event timing of the two kernels
         self.live_count = None      # optional int32 CUDA tensor: number of valid rows at the head of the batch (graph stepping)
@@ -229,6 +232,18 @@ class PolicyValueNet:
             f["Wh"], f["bh"] = Wh.to(torch.bfloat16), bh.to(torch.bfloat16)
             f["W0T"] = m["blocks.0.mlp.0.weight"].t().contiguous().to(dev, torch.bfloat16)
             f["W3T"] = m["blocks.0.mlp.3.weight"].t().contiguous().to(dev, torch.bfloat16)
+            # the same tail for the hand-written small-M GEMM (azk_nn_gemm_rows): weights in MFMA fragment order, float32 biases
+            import azk
+            f["WcombP"] = azk.pack_linear_weight(Wcomb.t().contiguous())                               # [D, H*D] as an nn.Linear weight
+            f["W0P"] = azk.pack_linear_weight(m[b + "mlp.0.weight"].to(dev))
+            f["W3P"] = azk.pack_linear_weight(m[b + "mlp.3.weight"].to(dev))
+            f["WhP"] = azk.pack_linear_weight(Wh)
+            f["bias1_f"] = (x0 + bo + Wo @ bvn).float().contiguous()
+            f["b0_f"] = m[b + "mlp.0.bias"].to(dev, torch.float32).contiguous()
+            bhp = torch.zeros(f["WhP"].numel() // D, device=dev)
+            bhp[:Ap] = bh
+            f["bh_f"] = bhp
+            self.hip_tail = D in (256, 512) and (H * D) % 256 == 0
             for k_, src in (("ln2_w", b + "norm2.weight"), ("ln2_b", b + "norm2.bias"), ("lnf_w", "norm.weight"),
                             ("lnf_b", "norm.bias"), ("b3", b + "mlp.3.bias")):
                 f[k_] = m[src].to(dev, torch.float32).contiguous()
@@ -242,8 +257,41 @@ class PolicyValueNet:
                 self._gelu_epilogue = False
         self._fold = f
 
+    def tail_hip(self, z):
+        """tail_fast on the hand-written kernels: every launch honours the device-side live count, split-K partial sums are
+        added by the row-wise kernel that follows (LayerNorm / finalize)."""
+        import azk
+        cfg, f = self.cfg, self._fold
+        n, A, D, H = z.shape[0], cfg.action_dim, cfg.embed_dim, cfg.num_heads
+        dev, cnt = z.device, self.live_count
+        bf = dict(dtype=torch.bfloat16, device=dev)
+        k1 = 8 if (H * D // 32) % 8 == 0 else 1
+        P1 = torch.empty((k1, n, D), dtype=torch.float32, device=dev)
+        azk.nn_gemm_rows(z.view(n, H * D), f["WcombP"], D, ksplit=k1, partials=P1, count=cnt)              # nn.py:54-56
+        h = torch.empty((n, D), **bf)
+        x1b = torch.empty((n, D), **bf)
+        azk.nn_layernorm_sum(P1, f["ln2_w"], f["ln2_b"], h, bias=f["bias1_f"], add_bias=f["b3"], x_out=x1b, count=cnt)
+        hh = torch.empty((n, 4 * D), **bf)
+        azk.nn_gemm_rows(h, f["W0P"], 4 * D, bias=f["b0_f"], gelu_out=hh, count=cnt)                       # nn.py:59 (Linear + GELU)
+        P3 = torch.empty((4, n, D), dtype=torch.float32, device=dev)
+        azk.nn_gemm_rows(hh, f["W3P"], D, ksplit=4, partials=P3, count=cnt)                                # nn.py:59-60
+        y = torch.empty((n, D), **bf)
+        azk.nn_layernorm_sum(P3, f["lnf_w"], f["lnf_b"], y, resid=x1b, count=cnt)                          # nn.py:78
+        Np = f["bh_f"].numel()
+        P4 = torch.empty((4, n, Np), dtype=torch.float32, device=dev)
+        azk.nn_gemm_rows(y, f["WhP"], Np, ksplit=4, partials=P4, count=cnt)                                # nn.py:82-83
+        if self.out_buffers is not None:
+            lb, vb = self.out_buffers
+        else:
+            lb = torch.empty((n, A), dtype=torch.float32, device=dev)
+            vb = torch.empty(n, dtype=torch.float32, device=dev)
+        azk.nn_heads_finalize_sum(P4, f["bh_f"], A, lb, vb, count=cnt)
+        return lb, (vb if self.out_buffers is not None else vb[:, None])
+
     def tail_fast(self, z):
         """depth-1 cls row after the pooled tokens zn [n, H, D]: composed projection, MLP, final norm, merged heads."""
+        if self.hip_tail and self.use_hip_tail:
+            return self.tail_hip(z)
         w, cfg, f = self.w, self.cfg, self._fold
         n, A = z.shape[0], cfg.action_dim
         import azk

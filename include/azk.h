@@ -269,6 +269,27 @@ int32_t azk_nn_embed_pool(const void *boards_dev, int32_t boards_are_f32, const 
                           int32_t rows, int32_t cols, int32_t ksize, int32_t kp, int32_t embed_dim, float ln_eps,
                           const int32_t *n_valid_dev, void *stream);
 
+/* ---- cls-row tail (nn.py:54-60, 78-83 for the row the heads read): small-M GEMMs with a device-side row count.
+ * azk_nn_gemm_rows: C = A W^T for A bf16 [m][lda] (first k columns), W = an nn.Linear weight [n_out][k] packed in MFMA
+ *   B-fragment order: Wp[n_out/64][k/32][4][64][8] with element [g][s][c][lane][i] = W[64 g + 4 (lane&15) + c][32 s + 8 (lane>>4) + i]
+ *   (n_out a multiple of 64, k of 32).  Either partials_out_dev != NULL: the K range is split over `ksplit` waves and
+ *   float32 partial sums are written to [ksplit][m][n_out] planes (the row-wise kernel that follows adds them: no
+ *   atomics); or gelu_out_bf16_dev != NULL (ksplit 1): bf16 [m][n_out] = GELU(A W^T + bias) (nn.GELU, exact erf).
+ * azk_nn_layernorm_sum: x = sum of nsplit partial planes (plane stride m_stride rows) (+ bias) (+ resid bf16);
+ *   y = LayerNorm(x) bf16; optional x_out = x + add_bias bf16 (the residual the next product is added to).
+ * azk_nn_heads_finalize_sum: logits / tanh(value) from the partial planes of the merged head GEMM (+ bias).
+ * n_valid_dev as above: rows at or beyond it are neither read nor written. */
+int32_t azk_nn_gemm_rows(const void *a_bf16_dev, int32_t lda, const void *w_packed_dev, int32_t m, int32_t n_out, int32_t k,
+                         int32_t ksplit, float *partials_out_dev, const float *bias_dev, void *gelu_out_bf16_dev,
+                         const int32_t *n_valid_dev, void *stream);
+int32_t azk_nn_layernorm_sum(const float *partials_dev, int32_t nsplit, int32_t m_stride, const float *bias_dev,
+                             const void *resid_bf16_dev, const float *w_dev, const float *b_dev, float eps, void *y_bf16_dev,
+                             const float *add_bias_dev, void *x_out_bf16_dev, int32_t n, int32_t embed_dim,
+                             const int32_t *n_valid_dev, void *stream);
+int32_t azk_nn_heads_finalize_sum(const float *partials_dev, int32_t nsplit, int32_t m_stride, int32_t ld, const float *bias_dev,
+                                  int32_t action_dim, int32_t n, float *logits_out_dev, float *values_out_dev,
+                                  const int32_t *n_valid_dev, void *stream);
+
 /* ---- vanilla mode: MCTS.mcts(model=None, ...) (mcts.py:57-59), MCTS.simulate (mcts.py:62-79), UCB1 of
  * utils.py:29-44 mode 'normal'.  A search is azk_begin_search(e, NULL) followed by azk_vanilla_search calls summing to
  * n simulations (each launch runs its simulations - select, expand, random rollout, backup - entirely on the device);

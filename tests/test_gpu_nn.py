@@ -175,3 +175,42 @@ def test_fused_embed_pool_vs_torch_fp32(static_ref):
     zf = azk.nn_embed_pool(x.float().contiguous(), f["wt_ext"], f["cpos_frag"], f["score_frag"], f["score_msum"],
                            f["score_ref"] if static_ref else None, 15, 15, 5, 512, 8)
     assert torch.equal(zf, z)
+
+
+def test_hand_written_tail_matches_library_tail():
+    """azk_nn_gemm_rows / azk_nn_layernorm_sum / azk_nn_heads_finalize_sum (cls-row tail with a device-side row count)
+    against the same tail on library GEMMs, and the GEMM alone against fp32 matmul.  bf16 operands, fp32 accumulation:
+    logits agree to 3e-2 absolute (scale ~0.5), values to 5e-3."""
+    import azk
+    cfg = NetConfig(15, 15, 2, 225, 5, 512, 8, 1)
+    net = PolicyValueNet(cfg, seed=2, device="cuda", dtype=torch.bfloat16, path="clsfold")
+    assert net.hip_tail
+    n, live = 333, 200
+    torch.manual_seed(0)
+    z = (torch.randn(n, 8, 512, device="cuda") * 0.1).to(torch.bfloat16)
+    net.use_hip_tail = False
+    l_ref, v_ref = net.tail_fast(z)
+    net.use_hip_tail = True
+    l_hip, v_hip = net.tail_fast(z)
+    assert (l_hip - l_ref).abs().max().item() < 3e-2 and (v_hip.reshape(-1) - v_ref.reshape(-1)).abs().max().item() < 5e-3
+    net.live_count = torch.tensor([live], dtype=torch.int32, device="cuda")
+    lb = torch.full((n, 225), 9.0, device="cuda")
+    vb = torch.full((n,), 9.0, device="cuda")
+    net.out_buffers = (lb, vb)
+    net.tail_fast(z)
+    assert torch.equal(lb[:live], l_hip[:live]) and bool((lb[live:] == 9.0).all()) and bool((vb[live:] == 9.0).all())
+    # the GEMM alone: partial planes sum to A W^T; GELU epilogue
+    a = (torch.randn(150, 1024, device="cuda") * 0.3).to(torch.bfloat16)
+    w = (torch.randn(200, 1024, device="cuda") * 0.05)
+    wp = azk.pack_linear_weight(w)
+    P = torch.zeros(2, 150, 256, device="cuda")
+    azk.nn_gemm_rows(a, wp, 256, ksplit=2, partials=P)
+    ref = a.float() @ w.to(torch.bfloat16).float().t()
+    got = P.sum(0)[:, :200]
+    assert (got - ref).abs().max().item() < 2e-3 * ref.abs().max().item() + 1e-3
+    assert bool((P.sum(0)[:, 200:] == 0).all())
+    bias = torch.randn(256, device="cuda") * 0.1
+    g = torch.empty(150, 256, device="cuda", dtype=torch.bfloat16)
+    azk.nn_gemm_rows(a, wp, 256, bias=bias, gelu_out=g)
+    refg = F.gelu(torch.cat([ref, torch.zeros(150, 56, device="cuda")], 1) + bias)
+    assert (g.float() - refg).abs().max().item() < 2e-2
