@@ -45,7 +45,10 @@ template <int CTRL> __device__ __forceinline__ int dpp_val(int v) { return dpp_i
 
 template <typename T>
 __device__ __forceinline__ void argmax_combine(T &v, int &idx, T ov, int oi) {
-    if (oi < 0x7fffffff && (idx == 0x7fffffff || ov > v || (ov == v && oi < idx))) { v = ov; idx = oi; }
+    // bitwise on purpose (no short-circuit): one compare chain and two selects instead of nested exec-mask branches
+    const bool take = (oi < 0x7fffffff) & ((idx == 0x7fffffff) | (ov > v) | ((ov == v) & (oi < idx)));
+    v = take ? ov : v;
+    idx = take ? oi : idx;
 }
 
 template <typename T>
@@ -59,6 +62,44 @@ __device__ __forceinline__ void wave_argmax_first(T &v, int &idx) {
         T ov = __shfl_xor(v, off);
         int oi = __shfl_xor(idx, off);
         argmax_combine(v, idx, ov, oi);
+    }
+}
+
+// Same reduction without LDS-crossbar shuffles: the four in-row steps, then row_bcast:15 into rows 1,3 and row_bcast:31 into
+// rows 2,3 (GFX9 DPP); the wave's result is valid in LANE 63 ONLY - read it with __builtin_amdgcn_readlane(x, 63).
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ int dpp_bcast_i32(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, CTRL, ROWMASK, 0xF, false); }
+
+template <typename T>
+__device__ __forceinline__ void wave_argmax_first_lane63(T &v, int &idx) {
+    argmax_combine(v, idx, dpp_val<0xB1>(v), dpp_i32<0xB1>(idx));     // quad_perm [1,0,3,2]
+    argmax_combine(v, idx, dpp_val<0x4E>(v), dpp_i32<0x4E>(idx));     // quad_perm [2,3,0,1]
+    argmax_combine(v, idx, dpp_val<0x141>(v), dpp_i32<0x141>(idx));   // row_half_mirror
+    argmax_combine(v, idx, dpp_val<0x140>(v), dpp_i32<0x140>(idx));   // row_mirror
+    if constexpr (sizeof(T) == 4) {
+        {
+            const int oi = dpp_bcast_i32<0x142, 0xA>(0x7fffffff, idx);                                    // rows 1, 3 <- lane 15 of rows 0, 2
+            const T ov = __builtin_bit_cast(T, dpp_bcast_i32<0x142, 0xA>(0, __builtin_bit_cast(int, v)));
+            argmax_combine(v, idx, ov, oi);
+        }
+        {
+            const int oi = dpp_bcast_i32<0x143, 0xC>(0x7fffffff, idx);                                    // rows 2, 3 <- lane 31
+            const T ov = __builtin_bit_cast(T, dpp_bcast_i32<0x143, 0xC>(0, __builtin_bit_cast(int, v)));
+            argmax_combine(v, idx, ov, oi);
+        }
+    } else {
+        {
+            const int oi = dpp_bcast_i32<0x142, 0xA>(0x7fffffff, idx);
+            const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+            const unsigned lo = (unsigned)dpp_bcast_i32<0x142, 0xA>(0, (int)(unsigned)b), hi = (unsigned)dpp_bcast_i32<0x142, 0xA>(0, (int)(unsigned)(b >> 32));
+            argmax_combine(v, idx, __builtin_bit_cast(T, ((unsigned long long)hi << 32) | lo), oi);
+        }
+        {
+            const int oi = dpp_bcast_i32<0x143, 0xC>(0x7fffffff, idx);
+            const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+            const unsigned lo = (unsigned)dpp_bcast_i32<0x143, 0xC>(0, (int)(unsigned)b), hi = (unsigned)dpp_bcast_i32<0x143, 0xC>(0, (int)(unsigned)(b >> 32));
+            argmax_combine(v, idx, __builtin_bit_cast(T, ((unsigned long long)hi << 32) | lo), oi);
+        }
     }
 }
 

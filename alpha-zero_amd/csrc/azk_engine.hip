@@ -122,6 +122,11 @@ __device__ __forceinline__ uint32_t meta_pack(int cell, int nch) { return ((uint
 __device__ __forceinline__ int meta_cell(uint32_t m) { return (int)(m >> 16); }
 __device__ __forceinline__ int meta_nch(uint32_t m) { return (int)(m & 0xffffu); }
 
+// device counters: fire-and-forget atomics (no load -> add -> store round trip on the simulation's critical path)
+__device__ __forceinline__ void count_add(const Dev &d, int which, int g, long long v) {
+    atomicAdd((unsigned long long *)&d.counters[(size_t)which * d.G + g], (unsigned long long)v);
+}
+
 // Node.backup (node.py:62-74): the node at trace index i gets value * (-1)^(depth - i); lanes take one node each.
 __device__ __forceinline__ void backup_path(const Dev &d, size_t base, const int *path, int depth, double value) {
     for (int i = azk_lane(); i <= depth; i += AZK_WAVE) {
@@ -148,81 +153,143 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev d, const float *__restric
     const bool stamp = (d.ablate & 16) != 0;
     long long t0 = stamp ? clock64() : 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
 
+    // ---- every load whose address depends only on the game index is issued here, together: ONE memory round trip for
+    //      the pending leaf's record, its path and move list, the game's state and board, and the root header ----
+    const int e_node = EXPAND ? d.leaf_node[g] : -1, e_slot = EXPAND ? d.leaf_slot[g] : 0, e_depth = EXPAND ? d.leaf_depth[g] : 0;
+    const int e_nv = EXPAND ? d.leaf_nmoves[g] : 0, e_top = EXPAND ? d.arena_top[g] : 0;
+    const int e_centry = (EXPAND && d.cache_entries) ? d.leaf_cache[g] : -1;
+    const int e_path = (EXPAND && lane < d.path_cap) ? d.path[(size_t)g * d.path_cap + lane] : 0;     // trace nodes 0..63 (deeper ones: below)
+    constexpr int KSL = 7;                                  // cells per lane: rc <= 448 (make_game allows 400)
+    int e_mv[KSL] = {0, 0, 0, 0, 0, 0, 0};
     if (EXPAND) {
-        const int node = uniform_i32(d.leaf_node[g]);
+#pragma unroll
+        for (int k4 = 0; k4 < KSL; k4++) { const int i = lane + AZK_WAVE * k4; if (i < rc) e_mv[k4] = d.leaf_moves[(size_t)g * rc + i]; }
+    }
+    const int s_done = SELECT ? d.done[g] : 1, s_player = SELECT ? d.to_move[g] : 0, s_mc = SELECT ? d.move_count[g] : 0;
+    int s_rootf64 = SELECT ? d.root_f64[g] : 0;
+    int r_fc = SELECT ? d.first_child[base] : -1, r_N = SELECT ? d.N[base] : 0;
+    uint32_t r_meta = SELECT ? d.meta[base] : 0u;
+    uint8_t s_cells[KSL] = {0, 0, 0, 0, 0, 0, 0};
+    if (SELECT) {
+#pragma unroll
+        for (int k4 = 0; k4 < KSL; k4++) { const int i = lane + AZK_WAVE * k4; if (i < rc) s_cells[k4] = d.cells[(size_t)g * d.rc_pad + i]; }
+    }
+
+    if (EXPAND) {
+        const int node = uniform_i32(e_node);
         if (node >= 0) {
-            const int slot = uniform_i32(d.leaf_slot[g]);
-            const int depth = uniform_i32(d.leaf_depth[g]);
-            const int nv = uniform_i32(d.leaf_nmoves[g]);
-            const int centry = d.cache_entries ? uniform_i32(d.leaf_cache[g]) : -1;
+            const int slot = uniform_i32(e_slot);
+            const int depth = uniform_i32(e_depth);
+            const int nv = uniform_i32(e_nv);
+            const int centry = d.cache_entries ? uniform_i32(e_centry) : -1;
             const bool hit = d.cache_entries && centry >= 0;
             const size_t crow = ((size_t)g * d.cache_entries + (hit ? centry : -(centry + 1)));
             const float *lg = hit ? d.cache_logits + crow * A : logits + (size_t)slot * A;
-            if (d.cache_entries && !hit)                              // MCTS.cache[board_key] = (...)  (mcts.py:51)
-                for (int i = lane; i < A; i += AZK_WAVE) d.cache_logits[crow * A + i] = lg[i];
+            // Node.backup operands (trace nodes 0..depth, one per lane) are fetched now, next to the logits: second round trip
+            const bool shortpath = depth < AZK_WAVE;
+            int bN = 0;
+            double bW = 0.0;
+            if (shortpath && lane <= depth) { bN = d.N[base + e_path]; bW = d.W[base + e_path]; }
+            // second (and last) round trip of the expansion, all straight-line: logits, value, the node's header, root noise
+            float lgv[KSL];
+#pragma unroll
+            for (int k4 = 0; k4 < KSL; k4++) { const int i = lane + AZK_WAVE * k4; lgv[k4] = lg[i < A ? i : A - 1]; }
+            const float vraw = hit ? d.cache_value[crow] : values[slot];
+            const uint32_t node_meta = d.meta[base + node];
+            const bool mix = depth == 0 && d.noise != nullptr;        // mcts.py:42-43,52-53
+            double nzv[KSL] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            if (mix) {
+#pragma unroll
+                for (int k4 = 0; k4 < KSL; k4++) {
+                    const int i = lane + AZK_WAVE * k4;
+                    nzv[k4] = d.noise[(size_t)g * A + azk_action_idx(gd, i < nv ? e_mv[k4] : 0)];   // (a lane's e_mv beyond nv is stale memory)
+                }
+            }
+            if (d.cache_entries && !hit) {                            // MCTS.cache[board_key] = (...)  (mcts.py:51)
+#pragma unroll
+                for (int k4 = 0; k4 < KSL; k4++) { const int i = lane + AZK_WAVE * k4; if (i < A) d.cache_logits[crow * A + i] = lgv[k4]; }
+                if (lane == 0) d.cache_value[crow] = vraw;
+            }
             // float32 softmax, no max subtraction (mcts.py:48-49)
-            for (int i = lane; i < A; i += AZK_WAVE) L.e[i] = (d.ablate & 1) ? 1.0f : azk_exp_det(lg[i]);
+#pragma unroll
+            for (int k4 = 0; k4 < KSL; k4++) {
+                if (AZK_WAVE * k4 >= A) break;
+                const int i = lane + AZK_WAVE * k4;
+                const float ev = (d.ablate & 1) ? 1.0f : azk_exp_det(lgv[k4]);
+                if (i < A) L.e[i] = ev;
+            }
             __syncthreads();
             const float s = azk_pairwise_sum(L.e, A, L.racc);
-            const int fc = uniform_i32(d.arena_top[g]);
+            const int fc = uniform_i32(e_top);
             const bool fits = fc + nv <= d.cap;
-            const bool mix = depth == 0 && d.noise != nullptr;        // mcts.py:42-43,52-53
             if (fits) {
-                for (int i = lane; i < nv; i += AZK_WAVE) {           // Node.expand (node.py:50-59)
-                    const int cell = d.leaf_moves[(size_t)g * rc + i];
+#pragma unroll
+                for (int k4 = 0; k4 < KSL; k4++) {                    // Node.expand (node.py:50-59)
+                    const int i = lane + AZK_WAVE * k4;
+                    if (i >= nv) break;
+                    const int cell = e_mv[k4];
                     const int a = azk_action_idx(gd, cell);
                     const float p = L.e[a] / s;
                     const size_t idx = base + fc + i;
                     d.N[idx] = 0; d.W[idx] = 0.0; d.P[idx] = p; d.meta[idx] = meta_pack(cell, 0);
                     d.first_child[idx] = -1;
-                    if (mix) d.rootP[(size_t)g * rc + i] = (double)(0.75f * p) + 0.25 * d.noise[(size_t)g * A + a];  // utils.py:24-25
+                    if (mix) d.rootP[(size_t)g * rc + i] = (double)(0.75f * p) + 0.25 * nzv[k4];   // utils.py:24-25
                 }
                 if (lane == 0) {
                     d.first_child[base + node] = fc;
-                    d.meta[base + node] = (d.meta[base + node] & 0xffff0000u) | (uint32_t)nv;
+                    d.meta[base + node] = (node_meta & 0xffff0000u) | (uint32_t)nv;
                     d.arena_top[g] = fc + nv;
                     if (depth == 0) d.root_f64[g] = mix ? 1 : 0;
-                    d.counters[(size_t)CNT_CREATED * d.G + g] += nv;
+                    count_add(d, CNT_CREATED, g, nv);
                 }
+                if (node == 0) { r_fc = fc; r_meta = (r_meta & 0xffff0000u) | (uint32_t)nv; s_rootf64 = mix ? 1 : 0; }   // the root header loaded above is stale now
             } else if (lane == 0) {
                 atomicExch(d.err, AZK_ERR_ARENA_FULL);
             }
-            float vraw;
-            if (hit) vraw = d.cache_value[crow];
-            else { vraw = values[slot]; if (d.cache_entries && lane == 0) d.cache_value[crow] = vraw; }
             const double v = -(double)vraw;                          // mcts.py:56
-            backup_path(d, base, d.path + (size_t)g * d.path_cap, depth, v);
+            if (shortpath) {                                          // Node.backup (node.py:62-74) on the operands fetched above
+                if (lane <= depth) {
+                    d.N[base + e_path] = bN + 1;
+                    d.W[base + e_path] = bW + (((depth - lane) & 1) ? -v : v);
+                }
+            } else {
+                backup_path(d, base, d.path + (size_t)g * d.path_cap, depth, v);
+            }
+            r_N += 1;                                                 // the root is trace node 0 of every simulation
             if (lane == 0) {
                 d.leaf_node[g] = -1;
-                d.counters[(size_t)CNT_TRACE * d.G + g] += depth + 1;
+                count_add(d, CNT_TRACE, g, depth + 1);
             }
         }
         __syncthreads();   // this wave's tree writes are visible to its own SELECT reads below
     }
 
     if (SELECT) {
-        const bool active = uniform_i32(d.done[g]) == 0;
+        const bool active = uniform_i32(s_done) == 0;
         if (!active) {
             if (lane == 0) d.leaf_flag[g] = 0;
             return;
         }
         if (stamp) t1 = clock64();
-        for (int i = lane; i < rc; i += AZK_WAVE) L.board[i] = d.cells[(size_t)g * d.rc_pad + i];
-        const int root_player = uniform_i32(d.to_move[g]);
-        const int root_mc = uniform_i32(d.move_count[g]);
+#pragma unroll
+        for (int k4 = 0; k4 < KSL; k4++) { const int i = lane + AZK_WAVE * k4; if (i < rc) L.board[i] = s_cells[k4]; }
+        const int root_player = uniform_i32(s_player);
+        const int root_mc = uniform_i32(s_mc);
         if (lane == 0) L.path[0] = 0;
         __syncthreads();
         int node = 0, depth = 0, scanned = 0;
         // header of the current node, carried in registers: one dependent round trip per level (the child scan itself
         // brings every candidate's header along, and the winner's is taken from the winning lane)
-        int fc = uniform_i32(d.first_child[base]);
-        int Np = uniform_i32(d.N[base]);
-        uint32_t nmeta = (uint32_t)uniform_i32((int)d.meta[base]);
+        int fc = uniform_i32(r_fc);
+        int Np = uniform_i32(r_N);
+        uint32_t nmeta = (uint32_t)uniform_i32((int)r_meta);
         int node_cell = -1;
-        const bool root_f64 = uniform_i32(d.root_f64[g]) != 0;
+        const bool root_f64 = uniform_i32(s_rootf64) != 0;
+        long long seg_a = 0, seg_b = 0, seg_c = 0, seg_d = 0, seg_t = 0;      // debug only (ablate & 64)
         for (;;) {                                                    // mcts.py:20-23
             const int nch = meta_nch(nmeta);
             if (nch <= 0 || (d.ablate & 2)) break;
+            if (d.ablate & 64) seg_t = clock64();
             const bool f64 = node == 0 && root_f64;
             double bu64 = 0.0;
             float bu32 = 0.f;
@@ -231,47 +298,71 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev d, const float *__restric
             // all of this level's loads are issued before any arithmetic: 4 candidates per lane per 256-child chunk
             for (int c0 = 0; c0 < nch; c0 += 4 * AZK_WAVE) {
                 int Nc[4], fcc[4];
-                double Wc[4], P64[4];
+                double Wc[4], P64[4] = {0.0, 0.0, 0.0, 0.0};
                 float P32[4];
                 uint32_t mc[4];
+                // straight-line loads, no per-slot control flow: a branch inside this loop makes the compiler wait for each
+                // slot's prior before issuing the next slot (four serial round trips per level instead of one)
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     const int i = c0 + lane + AZK_WAVE * k;
                     const size_t ci = base + fc + (i < nch ? i : 0);
-                    Nc[k] = d.N[ci]; Wc[k] = d.W[ci]; mc[k] = d.meta[ci]; fcc[k] = d.first_child[ci];
-                    if (f64) P64[k] = d.rootP[(size_t)g * rc + (i < nch ? i : 0)];
-                    else P32[k] = d.P[ci];
+                    Nc[k] = d.N[ci]; Wc[k] = d.W[ci]; mc[k] = d.meta[ci]; fcc[k] = d.first_child[ci]; P32[k] = d.P[ci];
                 }
+                if (f64) {                                            // root after Dirichlet mixing: float64 priors by child position
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const int i = c0 + lane + AZK_WAVE * k;
+                        P64[k] = d.rootP[(size_t)g * rc + (i < nch ? i : 0)];
+                    }
+                }
+                if (d.ablate & 64) {   // debug only: time the level's memory round trip separately from its arithmetic
+                    const long long ta = clock64();
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    seg_a += clock64() - ta;
+                    seg_d += ta - seg_t;                              // (reusing seg_d: issue of the level's loads)
+                }
+                // branch-free on purpose: every `if` around a division or a compare chain becomes a saveexec/branch pair on
+                // this target, and a level of the walk is a few hundred cycles of arithmetic buried under thousands of those
                 if (f64) {                                            // float64 priors => float64 UCB
                     const double s = sqrt((double)Np);
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
+                        if (c0 + AZK_WAVE * k >= nch) break;             // wave-uniform: no candidate in this slot at all
                         const int i = c0 + lane + AZK_WAVE * k;
-                        if (i >= nch) continue;
-                        double u = P64[k] * s / (double)(Nc[k] + 1);
-                        if (Nc[k] != 0) u = Wc[k] / (double)Nc[k] + u;
-                        if (best == 0x7fffffff || u > bu64) { bu64 = u; best = i; bN = Nc[k]; bmeta = mc[k]; bfc = fcc[k]; }
+                        const double u0 = P64[k] * s / (double)(Nc[k] + 1);
+                        const double q = Wc[k] / (double)Nc[k];          // N = 0: inf/nan, discarded by the select below
+                        const double u = Nc[k] != 0 ? q + u0 : u0;
+                        const bool take = (i < nch) & ((best == 0x7fffffff) | (u > bu64));
+                        bu64 = take ? u : bu64; best = take ? i : best; bN = take ? Nc[k] : bN;
+                        bmeta = take ? mc[k] : bmeta; bfc = take ? fcc[k] : bfc;
                     }
                 } else {                                              // float32 priors => float32 UCB (numpy>=2)
                     const float s = (float)sqrt((double)Np);
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
+                        if (c0 + AZK_WAVE * k >= nch) break;             // wave-uniform: no candidate in this slot at all
                         const int i = c0 + lane + AZK_WAVE * k;
-                        if (i >= nch) continue;
-                        float u = (P32[k] * s) / (float)(Nc[k] + 1);
-                        if (Nc[k] != 0) u = (float)(Wc[k] / (double)Nc[k]) + u;
-                        if (best == 0x7fffffff || u > bu32) { bu32 = u; best = i; bN = Nc[k]; bmeta = mc[k]; bfc = fcc[k]; }
+                        const float u0 = (P32[k] * s) / (float)(Nc[k] + 1);
+                        const float q = (float)(Wc[k] / (double)Nc[k]);  // N = 0: inf/nan, discarded by the select below
+                        const float u = Nc[k] != 0 ? q + u0 : u0;
+                        const bool take = (i < nch) & ((best == 0x7fffffff) | (u > bu32));
+                        bu32 = take ? u : bu32; best = take ? i : best; bN = take ? Nc[k] : bN;
+                        bmeta = take ? mc[k] : bmeta; bfc = take ? fcc[k] : bfc;
                     }
                 }
             }
-            if (f64) wave_argmax_first<double>(bu64, best);
-            else wave_argmax_first<float>(bu32, best);
-            best = uniform_i32(best);
+            if (d.ablate & 64) { const long long tn = clock64(); seg_b += tn - seg_t; seg_t = tn; }
+            if (f64) wave_argmax_first_lane63<double>(bu64, best);
+            else wave_argmax_first_lane63<float>(bu32, best);
+            best = __builtin_amdgcn_readlane(best, 63);               // DPP reduction: the wave's result lives in lane 63
             const int wl = best & 63;                                 // the lane whose own best candidate won
             scanned += nch;
             const int child = fc + best;
-            Np = __shfl(bN, wl); nmeta = (uint32_t)__shfl((int)bmeta, wl); fc = __shfl(bfc, wl);
-            Np = uniform_i32(Np); nmeta = (uint32_t)uniform_i32((int)nmeta); fc = uniform_i32(fc);
+            Np = __builtin_amdgcn_readlane(bN, wl);
+            nmeta = (uint32_t)__builtin_amdgcn_readlane((int)bmeta, wl);
+            fc = __builtin_amdgcn_readlane(bfc, wl);
+            if (d.ablate & 64) { const long long tn = clock64(); seg_c += tn - seg_t; seg_t = tn; }
             const int cellc = meta_cell(nmeta);
             const int mover = (root_player + depth) & 1;
             depth++;
@@ -285,6 +376,10 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev d, const float *__restric
             }
             if (depth + 1 >= d.path_cap) break;
         }
+        if ((d.ablate & 64) && lane == 0) {
+            long long *qq = d.dbg + (size_t)g * 8;
+            qq[0] += seg_a; qq[1] += seg_b; qq[2] += seg_c; qq[3] += seg_d; qq[5] += depth; qq[6] += 1;
+        }
         __syncthreads();
         if (stamp) t2 = clock64();
         const int node_player = (root_player + depth) & 1;
@@ -296,15 +391,15 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev d, const float *__restric
             else if (node_mc == gd.state_dim) term = 0;
         }
         if (lane == 0) {
-            d.counters[(size_t)CNT_SIMS * d.G + g] += 1;
-            d.counters[(size_t)CNT_SCANNED * d.G + g] += scanned;
+            count_add(d, CNT_SIMS, g, 1);
+            count_add(d, CNT_SCANNED, g, scanned);
         }
         if (term >= 0) {
             backup_path(d, base, L.path, depth, (double)term);
             if (lane == 0) {
                 d.leaf_flag[g] = 0;
-                d.counters[(size_t)CNT_TERMINAL * d.G + g] += 1;
-                d.counters[(size_t)CNT_TRACE * d.G + g] += depth + 1;
+                count_add(d, CNT_TERMINAL, g, 1);
+                count_add(d, CNT_TRACE, g, depth + 1);
             }
             return;
         }
@@ -342,11 +437,13 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev d, const float *__restric
         if (lane == 0) {
             d.leaf_node[g] = node; d.leaf_depth[g] = depth; d.leaf_nmoves[g] = nv;
             d.leaf_flag[g] = cached ? 0 : 1;
-            if (cached) d.counters[(size_t)CNT_CACHE_HITS * d.G + g] += 1;
-            d.counters[(size_t)CNT_LEAVES * d.G + g] += cached ? 0 : 1;
+            if (cached) count_add(d, CNT_CACHE_HITS, g, 1);
+            count_add(d, CNT_LEAVES, g, cached ? 0 : 1);
             if (stamp) {
                 long long *q = d.dbg + (size_t)g * 8;
-                q[0] += t1 - t0; q[1] += t2 - t1; q[2] += t3 - t2; q[3] += t4 - t3; q[4] += clock64() - t4; q[5] += depth; q[6] += 1;
+                const long long tend = clock64();
+                q[0] += t1 - t0; q[1] += t2 - t1; q[2] += t3 - t2; q[3] += t4 - t3; q[4] += tend - t4; q[5] += depth; q[6] += 1;
+                if (!(d.ablate & 64) && tend - t0 > q[7]) q[7] = tend - t0;   // slowest simulation of this game
             }
         }
     }
@@ -1391,6 +1488,7 @@ int32_t azk_debug_stamps(azk_engine *e, int64_t *out8_host) {
     std::vector<long long> h((size_t)e->d.G * 8);
     if (hipMemcpy(h.data(), e->d.dbg, h.size() * sizeof(long long), hipMemcpyDeviceToHost) != hipSuccess) return AZK_ERR_HIP;
     for (int k = 0; k < 8; k++) { long long s = 0; for (int g = 0; g < e->d.G; g++) s += h[(size_t)g * 8 + k]; out8_host[k] = s; }
+    { long long mx = 0; for (int g = 0; g < e->d.G; g++) if (h[(size_t)g * 8 + 7] > mx) mx = h[(size_t)g * 8 + 7]; if (getenv("AZK_STAMP_MAX")) out8_host[7] = mx; }
     return AZK_OK;
 }
 

@@ -813,21 +813,25 @@ struct EmbedPoolArgs {
     float eps;
 };
 
-template <int KS, int NH, bool STATIC_REF>
-__global__ __launch_bounds__(256, 2) void k_embed_pool(EmbedPoolArgs a) {
+// NB = boards in flight per workgroup (4 waves each; they share the weight image): NB = 1 with two workgroups per CU, or
+// NB = 3 with one workgroup of 12 waves per CU (three waves per SIMD hide each other's LDS / L2 / barrier stalls).
+template <int KS, int NH, bool STATIC_REF, int NB>
+__global__ __launch_bounds__(256 * NB, NB == 1 ? 2 : 1) void k_embed_pool(EmbedPoolArgs a) {
     constexpr int D = 512, KP = 32 * KS, NACC = 32, NTILE = NACC + 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint4 *bimg = (uint4 *)smem;                                  // [NTILE][KS][64] 16-byte B fragments
-    float *part = (float *)(smem + NTILE * KS * 64 * 16);         // [2 parities][16 rows][4 waves] partial sums of squares
-    uint4 *alut = (uint4 *)(smem + NTILE * KS * 64 * 16 + 512);   // [256] A fragment of 8 patch bits (bit q -> bf16 1.0 in slot q)
-    uint4 *pbits = alut + 256;                                    // [Tp] patch bits per token (<= 128 bits)
+    uint4 *alut = (uint4 *)(smem + NTILE * KS * 64 * 16);         // [256] A fragment of 8 patch bits (bit q -> bf16 1.0 in slot q)
+    const int Tp16 = ((a.T + 15) >> 4) * 16;
+    const int slot = threadIdx.x >> 8;                            // which of the NB boards in flight
+    float *part = (float *)(alut + 256) + slot * 128;             // per board: [2 parities][16 rows][4 waves] partial sums of squares
+    uint4 *pbits = (uint4 *)((float *)(alut + 256) + NB * 128) + slot * Tp16;   // per board: [Tp] patch bits per token (<= 128 bits)
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
     const int nvalid = a.count ? min(a.n, *a.count) : a.n;
-    if ((int)blockIdx.x >= nvalid) return;
+    if ((int)blockIdx.x * NB >= nvalid) return;
 
-    for (int f = tid; f < NTILE * KS * 64; f += 256) {
+    for (int f = threadIdx.x; f < NTILE * KS * 64; f += 256 * NB) {
         const int l = f & 63, s = (f >> 6) % KS, acc = (f >> 6) / KS;
         const int col = acc < NACC ? 128 * (acc >> 3) + 8 * (l & 15) + (acc & 7) : D + (l & 15);
         bimg[f] = *(const uint4 *)(a.wt + (size_t)col * KP + 32 * s + 8 * (l >> 4));
@@ -836,7 +840,7 @@ __global__ __launch_bounds__(256, 2) void k_embed_pool(EmbedPoolArgs a) {
         unsigned r[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) r[i] = (((tid >> (2 * i)) & 1) ? 0x3F80u : 0u) | (((tid >> (2 * i + 1)) & 1) ? 0x3F800000u : 0u);
-        alut[tid] = make_uint4(r[0], r[1], r[2], r[3]);
+        if (slot == 0) alut[tid] = make_uint4(r[0], r[1], r[2], r[3]);
     }
     __syncthreads();
 
@@ -849,7 +853,9 @@ __global__ __launch_bounds__(256, 2) void k_embed_pool(EmbedPoolArgs a) {
     const f32x4 *mbase = (const f32x4 *)a.mtab + lane;
     int par = 0;
 
-    for (int leaf = blockIdx.x; leaf < nvalid; leaf += gridDim.x) {
+    for (int base = blockIdx.x * NB; base < nvalid; base += gridDim.x * NB) {
+        const bool active = base + slot < nvalid;                    // an idle slot recomputes the last board (it shares the barriers) and stores nothing
+        const int leaf = active ? base + slot : nvalid - 1;
         unsigned wbits = 0;                             // lane i holds bits [32 (i-1), 32 i) of the board bit string (lane 0: zeros)
         for (int q = 0; q * 64 < ncell; q++) {
             const int e = q * 64 + lane;
@@ -996,7 +1002,7 @@ __global__ __launch_bounds__(256, 2) void k_embed_pool(EmbedPoolArgs a) {
         for (int j = 0; j < 4; j++) {
             const int head = 4 * l4 + j;
             const float Lh = __shfl(Lt, head & 15);
-            if (head < NH) {
+            if (head < NH && active) {
                 const float inv = 1.0f / Lh;
                 float v[8];
 #pragma unroll
@@ -1007,17 +1013,25 @@ __global__ __launch_bounds__(256, 2) void k_embed_pool(EmbedPoolArgs a) {
     }
 }
 
-template <int KS, int NH, bool SR>
-int launch_embed_pool2(const EmbedPoolArgs &a, hipStream_t st) {
-    const int lds = 33 * KS * 64 * 16 + 512 + 256 * 16 + ((a.T + 15) / 16) * 16 * 16;
+template <int KS, int NH, bool SR, int NB>
+int launch_embed_pool3(const EmbedPoolArgs &a, hipStream_t st) {
+    const int lds = 33 * KS * 64 * 16 + 256 * 16 + NB * (512 + ((a.T + 15) / 16) * 16 * 16);
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void *)k_embed_pool<KS, NH, SR>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return AZK_ERR_HIP;
+        if (hipFuncSetAttribute((const void *)k_embed_pool<KS, NH, SR, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return AZK_ERR_HIP;
         attr_set = true;
     }
-    const int blocks = a.n < 512 ? a.n : 512;                      // two resident workgroups per CU, each walks its boards
-    k_embed_pool<KS, NH, SR><<<blocks, 256, lds, st>>>(a);
+    const int resident = NB == 1 ? 512 : 256;                      // workgroups the chip holds at once; each walks its boards
+    const int want = (a.n + NB - 1) / NB;
+    k_embed_pool<KS, NH, SR, NB><<<want < resident ? want : resident, 256 * NB, lds, st>>>(a);
     return hipGetLastError() == hipSuccess ? AZK_OK : AZK_ERR_HIP;
+}
+
+template <int KS, int NH, bool SR>
+int launch_embed_pool2(const EmbedPoolArgs &a, hipStream_t st) {
+    static int nb = -1;
+    if (nb < 0) { const char *v = getenv("AZK_POOL_NB"); nb = v ? atoi(v) : 1; }     // measured: 3 wins only when every board is live
+    return nb == 1 ? launch_embed_pool3<KS, NH, SR, 1>(a, st) : launch_embed_pool3<KS, NH, SR, 3>(a, st);
 }
 
 template <int KS, int NH>

@@ -9,7 +9,7 @@ from fixture_eval import fixture_logits_value
 G = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 sims = int(sys.argv[2]) if len(sys.argv) > 2 else 800
 moves = int(sys.argv[3]) if len(sys.argv) > 3 else 6
-eng = azk.Engine("gomoku", G, sims, size=15)
+eng = azk.Engine("gomoku", G, sims, size=15, arena_nodes=int(os.environ.get("ARENA", 0)))
 eng.reset_games()
 lg = torch.randn(G, 225, device="cuda") * 0.05
 vl = torch.tanh(torch.randn(G, device="cuda") * 0.1)
@@ -40,7 +40,13 @@ if out[6]:
     n = out[6]
     print("stamps per leaf-sim (cycles): expand %.0f | board+root %.0f | walk %.0f | terminal %.0f | moves %.0f | writes %.0f | depth %.2f" % (
         out[0] / n, out[1] / n, out[2] / n, out[3] / n, out[4] / n, 0, out[5] / n))
+    print("slowest simulation per game: %s %.0f cycles (AZK_STAMP_MAX=1: max over games, else mean over games)" % (
+        "max" if os.environ.get("AZK_STAMP_MAX") else "mean", out[7] if os.environ.get("AZK_STAMP_MAX") else out[7] / G))
 
+if os.environ.get("AZK_TREE_ABLATE") == "64":
+    n = out[6]
+    print("walk per simulation (cycles): load wait %.0f | loads+ucb %.0f (incl. the wait) | argmax+readlanes %.0f | path/board update %.0f | levels %.2f" % (
+        out[0] / n, out[1] / n, out[2] / n, out[3] / n, out[5] / n))
 if os.environ.get("AZK_TREE_ABLATE") == "32":
     n = 8192000
     print("valid_moves sub-phases (cycles per sim): keys %.0f | prefix+rank %.0f | inserts %.0f | emit %.0f | candidates %.1f" % (
