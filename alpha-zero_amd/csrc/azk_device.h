@@ -192,21 +192,28 @@ __device__ int azk_valid_moves(const uint8_t *b, const GameDesc &g, int16_t *mov
     long long s0 = dbgv ? clock64() : 0, s1 = 0, s2 = 0, s3 = 0;
     // row bitmasks (bit c+1 of word r+1; zero border all around): stones (code & 3) and occupied (code != 0)
     uint32_t *rowst = ms.rows, *rowoc = ms.rows + 32;
+    // this lane's cells (lane + 64 k): board codes and (row, col) once, straight-line (no load sits behind a branch);
+    // e / C by multiplication: exact for e < 65536 / C
+    const unsigned inv = (65536u + (unsigned)C - 1u) / (unsigned)C;
+    uint8_t code[KMAX];
+    int rr[KMAX], cc[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; k++) {
+        const int e = lane + AZK_WAVE * k, ec = e < rc ? e : 0;
+        code[k] = b[ec];
+        rr[k] = (int)(((unsigned)ec * inv) >> 16);
+        cc[k] = ec - rr[k] * C;
+    }
     for (int w = lane; w < nwords; w += AZK_WAVE) ms.bits[w] = 0u;
-    for (int i = lane; i < ms.table_size; i += AZK_WAVE) { ms.tabA[i] = 0; ms.tabB[i] = 0; ms.claim[i] = 0xffffffffu; }
-    if (lane < 64) ms.rows[lane] = 0u;
+    if (lane < 8) { ms.tabA[lane] = 0; ms.claim[lane] = 0xffffffffu; }     // the first table; larger ones are cleared when the set grows into them
+    ms.rows[lane] = 0u;
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < KMAX; k++) {
-        const int e = lane + AZK_WAVE * k;
-        if (e < rc) {
-            const uint8_t code = b[e];
-            if (code) {
-                const int r = e / C, c = e - r * C;
-                atomicOr(&rowoc[r + 1], 1u << (c + 1));
-                if (code & 3) atomicOr(&rowst[r + 1], 1u << (c + 1));
-            }
-        }
+        if (AZK_WAVE * k >= rc) break;
+        const bool in = lane + AZK_WAVE * k < rc;
+        if (in && code[k]) atomicOr(&rowoc[rr[k] + 1], 1u << (cc[k] + 1));
+        if (in && (code[k] & 3)) atomicOr(&rowst[rr[k] + 1], 1u << (cc[k] + 1));
     }
     __syncthreads();
     // 1. per empty cell: key = (row-major index of the first stone that adds it) * 8 + (its slot in that stone's add
@@ -215,25 +222,24 @@ __device__ int azk_valid_moves(const uint8_t *b, const GameDesc &g, int16_t *mov
     unsigned key[KMAX];
 #pragma unroll
     for (int k = 0; k < KMAX; k++) {
-        const int e = lane + AZK_WAVE * k;
+        key[k] = 0xffffffffu;
+        if (AZK_WAVE * k >= rc) continue;                             // wave-uniform
+        const int e = lane + AZK_WAVE * k, r = rr[k], c = cc[k];
+        const uint32_t up = rowst[r] >> c, mid = rowst[r + 1] >> c, dn = rowst[r + 2] >> c;   // bit0 = col c-1, bit1 = c, bit2 = c+1
+        const bool empty = e < rc && ((rowoc[r + 1] >> (c + 1)) & 1u) == 0u;
+        const unsigned ib = (unsigned)((r - 1) * C + c - 1), im = (unsigned)(r * C + c - 1), id = (unsigned)((r + 1) * C + c - 1);
+        // select chain from the last candidate to the first (the first adder wins), no branches
         unsigned kk = 0xffffffffu;
-        if (e < rc) {
-            const int r = e / C, c = e - r * C;
-            const uint32_t up = rowst[r] >> c, mid = rowst[r + 1] >> c, dn = rowst[r + 2] >> c;   // bit0 = col c-1, bit1 = c, bit2 = c+1
-            const bool empty = ((rowoc[r + 1] >> (c + 1)) & 1u) == 0u;
-            if (empty) {
-                const unsigned ib = (unsigned)((r - 1) * C + c - 1), im = (unsigned)(r * C + c - 1), id = (unsigned)((r + 1) * C + c - 1);
-                if (up & 1u) kk = ib * 8u + 4u;                     // stone (r-1, c-1) adds e through (+1,+1)
-                else if (up & 2u) kk = (ib + 1u) * 8u + 2u;         // (r-1, c)   through (+1, 0)
-                else if (up & 4u) kk = (ib + 2u) * 8u + 6u;         // (r-1, c+1) through (+1,-1)
-                else if (mid & 1u) kk = im * 8u + 0u;               // (r, c-1)   through (0,+1)
-                else if (mid & 4u) kk = (im + 2u) * 8u + 1u;        // (r, c+1)   through (0,-1)
-                else if (dn & 1u) kk = id * 8u + 7u;                // (r+1, c-1) through (-1,+1)
-                else if (dn & 2u) kk = (id + 1u) * 8u + 3u;         // (r+1, c)   through (-1, 0)
-                else if (dn & 4u) kk = (id + 2u) * 8u + 5u;         // (r+1, c+1) through (-1,-1)
-            }
-            if (kk != 0xffffffffu) atomicOr(&ms.bits[kk >> 5], 1u << (kk & 31));
-        }
+        kk = (dn & 4u) ? (id + 2u) * 8u + 5u : kk;                    // (r+1, c+1) through (-1,-1)
+        kk = (dn & 2u) ? (id + 1u) * 8u + 3u : kk;                    // (r+1, c)   through (-1, 0)
+        kk = (dn & 1u) ? id * 8u + 7u : kk;                           // (r+1, c-1) through (-1,+1)
+        kk = (mid & 4u) ? (im + 2u) * 8u + 1u : kk;                   // (r, c+1)   through (0,-1)
+        kk = (mid & 1u) ? im * 8u + 0u : kk;                          // (r, c-1)   through (0,+1)
+        kk = (up & 4u) ? (ib + 2u) * 8u + 6u : kk;                    // (r-1, c+1) through (+1,-1)
+        kk = (up & 2u) ? (ib + 1u) * 8u + 2u : kk;                    // (r-1, c)   through (+1, 0)
+        kk = (up & 1u) ? ib * 8u + 4u : kk;                           // stone (r-1, c-1) adds e through (+1,+1)
+        kk = empty ? kk : 0xffffffffu;
+        if (kk != 0xffffffffu) atomicOr(&ms.bits[kk >> 5], 1u << (kk & 31));
         key[k] = kk;
     }
     __syncthreads();
@@ -279,13 +285,16 @@ __device__ int azk_valid_moves(const uint8_t *b, const GameDesc &g, int16_t *mov
     //    committed table (probe = slot i..i+9 then perturb, LINEAR_PROBES = 9); atomicMin claims on the chosen (first
     //    empty) slot expose clashes; the conflict-free PREFIX commits (a later key may only commit once every earlier key
     //    has, otherwise an earlier key re-probing could have reached its slot first); the rest retry next round.
+    unsigned stamp = 0x00ffffffu;     // claims carry a per-round stamp that only decreases: a newer round's atomicMin always beats
+                                      // whatever an older round left in the slot, so claims never need to be reset
     auto insert_batch = [&](uint16_t *tb, unsigned msk, const int16_t *list, int count) {
         for (int c0 = 0; c0 < count; c0 += AZK_WAVE) {
             const int idx = c0 + lane;
             const bool have = idx < count;
-            const unsigned keyv = have ? (unsigned)list[idx] : 0u;   // cell + 1
+            const unsigned keyv = have ? (unsigned)list[idx] : 1u;   // cell + 1
             const int cell = (int)keyv - 1;
-            const unsigned long long h = py_tuple2_hash(cell / C, cell % C);
+            const int hr = (int)(((unsigned)cell * inv) >> 16);
+            const unsigned long long h = py_tuple2_hash(hr, cell - hr * C);
             bool placed = !have;
             while (__ballot(!placed) != 0ull) {
                 unsigned slot = 0;
@@ -293,25 +302,32 @@ __device__ int azk_valid_moves(const uint8_t *b, const GameDesc &g, int16_t *mov
                     unsigned long long perturb = h;
                     unsigned i = (unsigned)h & msk;
                     for (;;) {
-                        const unsigned win = (i + 9 <= msk) ? 10u : 1u;
-                        bool found = false;
-                        for (unsigned j = 0; j < win; j++)
-                            if (tb[i + j] == 0) { slot = i + j; found = true; break; }
-                        if (found) break;
+                        if (i + 9 <= msk) {
+                            // the ten-slot window in one round trip: four aligned 64-bit reads cover slots base .. base+15;
+                            // entries are < 0x8000, so (x + 0x7fff) sets bit 15 of a 16-bit lane exactly when it is non-zero
+                            const unsigned bs = i & ~3u, off = i - bs;
+                            const unsigned long long *p = (const unsigned long long *)(tb + bs);
+                            const unsigned long long w0 = p[0], w1 = p[1], w2 = p[2], w3 = p[3];
+                            const unsigned long long K = 0x7fff7fff7fff7fffull, T = 0x8000800080008000ull;
+                            auto z4 = [&](unsigned long long w) -> unsigned {       // bit q set <=> 16-bit lane q of w is zero
+                                const unsigned long long y = ~(w + K) & T;
+                                return (unsigned)(((y >> 15) * 0x0001000200040008ull) >> 48) & 0xfu;     // lane q -> bit q
+                            };
+                            unsigned z = z4(w0) | (z4(w1) << 4) | (z4(w2) << 8) | (z4(w3) << 12);
+                            z = (z >> off) & 0x3ffu;
+                            if (z) { slot = i + (unsigned)__ffs((int)z) - 1u; break; }
+                        } else if (tb[i] == 0) { slot = i; break; }
                         perturb >>= 5;
                         i = (unsigned)((unsigned long long)i * 5 + 1 + perturb) & msk;
                     }
-                    atomicMin(&ms.claim[slot], (unsigned)lane);
+                    atomicMin(&ms.claim[slot], (stamp << 6) | (unsigned)lane);
                 }
                 __syncthreads();
-                const bool conflict = !placed && ms.claim[slot] != (unsigned)lane;
+                const bool conflict = !placed && ms.claim[slot] != ((stamp << 6) | (unsigned)lane);
                 const unsigned long long cb = __ballot(conflict);
                 const int first_bad = cb ? __ffsll((long long)cb) - 1 : AZK_WAVE;
-                __syncthreads();
-                if (!placed) {
-                    ms.claim[slot] = 0xffffffffu;
-                    if (lane < first_bad) { tb[slot] = (uint16_t)keyv; placed = true; }
-                }
+                if (!placed && lane < first_bad) { tb[slot] = (uint16_t)keyv; placed = true; }
+                stamp--;
                 __syncthreads();
             }
         }
@@ -341,7 +357,10 @@ __device__ int azk_valid_moves(const uint8_t *b, const GameDesc &g, int16_t *mov
                 const unsigned long long bm = __ballot(kv != 0);
                 if (kv) moves[nlist + __popcll(bm & ((1ull << lane) - 1ull))] = (int16_t)kv;   // `moves` doubles as the scratch list
                 nlist += __popcll(bm);
-                if (i <= mask) tab[i] = 0;
+            }
+            for (unsigned i = lane; i < newsize; i += AZK_WAVE) {       // the table the set grows into starts empty; new claim slots start free
+                other[i] = 0;
+                if (i > mask) ms.claim[i] = 0xffffffffu;
             }
             __syncthreads();
             uint16_t *tmp = tab; tab = other; other = tmp;
