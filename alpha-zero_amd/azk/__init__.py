@@ -27,7 +27,7 @@ SYMBOLS = [
     "azk_rules_check_winner", "azk_rules_canonical", "azk_softmax_rows",
     "azk_step_tree", "azk_step_gather", "azk_recycle_finished", "azk_nn_patch_embed", "azk_nn_cls_attention", "azk_nn_patch_embed_scores", "azk_nn_cls_pool", "azk_debug_stamps", "azk_emit_finished", "azk_clear_cache", "azk_nn_heads_finalize", "azk_nn_layernorm_rows",
     "azk_vanilla_set_rng", "azk_vanilla_get_rng", "azk_vanilla_search", "azk_nn_embed_pool",
-    "azk_nn_gemm_rows", "azk_nn_layernorm_sum", "azk_nn_heads_finalize_sum",
+    "azk_nn_gemm_rows", "azk_nn_layernorm_sum", "azk_nn_heads_finalize_sum", "azk_nn_ln_heads",
 ]
 
 
@@ -119,6 +119,7 @@ def lib():
     L.azk_recycle_finished.argtypes = [vp, vp, vp]
     L.azk_nn_patch_embed_scores.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, C.c_float, vp, vp]
     L.azk_nn_embed_pool.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, C.c_float, vp, vp]
+    L.azk_nn_ln_heads.argtypes = [vp, vp, vp, C.c_float, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]
     L.azk_nn_gemm_rows.argtypes = [vp, i32, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]
     L.azk_nn_layernorm_sum.argtypes = [vp, i32, i32, vp, vp, vp, vp, C.c_float, vp, vp, vp, i32, i32, vp, vp]
     L.azk_nn_heads_finalize_sum.argtypes = [vp, i32, i32, i32, vp, i32, i32, vp, vp, vp, vp]
@@ -630,3 +631,14 @@ def nn_heads_finalize_sum(partials, bias, action_dim, logits_out, values_out, co
                                          _p(values_out), _p(count), _stream())
     if rc != 0:
         raise AzkError(f"azk_nn_heads_finalize_sum failed ({rc})")
+
+
+def nn_ln_heads(x, ln_w, ln_b, w_packed, bias, action_dim, logits_out, values_out, eps=1e-5, count=None):
+    """Final LayerNorm + merged policy/value head + finalize in one launch: x bf16 [n, D] -> logits f32 [n, A], values f32 [n]."""
+    torch = _torch()
+    assert x.dtype == torch.bfloat16 and x.is_contiguous()
+    n, d = x.shape
+    rc = lib().azk_nn_ln_heads(_p(x), _p(ln_w), _p(ln_b), float(eps), _p(w_packed), _p(bias), n, d, bias.numel(), int(action_dim),
+                               _p(logits_out), _p(values_out), _p(count), _stream())
+    if rc != 0:
+        raise AzkError(f"azk_nn_ln_heads failed ({rc})")

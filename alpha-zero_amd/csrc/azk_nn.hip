@@ -1084,8 +1084,12 @@ struct GemmArgs {
     int M, N, K, ksplit;
     const int *count;
     float *P;                  // mode 0: [ksplit][M][N] float32 partial sums
-    const float *bias;         // mode 1: [N]
+    const float *bias;         // modes 1, 2: [N]
     unsigned short *out;       // mode 1: [M][N] bf16 = gelu(A W^T + bias)
+    const float *ln_w, *ln_b;  // mode 2: LayerNorm affine over the K input columns (applied to A on the fly)
+    float ln_eps;
+    float *logits, *values;    // mode 2: float32 [M][action_dim], [M] = tanh(column action_dim)
+    int action_dim;
 };
 
 template <int MODE, int RT, int KU>   // RT = 16-row tiles per wave (wave tile 16 RT rows x 64 columns); KU = k-steps whose fragments
@@ -1111,8 +1115,42 @@ __global__ __launch_bounds__(256, 2) void k_gemm_rows(GemmArgs a) {
             ap[i] = a.A + (size_t)row * a.lda + 32 * ks0 + 8 * l4;
         }
         const uint4 *bp = a.Wp + ((size_t)ng * ksteps + ks0) * 4 * 64 + lane;
+        // MODE 2: A is LayerNorm(rows) - the wave reads whole rows (ksplit 1), so it takes the row statistics itself in a
+        // first pass (fp32 sums over the lane's fragments, then across the four k-groups of a row)
+        float mean[RT], rstd[RT];
+        if (MODE == 2) {
+            float s1[RT], s2[RT];
+#pragma unroll
+            for (int i = 0; i < RT; i++) { s1[i] = 0.f; s2[i] = 0.f; }
+            for (int kb = 0; kb < nks; kb += KU) {
+                uint4 raw[KU][RT];
+#pragma unroll
+                for (int u = 0; u < KU; u++)
+#pragma unroll
+                    for (int i = 0; i < RT; i++) raw[u][i] = *(const uint4 *)(ap[i] + 32 * (kb + u));
+#pragma unroll
+                for (int u = 0; u < KU; u++)
+#pragma unroll
+                    for (int i = 0; i < RT; i++) {
+                        const unsigned w4[4] = {raw[u][i].x, raw[u][i].y, raw[u][i].z, raw[u][i].w};
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            const float lo = __uint_as_float(w4[q] << 16), hi = __uint_as_float(w4[q] & 0xffff0000u);
+                            s1[i] += lo + hi; s2[i] += lo * lo + hi * hi;
+                        }
+                    }
+            }
+#pragma unroll
+            for (int i = 0; i < RT; i++) {
+                s1[i] += __shfl_xor(s1[i], 16); s1[i] += __shfl_xor(s1[i], 32);
+                s2[i] += __shfl_xor(s2[i], 16); s2[i] += __shfl_xor(s2[i], 32);
+                mean[i] = s1[i] / (float)a.K;
+                rstd[i] = rsqrtf(fmaxf(s2[i] / (float)a.K - mean[i] * mean[i], 0.f) + a.ln_eps);
+            }
+        }
         for (int kb = 0; kb < nks; kb += KU) {
             union { uint4 u; bf16x8 v; } af[KU][RT], bf[KU][4];
+            f32x4 lw[KU][2], lb[KU][2];
 #pragma unroll
             for (int u = 0; u < KU; u++) {
                 const int ks = kb + u;                                // nks is a multiple of KU (checked by the host)
@@ -1120,8 +1158,28 @@ __global__ __launch_bounds__(256, 2) void k_gemm_rows(GemmArgs a) {
                 for (int i = 0; i < RT; i++) af[u][i].u = *(const uint4 *)(ap[i] + 32 * ks);
 #pragma unroll
                 for (int c = 0; c < 4; c++) bf[u][c].u = bp[(ks * 4 + c) * 64];
+                if (MODE == 2) {
+                    const float *pw = a.ln_w + 32 * (ks0 + ks) + 8 * l4, *pb = a.ln_b + 32 * (ks0 + ks) + 8 * l4;
+                    lw[u][0] = *(const f32x4 *)pw; lw[u][1] = *(const f32x4 *)(pw + 4);
+                    lb[u][0] = *(const f32x4 *)pb; lb[u][1] = *(const f32x4 *)(pb + 4);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);        // every load of the batch is issued before its first MFMA
+            if (MODE == 2) {
+#pragma unroll
+                for (int u = 0; u < KU; u++)
+#pragma unroll
+                    for (int i = 0; i < RT; i++) {
+                        const unsigned w4[4] = {af[u][i].u.x, af[u][i].u.y, af[u][i].u.z, af[u][i].u.w};
+                        float v[8];
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            v[2 * q] = (__uint_as_float(w4[q] << 16) - mean[i]) * rstd[i] * lw[u][q >> 1][(2 * q) & 3] + lb[u][q >> 1][(2 * q) & 3];
+                            v[2 * q + 1] = (__uint_as_float(w4[q] & 0xffff0000u) - mean[i]) * rstd[i] * lw[u][q >> 1][(2 * q + 1) & 3] + lb[u][q >> 1][(2 * q + 1) & 3];
+                        }
+                        af[u][i].u = pack8(v);
+                    }
+            }
 #pragma unroll
             for (int u = 0; u < KU; u++) {
 #pragma unroll
@@ -1132,7 +1190,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_rows(GemmArgs a) {
         }
         const int col0 = 64 * ng + 4 * l15;
         f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-        if (MODE == 1) bv = *(const f32x4 *)(a.bias + col0);
+        if (MODE >= 1) bv = *(const f32x4 *)(a.bias + col0);
 #pragma unroll
         for (int i = 0; i < RT; i++)
 #pragma unroll
@@ -1142,6 +1200,14 @@ __global__ __launch_bounds__(256, 2) void k_gemm_rows(GemmArgs a) {
                 f32x4 v = {acc[i][0][j], acc[i][1][j], acc[i][2][j], acc[i][3][j]};
                 if (MODE == 0) {
                     *(f32x4 *)(a.P + ((size_t)s * a.M + row) * a.N + col0) = v;
+                } else if (MODE == 2) {                               // merged heads: logits float32, tanh(value) (nn.py:82-83)
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        const int col = col0 + c;
+                        const float x = v[c] + bv[c];
+                        if (col < a.action_dim) a.logits[(size_t)row * a.action_dim + col] = x;
+                        else if (col == a.action_dim) a.values[row] = tanhf(x);
+                    }
                 } else {
 #pragma unroll
                     for (int c = 0; c < 4; c++) { const float x = v[c] + bv[c]; v[c] = 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }   // nn.GELU (exact)
@@ -1240,11 +1306,29 @@ extern "C" int32_t azk_nn_gemm_rows(const void *a_bf16_dev, int32_t lda, const v
     GemmArgs a;
     a.A = (const unsigned short *)a_bf16_dev; a.lda = lda; a.Wp = (const uint4 *)w_packed_dev; a.M = m; a.N = n_out; a.K = k;
     a.ksplit = ksplit; a.count = n_valid_dev; a.P = partials_out_dev; a.bias = bias_dev; a.out = (unsigned short *)gelu_out_bf16_dev;
+    a.ln_w = a.ln_b = nullptr; a.ln_eps = 0.f; a.logits = a.values = nullptr; a.action_dim = 0;
     const long long items = (long long)((m + 31) / 32) * (n_out / 64) * ksplit;      // 32-row x 64-column wave tiles
     const unsigned blocks = (unsigned)((items + 3) / 4 < 4096 ? (items + 3) / 4 : 4096);
     hipStream_t st = (hipStream_t)stream;
     if (partials_out_dev) k_gemm_rows<0, 2, 4><<<blocks, 256, 0, st>>>(a);
     else k_gemm_rows<1, 2, 4><<<blocks, 256, 0, st>>>(a);
+    return hipGetLastError() == hipSuccess ? AZK_OK : AZK_ERR_HIP;
+}
+
+extern "C" int32_t azk_nn_ln_heads(const void *x_bf16_dev, const float *ln_w_dev, const float *ln_b_dev, float eps,
+                                   const void *w_packed_dev, const float *bias_dev, int32_t n, int32_t embed_dim, int32_t n_out_padded,
+                                   int32_t action_dim, float *logits_out_dev, float *values_out_dev, const int32_t *n_valid_dev,
+                                   void *stream) {
+    if (!x_bf16_dev || !ln_w_dev || !ln_b_dev || !w_packed_dev || !bias_dev || !logits_out_dev || !values_out_dev) return AZK_ERR_ARG;
+    if (n < 0 || embed_dim < 128 || (embed_dim & 127) || n_out_padded < 64 || (n_out_padded & 63) || action_dim + 1 > n_out_padded) return AZK_ERR_ARG;
+    if (n == 0) return AZK_OK;
+    GemmArgs a;
+    a.A = (const unsigned short *)x_bf16_dev; a.lda = embed_dim; a.Wp = (const uint4 *)w_packed_dev; a.M = n; a.N = n_out_padded;
+    a.K = embed_dim; a.ksplit = 1; a.count = n_valid_dev; a.P = nullptr; a.bias = bias_dev; a.out = nullptr;
+    a.ln_w = ln_w_dev; a.ln_b = ln_b_dev; a.ln_eps = eps; a.logits = logits_out_dev; a.values = values_out_dev; a.action_dim = action_dim;
+    const long long items = (long long)((n + 15) / 16) * (n_out_padded / 64);       // 16-row x 64-column wave tiles
+    const unsigned blocks = (unsigned)((items + 3) / 4 < 4096 ? (items + 3) / 4 : 4096);
+    k_gemm_rows<2, 1, 4><<<blocks, 256, 0, (hipStream_t)stream>>>(a);
     return hipGetLastError() == hipSuccess ? AZK_OK : AZK_ERR_HIP;
 }
 

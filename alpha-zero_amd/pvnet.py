@@ -120,6 +120,7 @@ class PolicyValueNet:
         self.hip_tail = False           # set by _prepare_folded when the hand-written tail kernels cover this configuration
         self.use_hip_tail = False       # True: the cls-row tail on azk_nn_gemm_rows (every launch honours the live count; measured
                                         # 87 us vs 82 us for the hipBLASLt tail at 2048 rows / 1150 live, so the library GEMMs stay the default)
+        self.fuse_ln_heads = True       # final LayerNorm + heads + finalize as one hand-written launch (needs hip_tail's packed weights)
         self.fused_embed_pool = False   # set by _prepare_folded when azk_nn_embed_pool covers this configuration
         self.kernel_timers = None   # optional (embed_timer, pool_timer) with start()/stop(): HIP-event timing of the two kernels
         self.live_count = None      # optional int32 CUDA tensor: number of valid rows at the head of the batch (graph stepping)
@@ -303,6 +304,15 @@ class PolicyValueNet:
         else:
             h = F.gelu(F.linear(h, w["blocks.0.mlp.0.weight"], w["blocks.0.mlp.0.bias"]))
         x2 = x1.addmm_(h, f["W3T"])                                                                    # nn.py:59-60 (in place: no copy)
+        if self.hip_tail and self.fuse_ln_heads:
+            # final LayerNorm + merged heads + finalize in one launch (azk_nn_ln_heads), nn.py:78-83
+            if self.out_buffers is not None:
+                lb, vb = self.out_buffers
+            else:
+                lb = torch.empty((n, A), dtype=torch.float32, device=z.device)
+                vb = torch.empty(n, dtype=torch.float32, device=z.device)
+            azk.nn_ln_heads(x2, f["lnf_w"], f["lnf_b"], f["WhP"], f["bh_f"], A, lb, vb, count=self.live_count)
+            return lb, (vb if self.out_buffers is not None else vb[:, None])
         out = F.linear(azk.nn_layernorm_rows(x2, f["lnf_w"], f["lnf_b"], 1e-5, count=self.live_count), f["Wh"], f["bh"])   # nn.py:78-83
         if self.out_buffers is not None:
             # the step graph's own float32 buffers: conversion, slicing and tanh in one launch (azk_nn_heads_finalize)

@@ -158,7 +158,7 @@ def main():
         launches = args.steps * args.sims * runner.n_split      # k_tree launches (one per game group per simulation)
         alg_bytes = algorithmic_bytes(c, A) / launches
         roof = None
-        traffic, traffic_src = None, None
+        traffic, traffic_src, pmc = None, None, {}
         try:        # HBM bytes per k_tree launch from the PMC passes committed under profiles/ (FETCH_SIZE + WRITE_SIZE)
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
             traffic = pmc["k_tree<true, true>"]["bytes_per_launch"]
@@ -193,9 +193,15 @@ def main():
             kreal = cfg.channels * cfg.patch_size ** 2
             per_board = 2 * (T_tok - 1) * Dm * kreal + 2 * T_tok * 16 * kreal + 2 * T_tok * cfg.num_heads * Dm
             fl = per_board * live
+            ep_traffic = None
+            try:
+                ep_traffic = next(v["bytes_per_launch"] for k_, v in pmc.items() if k_.startswith("k_embed_pool"))
+            except Exception:
+                pass
             kernels.append({"kernel": "k_embed_pool", "bound": "mfma", "achieved": fl / (ms * 1e-3) / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS,
                             "unit": "TFLOP/s", "frac": fl / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, "avg_launch_us": ms * 1e3,
-                            "algorithmic_flops_per_launch": fl, "traffic": None, "event_samples": len(ch.pairs),
+                            "algorithmic_flops_per_launch": fl, "traffic": ep_traffic,
+                            "traffic_source": traffic_src if ep_traffic else None, "event_samples": len(ch.pairs),
                             "note": f"{per_board} flop per live board (conv + score columns + weighted token sum) x {live:.0f} live boards per launch; "
                                     "HBM traffic is 9 KB per board (board in, z out): the kernel is bound by VALU/MFMA issue and LDS, not HBM"})
         dominant = max(kernels, key=lambda k: k["avg_launch_us"]) if kernels else None

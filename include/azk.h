@@ -282,6 +282,12 @@ int32_t azk_nn_embed_pool(const void *boards_dev, int32_t boards_are_f32, const 
 int32_t azk_nn_gemm_rows(const void *a_bf16_dev, int32_t lda, const void *w_packed_dev, int32_t m, int32_t n_out, int32_t k,
                          int32_t ksplit, float *partials_out_dev, const float *bias_dev, void *gelu_out_bf16_dev,
                          const int32_t *n_valid_dev, void *stream);
+/* azk_nn_ln_heads: final LayerNorm + merged policy/value head + finalize in one launch (nn.py:78-83 for the cls row):
+ *   logits[n][A] = LN(x) Wh^T + bh (float32), values[n] = tanh(column A).  w_packed_dev: the merged head weight
+ *   [n_out_padded][embed_dim] in azk_nn_gemm_rows' packing; each wave reads whole rows and takes their statistics itself. */
+int32_t azk_nn_ln_heads(const void *x_bf16_dev, const float *ln_w_dev, const float *ln_b_dev, float eps, const void *w_packed_dev,
+                        const float *bias_dev, int32_t n, int32_t embed_dim, int32_t n_out_padded, int32_t action_dim,
+                        float *logits_out_dev, float *values_out_dev, const int32_t *n_valid_dev, void *stream);
 int32_t azk_nn_layernorm_sum(const float *partials_dev, int32_t nsplit, int32_t m_stride, const float *bias_dev,
                              const void *resid_bf16_dev, const float *w_dev, const float *b_dev, float eps, void *y_bf16_dev,
                              const float *add_bias_dev, void *x_out_bf16_dev, int32_t n, int32_t embed_dim,

@@ -214,3 +214,27 @@ def test_hand_written_tail_matches_library_tail():
     azk.nn_gemm_rows(a, wp, 256, bias=bias, gelu_out=g)
     refg = F.gelu(torch.cat([ref, torch.zeros(150, 56, device="cuda")], 1) + bias)
     assert (g.float() - refg).abs().max().item() < 2e-2
+
+
+def test_fused_final_norm_and_heads_vs_torch_fp32():
+    """azk_nn_ln_heads (final LayerNorm + merged policy/value head + tanh in one launch, the default cls tail) against
+    fp32 PyTorch on the same bf16 input: logits to 2e-2 (bf16 operands, scale ~0.5), value to 5e-3; honours the row count."""
+    import azk
+    cfg = NetConfig(15, 15, 2, 225, 5, 512, 8, 1)
+    net = PolicyValueNet(cfg, seed=4, device="cuda", dtype=torch.bfloat16, path="clsfold")
+    assert net.hip_tail and net.fuse_ln_heads
+    f, m = net._fold, net.master
+    n, live = 210, 77
+    torch.manual_seed(1)
+    x = (torch.randn(n, 512, device="cuda") * 1.3 + 0.2).to(torch.bfloat16)
+    y = F.layer_norm(x.float(), (512,), m["norm.weight"].cuda(), m["norm.bias"].cuda(), 1e-5)
+    ref_l = y @ m["policy_head.weight"].cuda().t() + m["policy_head.bias"].cuda()
+    ref_v = torch.tanh(y @ m["value_head.weight"].cuda().t() + m["value_head.bias"].cuda()).reshape(-1)
+    lb = torch.full((n, 225), 5.0, device="cuda")
+    vb = torch.full((n,), 5.0, device="cuda")
+    azk.nn_ln_heads(x, f["lnf_w"], f["lnf_b"], f["WhP"], f["bh_f"], 225, lb, vb)
+    assert (lb - ref_l).abs().max().item() < 2e-2 and (vb - ref_v).abs().max().item() < 5e-3
+    lb2 = torch.full((n, 225), 5.0, device="cuda")
+    vb2 = torch.full((n,), 5.0, device="cuda")
+    azk.nn_ln_heads(x, f["lnf_w"], f["lnf_b"], f["WhP"], f["bh_f"], 225, lb2, vb2, count=torch.tensor([live], dtype=torch.int32, device="cuda"))
+    assert torch.equal(lb2[:live], lb[:live]) and bool((lb2[live:] == 5.0).all()) and bool((vb2[live:] == 5.0).all())

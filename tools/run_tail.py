@@ -14,17 +14,18 @@ net = PolicyValueNet(cfg, seed=0, device="cuda", dtype=torch.bfloat16, path="cls
 z = torch.randn(n, 8, 512, device="cuda").to(torch.bfloat16) * 0.1
 lb = torch.empty(n, 225, device="cuda"); vb = torch.empty(n, device="cuda")
 net.out_buffers = (lb, vb)
-net.use_hip_tail = not os.environ.get("TORCH_TAIL")
+net.use_hip_tail = bool(os.environ.get("HIP_TAIL"))
+net.fuse_ln_heads = not os.environ.get("NO_FUSE_HEADS")
 live = int(os.environ.get("LIVE", n))
 net.live_count = torch.tensor([live], dtype=torch.int32, device="cuda")
 if len(sys.argv) > 3:     # accuracy: hand-written tail vs library tail on the same z
     with torch.no_grad():
-        net.use_hip_tail = True; l1, v1 = net.tail_fast(z); l1, v1 = l1.clone(), v1.clone()
-        net.use_hip_tail = False; l2, v2 = net.tail_fast(z)
+        net.use_hip_tail = False; net.fuse_ln_heads = True; l1, v1 = net.tail_fast(z); l1, v1 = l1.clone(), v1.clone()
+        net.fuse_ln_heads = False; l2, v2 = net.tail_fast(z)
     torch.cuda.synchronize()
-    print("hip vs torch tail: logits max diff", (l1[:live] - l2[:live]).abs().max().item(), "values", (v1[:live] - v2[:live]).abs().max().item(),
+    print("fused ln+heads vs library tail: logits max diff", (l1[:live] - l2[:live]).abs().max().item(), "values", (v1[:live] - v2[:live]).abs().max().item(),
           "| logits scale", l2[:live].abs().mean().item())
-    net.use_hip_tail = not os.environ.get("TORCH_TAIL")
+    net.use_hip_tail = bool(os.environ.get("HIP_TAIL")); net.fuse_ln_heads = not os.environ.get("NO_FUSE_HEADS")
 t0 = time.time()
 with torch.no_grad():
     for _ in range(3):
