@@ -89,7 +89,7 @@ def main():
     ap.add_argument("--nn-path", default="clsfold", choices=["clsfold", "cls", "full"])
     ap.add_argument("--no-graph", action="store_true", help="eager stepping with a host sync per simulation (n_leaf-sized batches)")
     ap.add_argument("--split", type=int, default=1, help="independent game groups stepped on separate streams inside the step graph")
-    ap.add_argument("--cache-entries", type=int, default=8192, help="per-game eval-cache entries (MCTS.cache); 0 = off")
+    ap.add_argument("--cache-entries", type=int, default=32768, help="per-game eval-cache entries (MCTS.cache; 64 GB of HBM at 2048 games x 32768); 0 = off")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="wall-clock budget of the CPU baseline leg (0 = skip)")
     ap.add_argument("--seed", type=int, default=0)
     args = ap.parse_args()
