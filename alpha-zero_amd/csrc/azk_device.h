@@ -444,9 +444,14 @@ __device__ float azk_pairwise_sum(const float *a, int n, float *racc) {
     int ml = q == 0 ? l0 : (q == 1 ? l1 : (q == 2 ? l2 : (q == 3 ? l3 : 0)));
     if (ml >= 8) {
         const float *p = a + ms;
-        float r = p[j];
-        int lim = ml - (ml % 8);
-        for (int i = 8; i < lim; i += 8) r += p[i + j];
+        const int lim = ml - (ml % 8);
+        // a leaf block has at most 128 elements: 16 strided terms per accumulator, all loads in flight before the first add
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) v[u] = p[(8 * u < lim ? 8 * u : 0) + j];
+        float r = v[0];
+#pragma unroll
+        for (int u = 1; u < 16; u++) r = (8 * u < lim) ? r + v[u] : r;
         racc[lane] = r;
     }
     __syncthreads();
