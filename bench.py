@@ -92,6 +92,9 @@ def main():
     ap.add_argument("--cache-entries", type=int, default=32768, help="per-game eval-cache entries (MCTS.cache; 64 GB of HBM at 2048 games x 32768); 0 = off")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="wall-clock budget of the CPU baseline leg (0 = skip)")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--train-step", action="store_true",
+                    help="BASELINE.json configs[4]: one train.py step (batch 512 per GPU, Adam lr 2.5e-4, one fused gradient bucket "
+                         "all-reduced over RCCL) after every move, fed from the device-resident replay ring")
     args = ap.parse_args()
 
     import torch
@@ -111,9 +114,27 @@ def main():
     cfg = NetConfig(args.size, args.size, 2, A, 5, 512, 8, 1)
     net = PolicyValueNet(cfg, seed=0, device=f"cuda:{local_rank}", dtype=torch.bfloat16, path=args.nn_path)
     kt = KernelTimer(stride=16)
+    replay = trainer = None
+    if args.train_step:
+        from azk import DeviceReplay
+        from trainer import Trainer
+        replay = DeviceReplay(400000, cfg.channels, cfg.rows, cfg.cols, cfg.action_dim, device=torch.device("cuda", local_rank))
+        trainer = Trainer(cfg, net.state_dict(), device=f"cuda:{local_rank}")
     runner = SelfPlayRunner("gomoku", net, args.games, args.sims, size=args.size, seed=args.seed,
                             first_global_game=shard_range(args.games, rank)[0], device=local_rank, leaf_dtype="bfloat16",
-                            recycle=True, kernel_timer=kt, use_graph=not args.no_graph, n_split=args.split, cache_entries=args.cache_entries)
+                            recycle=True, kernel_timer=kt, use_graph=not args.no_graph, n_split=args.split, cache_entries=args.cache_entries,
+                            replay=replay)
+    train_ms = []
+
+    def train_one():
+        """train.train with one iteration (train.py:85-123): fresh Adam, the reference's loss, gradient bucket all-reduce."""
+        if replay.size() < 512:
+            return
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        trainer.train([replay.sample(512)], 0.00025, dist=dist if world > 1 else None)
+        b.record()
+        train_ms.append((a, b))
     eng = runner.eng
 
     def sync_all():
@@ -124,6 +145,9 @@ def main():
 
     for _ in range(args.warmup):
         runner.play_move()
+        if args.train_step:
+            train_one()
+    train_ms.clear()
     runner.reset_counters()
     plies0, fin0, finp0 = runner.plies_played, runner.games_finished, runner.finished_plies
     kt.enabled = True
@@ -131,6 +155,8 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         runner.play_move()
+        if args.train_step:
+            train_one()
     sync_all()
     dt = time.perf_counter() - t0
     kt.enabled = False
@@ -224,6 +250,11 @@ def main():
             "mean_plies_per_game": mean_plies, "game_length_source": src, "games_finished_in_window": fin_window,
             "plies_in_window": plies_all, "counters_rank0": c, "roofline": dominant, "roofline_puct": roof, "kernel_rooflines": kernels,
         }
+        if args.train_step:
+            out["config"]["workload"] += " + one train step (batch 512 per GPU, fp32 autograd, fused gradient bucket all-reduce) after every move (BASELINE.json configs[4])"
+            out["train_step"] = {"steps": len(train_ms), "ms_per_train_step": (sum(x.elapsed_time(y) for x, y in train_ms) / len(train_ms)) if train_ms else None,
+                                 "batch_per_gpu": 512, "replay_tuples_rank0": replay.size(),
+                                 "note": "the network weights used for self-play are not refreshed inside the timed window (promotion happens per iteration in train_loop.py)"}
         if args.cpu_seconds > 0 and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.sims, args.cpu_seconds, mean_plies)
             out["gpu_over_cpu"] = games_per_s / out["cpu_baseline"]["value"]
