@@ -813,14 +813,13 @@ struct EmbedPoolArgs {
     float eps;
 };
 
-// NB = boards in flight per workgroup (4 waves each; they share the weight image): NB = 1 with two workgroups per CU, or
-// NB = 3 with one workgroup of 12 waves per CU (three waves per SIMD hide each other's LDS / L2 / barrier stalls).
+// NB = boards in flight per workgroup (4 waves each): NB = 1 with two workgroups per CU, or NB = 3 with one workgroup of
+// 12 waves per CU.
 template <int KS, int NH, bool STATIC_REF, int NB>
 __global__ __launch_bounds__(256 * NB, NB == 1 ? 2 : 1) void k_embed_pool(EmbedPoolArgs a) {
-    constexpr int D = 512, KP = 32 * KS, NACC = 32, NTILE = NACC + 1;
+    constexpr int D = 512, KP = 32 * KS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint4 *bimg = (uint4 *)smem;                                  // [NTILE][KS][64] 16-byte B fragments
-    uint4 *alut = (uint4 *)(smem + NTILE * KS * 64 * 16);         // [256] A fragment of 8 patch bits (bit q -> bf16 1.0 in slot q)
+    uint4 *alut = (uint4 *)smem;                                  // [256] A fragment of 8 patch bits (bit q -> bf16 1.0 in slot q)
     const int Tp16 = ((a.T + 15) >> 4) * 16;
     const int slot = threadIdx.x >> 8;                            // which of the NB boards in flight
     float *part = (float *)(alut + 256) + slot * 128;             // per board: [2 parities][16 rows][4 waves] partial sums of squares
@@ -831,11 +830,16 @@ __global__ __launch_bounds__(256 * NB, NB == 1 ? 2 : 1) void k_embed_pool(EmbedP
     const int nvalid = a.count ? min(a.n, *a.count) : a.n;
     if ((int)blockIdx.x * NB >= nvalid) return;
 
-    for (int f = threadIdx.x; f < NTILE * KS * 64; f += 256 * NB) {
-        const int l = f & 63, s = (f >> 6) % KS, acc = (f >> 6) / KS;
-        const int col = acc < NACC ? 128 * (acc >> 3) + 8 * (l & 15) + (acc & 7) : D + (l & 15);
-        bimg[f] = *(const uint4 *)(a.wt + (size_t)col * KP + 32 * s + 8 * (l >> 4));
-    }
+    // this wave's weight fragments (its 8 column tiles + the extra tile) live in registers for the whole kernel: 9 * KS * 4
+    // VGPRs instead of 9 * KS LDS reads per token tile.  Fragment (tile, s) of lane l = wt[col(tile, l)][32 s + 8 (l>>4) .. +8]
+    union BF { uint4 u; bf16x8 v; };
+    BF bw[8][KS], be[KS];
+#pragma unroll
+    for (int q = 0; q < 8; q++)
+#pragma unroll
+        for (int s = 0; s < KS; s++) bw[q][s].u = *(const uint4 *)(a.wt + (size_t)(128 * wave + 8 * l15 + q) * KP + 32 * s + 8 * l4);
+#pragma unroll
+    for (int s = 0; s < KS; s++) be[s].u = *(const uint4 *)(a.wt + (size_t)(D + l15) * KP + 32 * s + 8 * l4);
     {
         unsigned r[4];
 #pragma unroll
@@ -915,19 +919,11 @@ __global__ __launch_bounds__(256 * NB, NB == 1 ? 2 : 1) void k_embed_pool(EmbedP
                 afrag[s] = af.v;
             }
 #pragma unroll
-            for (int s = 0; s < KS; s++) {
-                union { uint4 u; bf16x8 v; } bf;
-                bf.u = bimg[(NACC * KS + s) * 64 + lane];
-                acce = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[s], bf.v, acce, 0, 0, 0);
-            }
+            for (int s = 0; s < KS; s++) acce = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[s], be[s].v, acce, 0, 0, 0);
 #pragma unroll
             for (int s = 0; s < KS; s++)
 #pragma unroll
-                for (int q = 0; q < 8; q++) {
-                    union { uint4 u; bf16x8 v; } bf;
-                    bf.u = bimg[((8 * wave + q) * KS + s) * 64 + lane];
-                    acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[s], bf.v, acc[q], 0, 0, 0);
-                }
+                for (int q = 0; q < 8; q++) acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[s], bw[q][s].v, acc[q], 0, 0, 0);
             // ---- LayerNorm statistics of the full rows.  The mean is GEMM column 15 of the extra tile; only the sum of
             //      squares needs this wave's 128 columns -> LDS -> all four waves ----
             float mean[4];
@@ -1015,7 +1011,7 @@ __global__ __launch_bounds__(256 * NB, NB == 1 ? 2 : 1) void k_embed_pool(EmbedP
 
 template <int KS, int NH, bool SR, int NB>
 int launch_embed_pool3(const EmbedPoolArgs &a, hipStream_t st) {
-    const int lds = 33 * KS * 64 * 16 + 256 * 16 + NB * (512 + ((a.T + 15) / 16) * 16 * 16);
+    const int lds = 256 * 16 + NB * (512 + ((a.T + 15) / 16) * 16 * 16);
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void *)k_embed_pool<KS, NH, SR, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return AZK_ERR_HIP;
