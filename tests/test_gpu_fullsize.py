@@ -158,3 +158,59 @@ def test_config2_connect4_with_the_rectangular_vit():
     assert all(r.winner in (0, 1, -1) and 7 <= len(r.cells) <= 42 for r in res)
     assert all(abs(p.sum() - 1) < 1e-12 for r in res for p in r.pis)
     assert stats["sims"] == 200 * sum(len(r.cells) for r in res) and stats["cache_hits"] > 0
+
+
+@pytest.mark.parametrize("use_graph,cache_entries", [(True, 256), (True, 0), (False, 256)])
+def test_continuous_runner_equals_batched_driver_and_oracle(use_graph, cache_entries):
+    """The bench's product path - SelfPlayRunner: hipGraph-replayed simulation steps with no host sync, evaluator over the
+    fixed-size leaf buffer, eval cache, finished slots restarted in place - must play, slot by slot, exactly the games the
+    eager batched driver plays with the same seed (and therefore the oracle's: one game is replayed on the oracle)."""
+    from oracle import az_oracle as ao
+    from selfplay import SelfPlayRunner, self_play_batch
+    G, n_sims, size, seed = 48, 40, 7, 3
+    A = size * size
+    want = self_play_batch("gomoku", ev(A), G, n_sims, size=size, seed=seed)
+    first = [dict(cells=[], pis=[], winner=None) for _ in range(G)]
+
+    def on_records(move_idx, base, h_pi, h_q, h_chosen, h_winner, h_done):
+        for g in range(G):
+            r = first[base + g]
+            if r["winner"] is not None:
+                continue                                             # that slot's first game is over (the slot has restarted)
+            r["cells"].append(int(h_chosen[g]))
+            r["pis"].append(h_pi[g].numpy().copy())
+            if int(h_done[g]):
+                r["winner"] = int(h_winner[g])
+
+    runner = SelfPlayRunner("gomoku", ev(A), G, n_sims, size=size, seed=seed, recycle=True, use_graph=use_graph,
+                            cache_entries=cache_entries, on_records=on_records)
+    for _ in range(size * size + 2):
+        runner.play_move()
+        if all(r["winner"] is not None for r in first):
+            break
+    runner.check_error()
+    assert runner.games_finished >= G
+    for g in range(G):
+        assert first[g]["winner"] == want[g].winner, g
+        assert first[g]["cells"] == want[g].cells, g
+        assert np.stack(first[g]["pis"]).tobytes() == np.stack(want[g].pis).tobytes(), g
+    c = runner.counters()
+    if cache_entries:
+        assert c["cache_hits"] > 0
+    # one of those games on the oracle, with the engine's own noise / uniform draws for that game
+    g0 = 5
+    eng = runner.eng
+    game = ao.OracleGame("gomoku", size)
+
+    def ev_cpu(canon):
+        logits, v = fixture_logits_value(torch.from_numpy(np.ascontiguousarray(canon))[None], A, "hash")
+        return ao.softmax_det(logits[0].numpy()), float(v[0])
+
+    def noise_fn(mc):
+        return eng.gen_noise(seed, 0, mc)[0][g0].cpu().numpy()
+
+    def uniform_fn(mc):
+        return float(eng.gen_noise(seed, 0, mc)[1][g0].item())
+    out = ao.self_play(game, ev_cpu, n_sims, noise_fn=noise_fn, uniform_fn=uniform_fn)
+    assert out["cells"].tolist() == want[g0].cells and out["winner"] == want[g0].winner
+    assert out["pis"].tobytes() == np.stack(want[g0].pis).tobytes()
