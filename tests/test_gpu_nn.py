@@ -238,3 +238,22 @@ def test_fused_final_norm_and_heads_vs_torch_fp32():
     vb2 = torch.full((n,), 5.0, device="cuda")
     azk.nn_ln_heads(x, f["lnf_w"], f["lnf_b"], f["WhP"], f["bh_f"], 225, lb2, vb2, count=torch.tensor([live], dtype=torch.int32, device="cuda"))
     assert torch.equal(lb2[:live], lb[:live]) and bool((lb2[live:] == 5.0).all()) and bool((vb2[live:] == 5.0).all())
+
+
+def test_live_count_leaves_valid_rows_unchanged():
+    """The step graph runs the network over the fixed-size leaf buffer with a device-side live count: the rows below the
+    count must come out bit-identical to a run without the count (same launch shapes), rows above are simply not produced."""
+    cfg = NetConfig(15, 15, 2, 225, 5, 512, 8, 1)
+    net = PolicyValueNet(cfg, seed=1, device="cuda", dtype=torch.bfloat16, path="clsfold")
+    n, live = 256, 150
+    x = random_boards(n, 2, 15, 15, 3).cuda().to(torch.bfloat16).contiguous()
+    lb0, vb0 = torch.zeros(n, 225, device="cuda"), torch.zeros(n, device="cuda")
+    net.out_buffers = (lb0, vb0)
+    net(x)
+    lb1, vb1 = torch.full((n, 225), 7.0, device="cuda"), torch.full((n,), 7.0, device="cuda")
+    net.out_buffers = (lb1, vb1)
+    net.live_count = torch.tensor([live], dtype=torch.int32, device="cuda")
+    net(x)
+    torch.cuda.synchronize()
+    assert torch.equal(lb1[:live], lb0[:live]) and torch.equal(vb1[:live], vb0[:live])
+    assert bool((lb1[live:] == 7.0).all()) and bool((vb1[live:] == 7.0).all())
