@@ -28,6 +28,7 @@ SYMBOLS = [
     "azk_step_tree", "azk_step_gather", "azk_recycle_finished", "azk_nn_patch_embed", "azk_nn_cls_attention", "azk_nn_patch_embed_scores", "azk_nn_cls_pool", "azk_debug_stamps", "azk_emit_finished", "azk_clear_cache", "azk_nn_heads_finalize", "azk_nn_layernorm_rows",
     "azk_vanilla_set_rng", "azk_vanilla_get_rng", "azk_vanilla_search", "azk_nn_embed_pool",
     "azk_nn_gemm_rows", "azk_nn_layernorm_sum", "azk_nn_heads_finalize_sum", "azk_nn_ln_heads",
+    "azk_leaf_source_of", "azk_nn_embed_pool_leaves",
 ]
 
 
@@ -39,6 +40,13 @@ class Config(C.Structure):
     _fields_ = [("game", C.c_int32), ("rows", C.c_int32), ("cols", C.c_int32), ("n_games", C.c_int32),
                 ("max_sims", C.c_int32), ("leaf_dtype", C.c_int32), ("device", C.c_int32),
                 ("arena_nodes", C.c_int32), ("cache_entries", C.c_int32), ("reserved", C.c_int32 * 7)]
+
+
+class LeafSource(C.Structure):
+    """azk_leaf_source (include/azk.h): where azk_nn_embed_pool_leaves finds the pending leaves of an engine."""
+    _fields_ = [("leaf_flag", C.c_void_p), ("leaf_cells", C.c_void_p), ("to_move", C.c_void_p), ("leaf_depth", C.c_void_p),
+                ("leaf_slot", C.c_void_p), ("n_leaf", C.c_void_p), ("n_games", C.c_int32), ("rows", C.c_int32), ("cols", C.c_int32),
+                ("rc", C.c_int32), ("rc_pad", C.c_int32), ("planes", C.c_int32), ("flag_bytes", C.c_int32)]
 
 
 class Counters(C.Structure):
@@ -119,6 +127,8 @@ def lib():
     L.azk_recycle_finished.argtypes = [vp, vp, vp]
     L.azk_nn_patch_embed_scores.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, C.c_float, vp, vp]
     L.azk_nn_embed_pool.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, C.c_float, vp, vp]
+    L.azk_leaf_source_of.argtypes = [vp, vp, C.POINTER(LeafSource)]
+    L.azk_nn_embed_pool_leaves.argtypes = [C.POINTER(LeafSource), vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, C.c_float, vp]
     L.azk_nn_ln_heads.argtypes = [vp, vp, vp, C.c_float, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]
     L.azk_nn_gemm_rows.argtypes = [vp, i32, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]
     L.azk_nn_layernorm_sum.argtypes = [vp, i32, i32, vp, vp, vp, vp, C.c_float, vp, vp, vp, i32, i32, vp, vp]
@@ -245,6 +255,14 @@ class Engine:
 
     def step_tree(self, logits=None, values=None):
         self._chk(self.L.azk_step_tree(self.h, _p(logits), _p(values), _stream()))
+
+    def leaf_source(self):
+        """The engine's pending-leaf arrays for azk_nn_embed_pool_leaves (the leaf count lands in self.n_leaf)."""
+        if getattr(self, "_leaf_source", None) is None:
+            src = LeafSource()
+            self._chk(self.L.azk_leaf_source_of(self.h, _p(self.n_leaf), C.byref(src)))
+            self._leaf_source = src
+        return self._leaf_source
 
     def step_gather(self):
         self._chk(self.L.azk_step_gather(self.h, _p(self.leaf_boards), _p(self.n_leaf), _stream()))
@@ -529,6 +547,25 @@ def nn_embed_pool(boards, wt_ext, cpos_frag, score_frag, score_msum, score_ref, 
         timers[0].stop()
     if rc != 0:
         raise AzkError(f"azk_nn_embed_pool failed ({rc})")
+    return z
+
+
+def nn_embed_pool_leaves(src, wt_ext, cpos_frag, score_frag, score_msum, score_ref, ksize, embed_dim, num_heads, eps=1e-5,
+                         timers=None):
+    """nn_embed_pool over an engine's pending leaves (LeafSource) instead of a compacted board batch: z bf16 [G, H, D],
+    rows [0, n_leaf) valid; also writes the engine's leaf slots and the leaf count (no azk_step_gather needed)."""
+    torch = _torch()
+    z = torch.empty((src.n_games, num_heads, embed_dim), dtype=torch.bfloat16, device=wt_ext.device)
+    fn = lib().azk_nn_embed_pool_leaves
+    args = (C.byref(src), _p(wt_ext), _p(cpos_frag), _p(score_frag), _p(score_msum), _p(score_ref), _p(z), num_heads, ksize,
+            wt_ext.shape[1], embed_dim, float(eps), _stream())
+    if timers is not None:
+        timers[0].start()
+    rc = fn(*args)
+    if timers is not None:
+        timers[0].stop()
+    if rc != 0:
+        raise AzkError(f"azk_nn_embed_pool_leaves failed ({rc})")
     return z
 
 

@@ -1330,6 +1330,16 @@ int32_t azk_vanilla_search(azk_engine *e, int32_t n_sims, void *stream) {
     return AZK_OK;
 }
 
+int32_t azk_leaf_source_of(azk_engine *e, int32_t *n_leaf_dev, azk_leaf_source *out) {
+    if (!e || !n_leaf_dev || !out) return AZK_ERR_ARG;
+    const Dev &d = e->d;
+    out->leaf_flag = d.leaf_flag; out->leaf_cells = d.leaf_cells; out->to_move = d.to_move; out->leaf_depth = d.leaf_depth;
+    out->leaf_slot = d.leaf_slot; out->n_leaf = n_leaf_dev;
+    out->n_games = d.G; out->rows = d.g.rows; out->cols = d.g.cols; out->rc = d.g.rc; out->rc_pad = d.rc_pad; out->planes = d.g.planes;
+    out->flag_bytes = ((d.G + 511) / 512) * 512 + 512;
+    return AZK_OK;
+}
+
 int32_t azk_emit_finished(azk_engine *e, float *states_dev, double *pis_dev, float *zs_dev, int64_t capacity,
                           int64_t *cursor_dev, int32_t *game_base_dev, void *stream) {
     if (!e || !states_dev || !pis_dev || !zs_dev || !cursor_dev || capacity < 1) return AZK_ERR_ARG;

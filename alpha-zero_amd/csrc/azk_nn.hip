@@ -17,6 +17,7 @@
 #include <hip/hip_bf16.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <string.h>
 #include <type_traits>
 
 #include "azk.h"
@@ -811,24 +812,46 @@ struct EmbedPoolArgs {
     const int *count;
     int n, C, R, Cc, ksz, T;
     float eps;
+    azk_leaf_source src;        // SRC variant only
 };
 
-// NB = boards in flight per workgroup (4 waves each): NB = 1 with two workgroups per CU, or NB = 3 with one workgroup of
-// 12 waves per CU.
-template <int KS, int NH, bool STATIC_REF, int NB>
-__global__ __launch_bounds__(256 * NB, NB == 1 ? 2 : 1) void k_embed_pool(EmbedPoolArgs a) {
+// SRC: the boards are the engine's pending leaves (azk_leaf_source): the kernel builds the prefix over the leaf flags itself
+// (board j = the j-th flagged game, ascending game order = azk_step_gather's order), reads the cell codes of that game,
+// records the slot for the next expansion and publishes the leaf count - no compaction launch, no evaluator batch.
+template <int KS, int NH, bool STATIC_REF, bool SRC>
+__global__ __launch_bounds__(256, 2) void k_embed_pool(EmbedPoolArgs a) {
     constexpr int D = 512, KP = 32 * KS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint4 *alut = (uint4 *)smem;                                  // [256] A fragment of 8 patch bits (bit q -> bf16 1.0 in slot q)
     const int Tp16 = ((a.T + 15) >> 4) * 16;
-    const int slot = threadIdx.x >> 8;                            // which of the NB boards in flight
-    float *part = (float *)(alut + 256) + slot * 128;             // per board: [2 parities][16 rows][4 waves] partial sums of squares
-    uint4 *pbits = (uint4 *)((float *)(alut + 256) + NB * 128) + slot * Tp16;   // per board: [Tp] patch bits per token (<= 128 bits)
+    float *part = (float *)(alut + 256);                          // [2 parities][16 rows][4 waves] partial sums of squares
+    uint4 *pbits = (uint4 *)(part + 128);                         // [Tp] patch bits per token (<= 128 bits)
+    int *scan = (int *)(pbits + Tp16);                            // SRC: [4] wave totals, [16] games of this workgroup's next leaves
 
-    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
-    const int nvalid = a.count ? min(a.n, *a.count) : a.n;
-    if ((int)blockIdx.x * NB >= nvalid) return;
+    int nvalid, my_first = 0, my_count = 0, my_lo = 0, my_per = 0;
+    if (SRC) {
+        // exclusive prefix of the leaf flags over the workgroup's 256 threads (thread t owns games [t per, (t+1) per))
+        my_per = ((((a.src.n_games + 255) >> 8) + 7) >> 3) << 3;
+        my_lo = tid * my_per;
+        for (int w = 0; w < my_per; w += 8)
+            if (my_lo + w < a.src.flag_bytes) my_count += __popcll(*(const unsigned long long *)(a.src.leaf_flag + my_lo + w));
+        int incl = my_count;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(incl, off); if (lane >= off) incl += v; }
+        if (lane == 63) scan[wave] = incl;
+        __syncthreads();
+        int before = 0;
+        for (int w = 0; w < wave; w++) before += scan[w];
+        my_first = before + incl - my_count;
+        nvalid = scan[0] + scan[1] + scan[2] + scan[3];
+        if (blockIdx.x == 0 && tid == 0) *a.src.n_leaf = nvalid;
+        __syncthreads();
+    } else {
+        nvalid = a.count ? min(a.n, *a.count) : a.n;
+    }
+    if ((int)blockIdx.x >= nvalid) return;
 
     // this wave's weight fragments (its 8 column tiles + the extra tile) live in registers for the whole kernel: 9 * KS * 4
     // VGPRs instead of 9 * KS LDS reads per token tile.  Fragment (tile, s) of lane l = wt[col(tile, l)][32 s + 8 (l>>4) .. +8]
@@ -844,7 +867,7 @@ __global__ __launch_bounds__(256 * NB, NB == 1 ? 2 : 1) void k_embed_pool(EmbedP
         unsigned r[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) r[i] = (((tid >> (2 * i)) & 1) ? 0x3F80u : 0u) | (((tid >> (2 * i + 1)) & 1) ? 0x3F800000u : 0u);
-        if (slot == 0) alut[tid] = make_uint4(r[0], r[1], r[2], r[3]);
+        alut[tid] = make_uint4(r[0], r[1], r[2], r[3]);
     }
     __syncthreads();
 
@@ -857,14 +880,45 @@ __global__ __launch_bounds__(256 * NB, NB == 1 ? 2 : 1) void k_embed_pool(EmbedP
     const f32x4 *mbase = (const f32x4 *)a.mtab + lane;
     int par = 0;
 
-    for (int base = blockIdx.x * NB; base < nvalid; base += gridDim.x * NB) {
-        const bool active = base + slot < nvalid;                    // an idle slot recomputes the last board (it shares the barriers) and stores nothing
-        const int leaf = active ? base + slot : nvalid - 1;
+    for (int leaf0 = blockIdx.x; leaf0 < nvalid; leaf0 += 16 * gridDim.x) {
+      if (SRC) {
+          // the games behind this workgroup's next (up to 16) leaves, resolved in one pass: the thread whose flag range holds
+          // the leaf-th flagged game finds it, records its slot for the next expansion and posts the game index
+          __syncthreads();
+          for (int k = 0; k < 16; k++) {
+              const int lf = leaf0 + k * (int)gridDim.x;
+              if (lf >= nvalid) break;
+              if (lf >= my_first && lf < my_first + my_count) {
+                  int kk = lf - my_first, g = my_lo;
+                  for (int w = 0; w < my_per; w++) {
+                      const int f = a.src.leaf_flag[my_lo + w];
+                      if (f && kk-- == 0) { g = my_lo + w; break; }
+                  }
+                  scan[4 + k] = g;
+                  a.src.leaf_slot[g] = lf;
+              }
+          }
+          __syncthreads();
+      }
+      for (int k16 = 0; k16 < 16; k16++) {
+        const int leaf = leaf0 + k16 * (int)gridDim.x;
+        if (leaf >= nvalid) break;
+        int game = 0, player = 0;
+        if (SRC) {
+            game = scan[4 + k16];
+            player = (a.src.to_move[game] + a.src.leaf_depth[game]) & 1;     // node.currentPlayer at the leaf
+        }
         unsigned wbits = 0;                             // lane i holds bits [32 (i-1), 32 i) of the board bit string (lane 0: zeros)
         for (int q = 0; q * 64 < ncell; q++) {
             const int e = q * 64 + lane;
             bool on = false;
-            if (e < ncell)
+            if (SRC) {
+                if (e < ncell) {                                     // canonical planes from the cell codes (gomoku.py:34-40; 3-plane: mcts.py:126-137)
+                    const int ch = (e >= RC) + (e >= 2 * RC), cell = e - ch * RC;
+                    const int code = a.src.leaf_cells[(size_t)game * a.src.rc_pad + cell];
+                    on = ch == 2 ? player != 0 : ((code >> (ch ^ player)) & 1) != 0;
+                }
+            } else if (e < ncell)
                 on = a.boards_f32 ? ((const float *)a.boards)[(size_t)leaf * ncell + e] != 0.0f
                                   : (((const unsigned short *)a.boards)[(size_t)leaf * ncell + e] & 0x7fff) != 0;
             const unsigned long long m = __ballot(on);
@@ -998,7 +1052,7 @@ __global__ __launch_bounds__(256 * NB, NB == 1 ? 2 : 1) void k_embed_pool(EmbedP
         for (int j = 0; j < 4; j++) {
             const int head = 4 * l4 + j;
             const float Lh = __shfl(Lt, head & 15);
-            if (head < NH && active) {
+            if (head < NH) {
                 const float inv = 1.0f / Lh;
                 float v[8];
 #pragma unroll
@@ -1006,52 +1060,48 @@ __global__ __launch_bounds__(256 * NB, NB == 1 ? 2 : 1) void k_embed_pool(EmbedP
                 *(uint4 *)(a.z + ((size_t)leaf * NH + head) * D + 128 * wave + 8 * l15) = pack8(v);
             }
         }
+      }
     }
 }
 
-template <int KS, int NH, bool SR, int NB>
-int launch_embed_pool3(const EmbedPoolArgs &a, hipStream_t st) {
-    const int lds = 256 * 16 + NB * (512 + ((a.T + 15) / 16) * 16 * 16);
+template <int KS, int NH, bool SR, bool SRC>
+int launch_embed_pool2(const EmbedPoolArgs &a, hipStream_t st) {
+    const int lds = 256 * 16 + 512 + ((a.T + 15) / 16) * 16 * 16 + 96;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void *)k_embed_pool<KS, NH, SR, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return AZK_ERR_HIP;
+        if (hipFuncSetAttribute((const void *)k_embed_pool<KS, NH, SR, SRC>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return AZK_ERR_HIP;
         attr_set = true;
     }
-    const int resident = NB == 1 ? 512 : 256;                      // workgroups the chip holds at once; each walks its boards
-    const int want = (a.n + NB - 1) / NB;
-    k_embed_pool<KS, NH, SR, NB><<<want < resident ? want : resident, 256 * NB, lds, st>>>(a);
+    const int blocks = a.n < 512 ? a.n : 512;                      // two resident workgroups per CU, each walks its boards
+    k_embed_pool<KS, NH, SR, SRC><<<blocks, 256, lds, st>>>(a);
     return hipGetLastError() == hipSuccess ? AZK_OK : AZK_ERR_HIP;
-}
-
-template <int KS, int NH, bool SR>
-int launch_embed_pool2(const EmbedPoolArgs &a, hipStream_t st) {
-    static int nb = -1;
-    if (nb < 0) { const char *v = getenv("AZK_POOL_NB"); nb = v ? atoi(v) : 1; }     // measured: 3 wins only when every board is live
-    return nb == 1 ? launch_embed_pool3<KS, NH, SR, 1>(a, st) : launch_embed_pool3<KS, NH, SR, 3>(a, st);
 }
 
 template <int KS, int NH>
 int launch_embed_pool(const EmbedPoolArgs &a, hipStream_t st) {
-    return a.sref ? launch_embed_pool2<KS, NH, true>(a, st) : launch_embed_pool2<KS, NH, false>(a, st);
+    if (a.src.leaf_flag) return a.sref ? launch_embed_pool2<KS, NH, true, true>(a, st) : launch_embed_pool2<KS, NH, false, true>(a, st);
+    return a.sref ? launch_embed_pool2<KS, NH, true, false>(a, st) : launch_embed_pool2<KS, NH, false, false>(a, st);
 }
 }  // namespace
 
-extern "C" int32_t azk_nn_embed_pool(const void *boards_dev, int32_t boards_are_f32, const void *wt_ext_bf16_dev,
-                                     const float *cpos_frag_dev, const float *score_frag_dev, const float *score_msum_dev,
-                                     const float *score_ref_dev, void *z_out_bf16_dev, int32_t num_heads, int32_t n,
-                                     int32_t channels, int32_t rows, int32_t cols, int32_t ksize, int32_t kp, int32_t embed_dim,
-                                     float ln_eps, const int32_t *n_valid_dev, void *stream) {
-    if (!boards_dev || !wt_ext_bf16_dev || !cpos_frag_dev || !score_frag_dev || !score_msum_dev || !z_out_bf16_dev) return AZK_ERR_ARG;
+static int32_t embed_pool_impl(const void *boards_dev, int32_t boards_are_f32, const azk_leaf_source *src, const void *wt_ext_bf16_dev,
+                               const float *cpos_frag_dev, const float *score_frag_dev, const float *score_msum_dev,
+                               const float *score_ref_dev, void *z_out_bf16_dev, int32_t num_heads, int32_t n, int32_t channels,
+                               int32_t rows, int32_t cols, int32_t ksize, int32_t kp, int32_t embed_dim, float ln_eps,
+                               const int32_t *n_valid_dev, void *stream) {
+    if ((!boards_dev && !src) || !wt_ext_bf16_dev || !cpos_frag_dev || !score_frag_dev || !score_msum_dev || !z_out_bf16_dev) return AZK_ERR_ARG;
     if (n < 0 || channels < 1 || rows < 1 || cols < 1 || ksize < 1 || (ksize & 1) == 0 || ksize > 7) return AZK_ERR_ARG;
     if (kp < channels * ksize * ksize || kp % 32 != 0 || kp > 96) return AZK_ERR_ARG;
     if (channels * rows * cols > 62 * 32 || embed_dim != 512) return AZK_ERR_ARG;      // one column group per wave, four waves
     if (num_heads != 8 && num_heads != 4) return AZK_ERR_ARG;
     if (n == 0) return AZK_OK;
     EmbedPoolArgs a;
+    memset(&a, 0, sizeof a);
     a.boards = boards_dev; a.boards_f32 = boards_are_f32; a.wt = (const __hip_bfloat16 *)wt_ext_bf16_dev; a.cpos = cpos_frag_dev;
     a.mtab = score_frag_dev; a.msum = score_msum_dev; a.sref = score_ref_dev; a.z = (__hip_bfloat16 *)z_out_bf16_dev;
     a.count = n_valid_dev;
     a.n = n; a.C = channels; a.R = rows; a.Cc = cols; a.ksz = ksize; a.T = rows * cols + 1; a.eps = ln_eps;
+    if (src) a.src = *src;
     hipStream_t st = (hipStream_t)stream;
     const int ks = kp / 32;
 #define CASE(KS_, NH_) if (ks == KS_ && num_heads == NH_) return launch_embed_pool<KS_, NH_>(a, st)
@@ -1060,6 +1110,25 @@ extern "C" int32_t azk_nn_embed_pool(const void *boards_dev, int32_t boards_are_
     return AZK_ERR_ARG;
 }
 
+extern "C" int32_t azk_nn_embed_pool(const void *boards_dev, int32_t boards_are_f32, const void *wt_ext_bf16_dev,
+                                     const float *cpos_frag_dev, const float *score_frag_dev, const float *score_msum_dev,
+                                     const float *score_ref_dev, void *z_out_bf16_dev, int32_t num_heads, int32_t n,
+                                     int32_t channels, int32_t rows, int32_t cols, int32_t ksize, int32_t kp, int32_t embed_dim,
+                                     float ln_eps, const int32_t *n_valid_dev, void *stream) {
+    if (!boards_dev) return AZK_ERR_ARG;
+    return embed_pool_impl(boards_dev, boards_are_f32, nullptr, wt_ext_bf16_dev, cpos_frag_dev, score_frag_dev, score_msum_dev,
+                           score_ref_dev, z_out_bf16_dev, num_heads, n, channels, rows, cols, ksize, kp, embed_dim, ln_eps, n_valid_dev, stream);
+}
+
+extern "C" int32_t azk_nn_embed_pool_leaves(const azk_leaf_source *src, const void *wt_ext_bf16_dev, const float *cpos_frag_dev,
+                                            const float *score_frag_dev, const float *score_msum_dev, const float *score_ref_dev,
+                                            void *z_out_bf16_dev, int32_t num_heads, int32_t ksize, int32_t kp, int32_t embed_dim,
+                                            float ln_eps, void *stream) {
+    if (!src || !src->leaf_flag || !src->leaf_cells || !src->to_move || !src->leaf_depth || !src->leaf_slot || !src->n_leaf) return AZK_ERR_ARG;
+    if (src->n_games < 1 || src->rows * src->cols != src->rc || src->flag_bytes < src->n_games) return AZK_ERR_ARG;
+    return embed_pool_impl(nullptr, 0, src, wt_ext_bf16_dev, cpos_frag_dev, score_frag_dev, score_msum_dev, score_ref_dev,
+                           z_out_bf16_dev, num_heads, src->n_games, src->planes, src->rows, src->cols, ksize, kp, embed_dim, ln_eps, nullptr, stream);
+}
 
 // =====================================================================================================
 // cls-row tail (nn.py:54-60, 78-83 for the one row the heads read): small-M GEMMs with a device-side row count.

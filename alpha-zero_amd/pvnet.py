@@ -120,6 +120,7 @@ class PolicyValueNet:
         self.hip_tail = False           # set by _prepare_folded when the hand-written tail kernels cover this configuration
         self.use_hip_tail = False       # True: the cls-row tail on azk_nn_gemm_rows (every launch honours the live count; measured
                                         # 87 us vs 82 us for the hipBLASLt tail at 2048 rows / 1150 live, so the library GEMMs stay the default)
+        self.leaf_source = None         # azk.LeafSource of the engine being stepped: the fused kernel reads the pending leaves itself
         self.fuse_ln_heads = True       # final LayerNorm + heads + finalize as one hand-written launch (needs hip_tail's packed weights)
         self.fused_embed_pool = False   # set by _prepare_folded when azk_nn_embed_pool covers this configuration
         self.kernel_timers = None   # optional (embed_timer, pool_timer) with start()/stop(): HIP-event timing of the two kernels
@@ -458,7 +459,12 @@ class PolicyValueNet:
                 if self.cfg.num_heads in (4, 8):
                     if x.dtype not in (torch.bfloat16, torch.float32):
                         x = x.float()
-                    if self.fused_embed_pool:
+                    if self.fused_embed_pool and self.leaf_source is not None:
+                        # boards straight from the engine's pending leaves (no compaction launch, no evaluator batch)
+                        z = azk.nn_embed_pool_leaves(self.leaf_source, f["wt_ext"], f["cpos_frag"], f["score_frag"], f["score_msum"],
+                                                     f["score_ref"], self.cfg.patch_size, self.cfg.embed_dim, self.cfg.num_heads,
+                                                     timers=self.kernel_timers)
+                    elif self.fused_embed_pool:
                         # one launch: the normalised tokens never reach HBM (azk_nn_embed_pool)
                         z = azk.nn_embed_pool(x.contiguous(), f["wt_ext"], f["cpos_frag"], f["score_frag"], f["score_msum"],
                                               f["score_ref"], self.cfg.rows, self.cfg.cols, self.cfg.patch_size, self.cfg.embed_dim,

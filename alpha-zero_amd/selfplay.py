@@ -173,6 +173,7 @@ class SelfPlayRunner:
         self.dirichlet, self.alpha, self.recycle, self.on_records = dirichlet, alpha, recycle, on_records
         self.sample_until = SAMPLE_UNTIL[game]
         self.kernel_timer = kernel_timer
+        self.leaf_source_ok = True              # let a fused evaluator read the pending leaves straight from the engine (no azk_step_gather)
         self.streams = [torch.cuda.Stream(device=self.eng.device) for _ in range(self.n_split)] if self.n_split > 1 else []
         self.move_idx = 0
         self.plies_played = 0
@@ -242,11 +243,17 @@ class SelfPlayRunner:
         PUCT select, leaf compaction, then the evaluator over the (fixed-size) leaf buffer.  Rows past n_leaf hold
         older boards; kernels that honour `live_count` skip them and nothing ever reads their outputs."""
         e = h.eng
+        from_leaves = getattr(self.evaluator, "fused_embed_pool", False) and self.leaf_source_ok
+        if hasattr(self.evaluator, "leaf_source"):
+            self.evaluator.leaf_source = e.leaf_source() if from_leaves else None
         if timer is not None:
             timer.start()
             e.step_tree(h.logits_buf, h.values_buf)
             timer.stop()
-            e.step_gather()
+            if not from_leaves:
+                e.step_gather()
+        elif from_leaves:
+            e.step_tree(h.logits_buf, h.values_buf)          # the network kernel compacts the leaves itself
         else:
             e.step(h.logits_buf, h.values_buf)
         if hasattr(self.evaluator, "live_count"):
@@ -267,6 +274,8 @@ class SelfPlayRunner:
             h.values_buf.copy_(values.reshape(-1))
         if hasattr(self.evaluator, "out_buffers"):
             self.evaluator.out_buffers = None
+        if hasattr(self.evaluator, "leaf_source"):
+            self.evaluator.leaf_source = None
 
     def _all_bodies(self):
         torch = self.torch

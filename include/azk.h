@@ -269,6 +269,27 @@ int32_t azk_nn_embed_pool(const void *boards_dev, int32_t boards_are_f32, const 
                           int32_t rows, int32_t cols, int32_t ksize, int32_t kp, int32_t embed_dim, float ln_eps,
                           const int32_t *n_valid_dev, void *stream);
 
+/* Board source for the fused step: azk_nn_embed_pool_leaves takes the pending leaves of the last azk_step_tree straight from
+ * the engine - it builds the prefix over the leaf flags itself (board j = the j-th flagged game in ascending game order,
+ * exactly azk_step_gather's order), reads that game's cell codes, stores the slot j the next expansion will read its
+ * logits row from, and writes the leaf count to n_leaf - so a simulation step is azk_step_tree -> azk_nn_embed_pool_leaves
+ * -> tail, without azk_step_gather and without an evaluator batch.  Pointers are device pointers owned by the engine
+ * (valid until azk_destroy) except n_leaf, which is the caller's. */
+typedef struct azk_leaf_source {
+    const uint8_t *leaf_flag;     /* [flag_bytes] 1 = the game has a pending leaf that needs the evaluator */
+    const uint8_t *leaf_cells;    /* [n_games][rc_pad] cell codes at the leaf (bit 0 / 1 = player 0 / 1 stone) */
+    const int32_t *to_move;       /* [n_games] side to move at the root */
+    const int32_t *leaf_depth;    /* [n_games] */
+    int32_t *leaf_slot;           /* [n_games] out: row of the evaluator outputs */
+    int32_t *n_leaf;              /* [1] out */
+    int32_t n_games, rows, cols, rc, rc_pad, planes, flag_bytes;
+} azk_leaf_source;
+int32_t azk_leaf_source_of(azk_engine *e, int32_t *n_leaf_dev, azk_leaf_source *out);
+int32_t azk_nn_embed_pool_leaves(const azk_leaf_source *src, const void *wt_ext_bf16_dev, const float *cpos_frag_dev,
+                                 const float *score_frag_dev, const float *score_msum_dev, const float *score_ref_dev,
+                                 void *z_out_bf16_dev, int32_t num_heads, int32_t ksize, int32_t kp, int32_t embed_dim,
+                                 float ln_eps, void *stream);
+
 /* ---- cls-row tail (nn.py:54-60, 78-83 for the row the heads read): small-M GEMMs with a device-side row count.
  * azk_nn_gemm_rows: C = A W^T for A bf16 [m][lda] (first k columns), W = an nn.Linear weight [n_out][k] packed in MFMA
  *   B-fragment order: Wp[n_out/64][k/32][4][64][8] with element [g][s][c][lane][i] = W[64 g + 4 (lane&15) + c][32 s + 8 (lane>>4) + i]

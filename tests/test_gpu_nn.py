@@ -257,3 +257,48 @@ def test_live_count_leaves_valid_rows_unchanged():
     torch.cuda.synchronize()
     assert torch.equal(lb1[:live], lb0[:live]) and torch.equal(vb1[:live], vb0[:live])
     assert bool((lb1[live:] == 7.0).all()) and bool((vb1[live:] == 7.0).all())
+
+
+def test_embed_pool_from_engine_leaves_equals_gathered_batch():
+    """azk_nn_embed_pool_leaves (boards straight from the engine's pending leaves: own flag prefix, cell codes, slots, count)
+    against azk_step_gather + azk_nn_embed_pool on the same engine state: same leaf order, same count, bit-identical pooled
+    tokens; and whole continuous-self-play moves through the real network are identical with and without the compaction
+    launch (which also proves the slots the kernel hands to the next expansion)."""
+    import azk
+    from selfplay import SelfPlayRunner
+    cfg = NetConfig(15, 15, 2, 225, 5, 512, 8, 1)
+    net = PolicyValueNet(cfg, seed=6, device="cuda", dtype=torch.bfloat16, path="clsfold")
+    f = net._fold
+    G, A = 300, 225
+    eng = azk.Engine("gomoku", G, 64, size=15, leaf_dtype="bfloat16", cache_entries=64)
+    eng.reset_games()
+    noise, uni = eng.gen_noise(3, 0, 0)
+    eng.begin_search(noise)
+    logits = values = None
+    for s in range(24):                                           # a few simulations so leaves, cache hits and terminals mix
+        eng.step_tree(logits, values)
+        eng.step_gather()
+        logits, values = torch.randn(G, A, device="cuda") * 0.3, torch.tanh(torch.randn(G, device="cuda"))
+    n = int(eng.n_leaf.item())
+    assert 0 < n <= G
+    z_ref = azk.nn_embed_pool(eng.leaf_boards[:n].contiguous(), f["wt_ext"], f["cpos_frag"], f["score_frag"], f["score_msum"], f["score_ref"],
+                              15, 15, 5, 512, 8)
+    eng.n_leaf.zero_()
+    z_new = azk.nn_embed_pool_leaves(eng.leaf_source(), f["wt_ext"], f["cpos_frag"], f["score_frag"], f["score_msum"], f["score_ref"], 5, 512, 8)
+    torch.cuda.synchronize()
+    assert int(eng.n_leaf.item()) == n
+    assert torch.equal(z_new[:n], z_ref)
+    eng.close()
+
+    def play(leaves):
+        rec = []
+        r = SelfPlayRunner("gomoku", net, 128, 48, size=15, seed=9, leaf_dtype="bfloat16", recycle=True, use_graph=True, cache_entries=128,
+                           on_records=lambda mv, base, pi, q, ch, w, d: rec.append((pi.numpy().copy(), ch.numpy().copy())))
+        r.leaf_source_ok = leaves
+        for _ in range(3):
+            r.play_move()
+        r.check_error()
+        return rec
+    a, b = play(True), play(False)
+    for (pa, ca), (pb, cb) in zip(a, b):
+        assert np.array_equal(ca, cb) and pa.tobytes() == pb.tobytes()
