@@ -591,6 +591,49 @@ class DeviceReplay:
         idx = self.torch.randperm(n, device=self.states.device)[:batch_size]
         return self.states[idx], self.pis[idx].float(), self.zs[idx][:, None]
 
+    # ---- interchange with the reference's host-side ReplayBuffer (replay_buffer.py) ------------------------------
+    def add(self, state, policy_distribution, reward):
+        """ReplayBuffer.add (replay_buffer.py:12): append one tuple from the host (reward: float or [float])."""
+        torch = self.torch
+        i = int(self.cursor.item()) % self.capacity
+        self.states[i] = torch.as_tensor(np.asarray(state, np.float32))
+        self.pis[i] = torch.as_tensor(np.asarray(policy_distribution, np.float64))
+        self.zs[i] = float(np.asarray(reward, np.float32).reshape(-1)[0])
+        self.cursor += 1
+
+    def to_reference_deque(self):
+        """The ring as the reference keeps it: deque(maxlen=capacity) of (state float32 [F,R,C], pi float64 [A], [z]) tuples,
+        oldest first (train.save_data_to_buffer's element format, train.py:30-49)."""
+        from collections import deque
+        n, cur = self.size(), int(self.cursor.item())
+        order = [(cur - n + j) % self.capacity for j in range(n)]
+        s, p, z = self.states.cpu().numpy(), self.pis.cpu().numpy(), self.zs.cpu().numpy()
+        return deque(((s[i].copy(), p[i].copy(), [float(z[i])]) for i in order), maxlen=self.capacity)
+
+    def save_pickle(self, filename):
+        """ReplayBuffer.save_pickle's file format (replay_buffer.py:37-54): pickle.dump of the deque."""
+        import os, pickle
+        folder = os.path.dirname(filename)
+        if folder:
+            os.makedirs(folder, exist_ok=True)
+        with open(filename, "wb") as fh:
+            pickle.dump(self.to_reference_deque(), fh)
+
+    def load_pickle(self, filename):
+        """Refill the ring from a file in that format (one this class or the reference's ReplayBuffer wrote).  pickle executes
+        what the file says: only load files you produced."""
+        import pickle
+        with open(filename, "rb") as fh:
+            items = list(pickle.load(fh))[-self.capacity:]
+        self.cursor.zero_()
+        if items:
+            torch = self.torch
+            n = len(items)
+            self.states[:n] = torch.as_tensor(np.stack([np.asarray(t[0], np.float32) for t in items]))
+            self.pis[:n] = torch.as_tensor(np.stack([np.asarray(t[1], np.float64) for t in items]))
+            self.zs[:n] = torch.as_tensor(np.array([float(np.asarray(t[2], np.float32).reshape(-1)[0]) for t in items], np.float32))
+            self.cursor += n
+
 
 def nn_heads_finalize(heads, action_dim, logits_out, values_out, count=None):
     """heads bf16 [n, ld] (merged policy/value GEMM) -> logits_out f32 [n, A], values_out f32 [n] = tanh(raw), one launch."""

@@ -76,3 +76,39 @@ def test_collect_train_promote_loop():
     assert changed >= len(w0) - 1
     # policy loss starts near log(49) for a random net and the L2 term is the dominant, slowly shrinking part
     assert 2.0 < hist[0]["losses"][1] < 6.0
+
+
+def test_device_ring_interchanges_with_the_reference_buffer_format(tmp_path):
+    """DeviceReplay <-> replay_buffer.ReplayBuffer: chronological export as the reference's deque of
+    (state f32, pi f64, [z]) tuples (digest == the reference's own buffer), save / load in its on-disk format, host add."""
+    import pickle
+    import azk
+    from oracle import replay_oracle as ro
+    from selfplay import self_play_batch
+    m = _META[0]
+    k = f"g{m['game']}_"
+    noise, uniforms = _GZ[k + "noise"], _GZ[k + "uniforms"]
+    size, A = m["size"], m["size"] ** 2
+    replay = azk.DeviceReplay(m["buffer_len"] + 8, 2, size, size, A)
+    self_play_batch("gomoku", lambda x: fixture_logits_value(x, A, m["variant"]), 1, m["n_sims"], size=size,
+                    noise_fn=lambda mv: noise[min(mv, len(noise) - 1)][None], uniform_fn=lambda mv: np.full(1, uniforms[mv] if mv < len(uniforms) else 0.5),
+                    replay=replay)
+    dq = replay.to_reference_deque()
+    assert len(dq) == m["buffer_len"] and dq.maxlen == m["buffer_len"] + 8
+    assert dq[0][0].dtype == np.float32 and dq[0][1].dtype == np.float64 and isinstance(dq[0][2], list)
+    assert ro.digest([(s, p, z[0]) for s, p, z in dq]) == m["buffer_digest"]
+    path = str(tmp_path / "replay_buffers" / "replay_buffer_test.pkl")
+    replay.save_pickle(path)
+    with open(path, "rb") as fh:
+        raw = pickle.load(fh)                                             # a plain deque, as ReplayBuffer.load_pickle expects
+    assert type(raw).__name__ == "deque" and len(raw) == m["buffer_len"]
+    other = azk.DeviceReplay(m["buffer_len"] + 8, 2, size, size, A)
+    other.load_pickle(path)
+    assert other.size() == m["buffer_len"]
+    assert ro.digest([(s, p, z[0]) for s, p, z in other.to_reference_deque()]) == m["buffer_digest"]
+    # host-side add wraps like deque(maxlen)
+    for j in range(10):
+        other.add(np.full((2, size, size), j, np.float32), np.full(A, 1.0 / A), [1.0 if j % 2 else -1.0])
+    dq2 = other.to_reference_deque()
+    assert len(dq2) == m["buffer_len"] + 8 and float(dq2[-1][0][0, 0, 0]) == 9.0 and dq2[-1][2] == [1.0]
+    assert ro.digest([(s, p, z[0]) for s, p, z in list(dq2)[:m["buffer_len"] - 2]]) == ro.digest([(s, p, z[0]) for s, p, z in list(dq)[2:]])
