@@ -135,6 +135,15 @@ class PolicyValueNet:
     def from_state_dict(cls, cfg, sd, **kw):
         return cls(cfg, weights=sd, **kw)
 
+    def load_state_dict(self, sd):
+        """nn.Module.load_state_dict for the reference's keys: replaces the weights in place (device copies and the folded
+        constants of the HIP paths are rebuilt; a captured step graph must be re-captured by its owner)."""
+        want = reference_key_shapes(self.cfg)
+        for k_, shape in want.items():
+            assert k_ in sd and tuple(sd[k_].shape) == tuple(shape), k_
+        self.master = {k_: torch.as_tensor(sd[k_]).detach().to("cpu", torch.float32).clone() for k_ in want}
+        self.to(self.device, self.dtype)
+
     def to(self, device, dtype=None):
         self.device = torch.device(device)
         self.dtype = dtype or self.dtype

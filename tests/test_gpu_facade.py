@@ -157,3 +157,46 @@ def test_vanilla_mcts_mcts_reference_signature():
     assert all(c.prior == 0.0 for c in root.children)
     assert root.visit == 90 and root.value == tree.root_value
     assert np.random.randint(1 << 30) == rs.randint(1 << 30)
+
+
+def test_train_py_facade_collect_and_train():
+    """train.collect_data / save_data_to_buffer / train with the reference's signatures (train.py:30-123): the device ring
+    filled by the engine holds exactly what the host path (save_data_to_buffer on the same games) appends, and one train
+    call updates the network in place."""
+    import azk
+    import train as az_train
+    from games import Gomoku
+    from pvnet import NetConfig, PolicyValueNet
+    Gomoku.rows = Gomoku.cols = 7
+    Gomoku.action_dim = Gomoku.state_dim = 49
+    model = GpuFixtureModel(49, "hash")
+    dev_buf = azk.DeviceReplay(4096, 2, 7, 7, 49)
+
+    class HostBuffer:                                              # the reference's ReplayBuffer interface (replay_buffer.py:7-13)
+        def __init__(self):
+            self.buffer = []
+
+        def add(self, s, p, r):
+            self.buffer.append((np.array(s, np.float32), np.array(p, np.float64), list(r)))
+
+        def size(self):
+            return len(self.buffer)
+    host_buf = HostBuffer()
+    r1 = az_train.collect_data(Gomoku, model, dev_buf, 6, 30, seed=11)
+    r2 = az_train.collect_data(Gomoku, model, host_buf, 6, 30, seed=11)
+    assert r1 == r2 and sum(r1) == 6
+    assert dev_buf.size() == host_buf.size() > 0
+    # same multiset of tuples (the device ring orders games by finishing time, the host path by game index)
+    def keyed(items):
+        return sorted((s.tobytes(), p.tobytes(), float(z[0])) for s, p, z in items)
+    assert keyed(dev_buf.to_reference_deque()) == keyed(host_buf.buffer)
+    # train(): in-place weight update of a PolicyValueNet from the device ring
+    cfg = NetConfig(7, 7, 2, 49, 3, 128, 4, 1)
+    net = PolicyValueNet(cfg, seed=0, device="cuda", dtype=torch.bfloat16, path="cls")
+    before = net.state_dict()
+    out = az_train.train(net, 64, dev_buf, 3, 0.00025, "cuda")
+    assert len(out) == 4 and all(np.isfinite(v) for v in out)
+    after = net.state_dict()
+    assert any(not torch.equal(before[k], after[k]) for k in before)
+    logits, v = net(torch.zeros(2, 2, 7, 7, device="cuda"))
+    assert logits.shape == (2, 49) and torch.isfinite(logits.float()).all()
