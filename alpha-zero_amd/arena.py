@@ -12,9 +12,17 @@ import numpy as np
 from selfplay import self_play_batch
 
 
+def _game_name(game, size):
+    """`game`: an engine name ("gomoku", ...) or one of the facade's Game classes (games.Gomoku, ...), as test.py passes it."""
+    if isinstance(game, str):
+        return game, size
+    return game.engine_name, (game._size() if size is None else size)
+
+
 def compete_batch(game, model1, model2, n_games, model1_mcts_iter=50, model2_mcts_iter=50, sampling=False, size=None,
                   seed=0, first_global_game=0, device=0, leaf_dtype="float32", noise_fn=None, uniform_fn=None):
     """n_games independent test.compete games at once -> (winners int array in {0, 1, -1}, final boards)."""
+    game, size = _game_name(game, size)
     res = self_play_batch(game, (model1, model2), n_games, (model1_mcts_iter, model2_mcts_iter), size=size, seed=seed,
                           first_global_game=first_global_game, device=device, leaf_dtype=leaf_dtype,
                           noise_fn=noise_fn, uniform_fn=uniform_fn, sample_until=20 if sampling else 0)
@@ -47,6 +55,9 @@ def score_like_reference(winners_first_half, winners_second_half, iterations, ea
 
 def compare(game, best_model, contender_model, best_model_mcts_iter, contender_model_mcts_iter, iterations, sampling,
             early_stopping, size=None, seed=0, device=0, leaf_dtype="float32"):
+    """test.compare(Game, best_model, contender_model, best_iter, contender_iter, iterations, sampling, early_stopping)
+    (test.py:107-140); a model of None plays vanilla MCTS (main.py:76)."""
+    game, size = _game_name(game, size)
     half = iterations // 2
     w1, _ = compete_batch(game, best_model, contender_model, half, best_model_mcts_iter, contender_model_mcts_iter,
                           sampling, size, seed, 0, device, leaf_dtype) if half else (np.zeros(0, np.int64), None)

@@ -160,3 +160,14 @@ def test_compete_against_vanilla_equals_oracle(azk, ao):
         assert out["winner"] == res[g].winner
         assert out["cells"].tolist() == res[g].cells
         assert out["pis"].tobytes() == np.stack(res[g].pis).tobytes()
+
+
+def test_compare_against_vanilla_with_a_game_class(azk):
+    """test.compare(Game, None, model, ...) as main.py:76 calls it: a Game class and a None (vanilla) opponent."""
+    from arena import compare
+    from fixture_eval import fixture_logits_value
+    from games import Gomoku
+    Gomoku.rows = Gomoku.cols = 7
+    Gomoku.action_dim = Gomoku.state_dim = 49
+    rate = compare(Gomoku, None, lambda x: fixture_logits_value(x, 49, "hash"), 20, 20, iterations=4, sampling=False, early_stopping=False)
+    assert 0.0 <= rate <= 1.0
