@@ -178,6 +178,9 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev d, const float *__restric
     if (EXPAND) {
         const int node = uniform_i32(e_node);
         if (node >= 0) {
+            const bool xst = (d.ablate & 1024) != 0;              // debug only: cycle stamps of the expansion's sub-phases
+            long long x0 = 0, x1 = 0, x2 = 0, x3 = 0, x4 = 0;
+            if (xst) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); x0 = clock64(); }
             const int slot = uniform_i32(e_slot);
             const int depth = uniform_i32(e_depth);
             const int nv = uniform_i32(e_nv);
@@ -210,6 +213,7 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev d, const float *__restric
                 for (int k4 = 0; k4 < KSL; k4++) { const int i = lane + AZK_WAVE * k4; if (i < A) d.cache_logits[crow * A + i] = lgv[k4]; }
                 if (lane == 0) d.cache_value[crow] = vraw;
             }
+            if (xst) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); x1 = clock64(); }
             // float32 softmax, no max subtraction (mcts.py:48-49)
 #pragma unroll
             for (int k4 = 0; k4 < KSL; k4++) {
@@ -219,7 +223,9 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev d, const float *__restric
                 if (i < A) L.e[i] = ev;
             }
             __syncthreads();
+            if (xst) x2 = clock64();
             const float s = azk_pairwise_sum(L.e, A, L.racc);
+            if (xst) x3 = clock64();
             const int fc = uniform_i32(e_top);
             const bool fits = fc + nv <= d.cap;
             if (fits) {
@@ -256,6 +262,11 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev d, const float *__restric
                 backup_path(d, base, d.path + (size_t)g * d.path_cap, depth, v);
             }
             r_N += 1;                                                 // the root is trace node 0 of every simulation
+            if (xst && lane == 0) {
+                x4 = clock64();
+                long long *qq = d.dbg + (size_t)g * 8;
+                qq[0] += x0 - t0; qq[1] += x1 - x0; qq[2] += x2 - x1; qq[3] += x3 - x2; qq[4] += x4 - x3; qq[6] += 1;
+            }
             if (lane == 0) {
                 d.leaf_node[g] = -1;
                 count_add(d, CNT_TRACE, g, depth + 1);

@@ -43,6 +43,10 @@ if out[6]:
     print("slowest simulation per game: %s %.0f cycles (AZK_STAMP_MAX=1: max over games, else mean over games)" % (
         "max" if os.environ.get("AZK_STAMP_MAX") else "mean", out[7] if os.environ.get("AZK_STAMP_MAX") else out[7] / G))
 
+if os.environ.get("AZK_TREE_ABLATE") == "1024":
+    n = out[6]
+    print("expansion per leaf (cycles): entry loads %.0f | logits/noise/header loads %.0f | exp %.0f | pairwise sum %.0f | children + backup %.0f" % (
+        out[0] / n, out[1] / n, out[2] / n, out[3] / n, out[4] / n))
 if os.environ.get("AZK_TREE_ABLATE") == "64":
     n = out[6]
     print("walk per simulation (cycles): load wait %.0f | loads+ucb %.0f (incl. the wait) | argmax+readlanes %.0f | path/board update %.0f | levels %.2f" % (
