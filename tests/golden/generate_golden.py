@@ -354,7 +354,8 @@ def gen_games():
     import json
     specs = [("gomoku", 7, 100, "hash", 7), ("gomoku", 7, 60, "uniform", 8), ("gomoku", 15, 800, "hash", 0),
              ("gomoku", 15, 200, "uniform", 3), ("tictactoe", 3, 25, "hash", 11), ("connect4", 0, 200, "hash", 12),
-             ("tictactoe", 3, 25, None, 0), ("connect4", 0, 50, None, 5)]
+             ("tictactoe", 3, 25, None, 0), ("connect4", 0, 50, None, 5),
+             ("gomoku", 7, 40, None, 9), ("gomoku", 15, 16, None, 4)]       # vanilla Gomoku: rollouts through get_valid_moves' set order
     for gi, (gname, size, n_sims, variant, seed) in enumerate(specs):
         Game = {"gomoku": GMK, "tictactoe": TTT, "connect4": C4}[gname]
         if gname == "gomoku":

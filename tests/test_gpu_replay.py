@@ -11,7 +11,7 @@ from fixture_eval import fixture_logits_value
 pytestmark = pytest.mark.gpu
 
 _GZ = load_golden("games.npz")
-_META = [m for m in golden_meta(_GZ) if "buffer_digest" in m]
+_META = [m for m in golden_meta(_GZ) if "buffer_digest" in m and m["variant"]]
 
 
 @pytest.mark.parametrize("m", _META, ids=[f"g{m['game']}-gomoku{m['size']}-n{m['n_sims']}-{m['variant']}" for m in _META])
