@@ -990,27 +990,33 @@ __global__ __launch_bounds__(256, 2) void k_embed_pool(EmbedPoolArgs a) {
                 q01 = __builtin_elementwise_fma(lo, lo, q01);
                 q23 = __builtin_elementwise_fma(hi, hi, q23);
             }
-            const float pss[4] = {row16_sum(q01[0]), row16_sum(q01[1]), row16_sum(q23[0]), row16_sum(q23[1])};
+            // the row pairs (0,1) and (2,3) travel as float2 from here on: every step below works on adjacent register pairs
+            // (packed-math operands), nothing has to be shuffled into place
+            const f32x2 pq01 = {row16_sum(q01[0]), row16_sum(q01[1])}, pq23 = {row16_sum(q23[0]), row16_sum(q23[1])};
+            f32x2 *part2 = (f32x2 *)part;                             // [parity][8 row pairs][4 waves]
             if (l15 == 0) {
-#pragma unroll
-                for (int r4 = 0; r4 < 4; r4++) part[(par * 16 + 4 * l4 + r4) * 4 + wave] = pss[r4];
+                part2[(par * 8 + 2 * l4) * 4 + wave] = pq01;
+                part2[(par * 8 + 2 * l4 + 1) * 4 + wave] = pq23;
             }
             __syncthreads();
-            float rstd[4], shift[4];
-#pragma unroll
-            for (int r4 = 0; r4 < 4; r4++) {
-                const f32x4 p = *(const f32x4 *)(part + (par * 16 + 4 * l4 + r4) * 4);
-                const float s2 = (p[0] + p[1]) + (p[2] + p[3]);
-                const float var = fmaxf(s2 * (1.0f / (float)D) - mean[r4] * mean[r4], 0.f);
-                rstd[r4] = __builtin_amdgcn_rsqf(var + a.eps);
-                shift[r4] = -mean[r4] * rstd[r4];
-            }
+            const f32x4 *pp = (const f32x4 *)(part2 + (par * 8 + 2 * l4) * 4);
+            const f32x4 a0 = pp[0], a1 = pp[1], b0 = pp[2], b1 = pp[3];   // pair (0,1): waves 0,1 | 2,3; pair (2,3): likewise
+            const f32x2 s01 = (f32x2{a0[0], a0[1]} + f32x2{a0[2], a0[3]}) + (f32x2{a1[0], a1[1]} + f32x2{a1[2], a1[3]});
+            const f32x2 s23 = (f32x2{b0[0], b0[1]} + f32x2{b0[2], b0[3]}) + (f32x2{b1[0], b1[1]} + f32x2{b1[2], b1[3]});
+            const f32x2 mean01 = {mean[0], mean[1]}, mean23 = {mean[2], mean[3]};
+            const f32x2 invD = {1.0f / (float)D, 1.0f / (float)D};
+            const f32x2 v01 = __builtin_elementwise_fma(-mean01, mean01, s01 * invD), v23 = __builtin_elementwise_fma(-mean23, mean23, s23 * invD);
+            const f32x2 r01 = {__builtin_amdgcn_rsqf(fmaxf(v01[0], 0.f) + a.eps), __builtin_amdgcn_rsqf(fmaxf(v01[1], 0.f) + a.eps)};
+            const f32x2 r23 = {__builtin_amdgcn_rsqf(fmaxf(v23[0], 0.f) + a.eps), __builtin_amdgcn_rsqf(fmaxf(v23[1], 0.f) + a.eps)};
+            const f32x2 h01 = -mean01 * r01, h23 = -mean23 * r23;    // xn = x * rstd + shift
             par ^= 1;
             // ---- scores (head = lane&15, tokens 4 (lane>>4) + r4) and softmax weights; lanes >= NH carry harmless finite
             //      values into rows of Z that are never stored ----
-            float sc[4], w[4];
-#pragma unroll
-            for (int r4 = 0; r4 < 4; r4++) sc[r4] = rstd[r4] * (acce[r4] - mean[r4] * msum);
+            const f32x2 ms2 = {msum, msum};
+            const f32x2 sc01 = r01 * __builtin_elementwise_fma(-mean01, ms2, f32x2{acce[0], acce[1]});
+            const f32x2 sc23 = r23 * __builtin_elementwise_fma(-mean23, ms2, f32x2{acce[2], acce[3]});
+            const float sc[4] = {sc01[0], sc01[1], sc23[0], sc23[1]};
+            float w[4];
             if (STATIC_REF) {
 #pragma unroll
                 for (int r4 = 0; r4 < 4; r4++) w[r4] = __expf(sc[r4] - sref);
@@ -1037,7 +1043,6 @@ __global__ __launch_bounds__(256, 2) void k_embed_pool(EmbedPoolArgs a) {
             L += (w[0] + w[1]) + (w[2] + w[3]);
             // ---- Z += W^T Xn : A = weights (bf16), B = normalised tile (bf16), both already in operand layout ----
             const s16x4 wa = pack4_bf16(f32x2{w[0], w[1]}, f32x2{w[2], w[3]});
-            const f32x2 r01 = {rstd[0], rstd[1]}, r23 = {rstd[2], rstd[3]}, h01 = {shift[0], shift[1]}, h23 = {shift[2], shift[3]};
 #pragma unroll
             for (int q = 0; q < 8; q++) {
                 const f32x2 lo = {acc[q][0], acc[q][1]}, hi = {acc[q][2], acc[q][3]};
