@@ -249,14 +249,17 @@ __device__ int azk_valid_moves(const uint8_t *b, const GameDesc &g, int16_t *mov
     for (int base = 0; base < nwords; base += AZK_WAVE) {
         const int w = base + lane;
         const int p = w < nwords ? __popc(ms.bits[w]) : 0;
+        // inclusive wave scan on DPP (GFX9): row_shr 1,2,4,8 with zero fill, then row_bcast:15 into rows 1,3 and
+        // row_bcast:31 into rows 2,3 - no LDS-crossbar shuffles
         int incl = p;
-#pragma unroll
-        for (int off = 1; off < AZK_WAVE; off <<= 1) {
-            const int t = __shfl_up(incl, off);
-            if (lane >= off) incl += t;
-        }
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, true);
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, true);
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xF, 0xF, true);
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xF, 0xF, true);
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xA, 0xF, false);
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xC, 0xF, false);
         if (w < nwords) ms.pref[w] = (uint16_t)(total + incl - p);
-        total += __shfl(incl, AZK_WAVE - 1);
+        total += __builtin_amdgcn_readlane(incl, AZK_WAVE - 1);
     }
     __syncthreads();
     const int m = total;
@@ -266,11 +269,20 @@ __device__ int azk_valid_moves(const uint8_t *b, const GameDesc &g, int16_t *mov
         return 1;
     }
     // 3. rank every candidate by its key -> first-insertion order (ord[] holds cell + 1)
+    {
+        unsigned pf[KMAX], bw[KMAX];
 #pragma unroll
-    for (int k = 0; k < KMAX; k++) {
-        if (key[k] != 0xffffffffu) {
-            const int rank = ms.pref[key[k] >> 5] + __popc(ms.bits[key[k] >> 5] & ((1u << (key[k] & 31)) - 1u));
-            ms.ord[rank] = (int16_t)(lane + AZK_WAVE * k + 1);
+        for (int k = 0; k < KMAX; k++) {                            // straight-line LDS reads (invalid keys read word 0)
+            const unsigned wd = key[k] != 0xffffffffu ? key[k] >> 5 : 0u;
+            pf[k] = ms.pref[wd];
+            bw[k] = ms.bits[wd];
+        }
+#pragma unroll
+        for (int k = 0; k < KMAX; k++) {
+            if (key[k] != 0xffffffffu) {
+                const int rank = (int)pf[k] + __popc(bw[k] & ((1u << (key[k] & 31)) - 1u));
+                ms.ord[rank] = (int16_t)(lane + AZK_WAVE * k + 1);
+            }
         }
     }
     __syncthreads();
