@@ -22,7 +22,7 @@ def boards_of(m, k):
 
 
 def test_emission_matches_reference_buffers():
-    assert len(_META) == 4
+    assert len(_META) == 6                                           # four network-mode Gomoku games + two vanilla ones
     for m in _META:
         k = f"g{m['game']}_"
         tuples = ro.emit_tuples(boards_of(m, k), list(_Z[k + "pis"]), m["winner"])
