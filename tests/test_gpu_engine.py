@@ -409,3 +409,50 @@ def test_eval_cache_whole_games_identical(azk):
     assert s0["cache_hits"] == 0 and s1["cache_hits"] > 0
     assert s1["leaves_evaluated"] + s1["cache_hits"] == s0["leaves_evaluated"]
     assert s1["cache_hits"] / s0["leaves_evaluated"] > 0.15          # the reference sees 34-66 %
+
+
+@pytest.mark.parametrize("size,plies,n_sims", [(19, 0, 40), (19, 30, 120), (20, 90, 80), (11, 14, 150)])
+def test_large_and_odd_gomoku_boards_vs_oracle(azk, ao, size, plies, n_sims):
+    """Boards beyond 256 cells (19x19, 20x20: seven cells per lane, the 2048-slot set tables) and an odd mid size: legal-move
+    order on dense random boards and whole search trees equal the oracle's."""
+    game = ao.OracleGame("gomoku", size)
+    rng = np.random.RandomState(size * 1000 + plies)
+    # rules: random boards of every density
+    n = 24
+    boards = np.zeros((n, 2, size, size), np.float32)
+    for i in range(n):
+        dens = rng.uniform(0.02, 0.9)
+        u = rng.rand(size, size)
+        boards[i, 0] = u < dens / 2
+        boards[i, 1] = (u >= dens / 2) & (u < dens)
+    moves, counts = azk.rules_legal_moves("gomoku", torch.from_numpy(boards).to(dev()), size)
+    moves, counts = moves.cpu().numpy(), counts.cpu().numpy()
+    for i in range(n):
+        assert moves[i, :counts[i]].tolist() == game.valid_cells(boards[i]).tolist(), i
+    # search: a random legal prefix without a winner, then a tree
+    b = game.new_board()
+    player, mc = 0, 0
+    while mc < plies:
+        vm = game.valid_cells(b)
+        cell = int(vm[rng.randint(len(vm))])
+        b2 = b.copy()
+        nxt = game.make_move(b2, player, game.rc(cell))
+        if game.check_winner(b2, player, game.rc(cell)) == -1:
+            b, player, mc = b2, nxt, mc + 1
+    cells = (b[0] + 2 * b[1]).astype(np.int8).reshape(-1)
+    A = size * size
+    noise = rng.dirichlet([0.03] * A)
+
+    def evc(canon):
+        logits, v = fixture_logits_value(torch.from_numpy(np.ascontiguousarray(canon))[None], A, "hash")
+        return ao.softmax_det(logits[0].numpy()), float(v[0])
+    tree = ao.OracleTree(game, cap=1 + n_sims * A)
+    tree.reset(player, mc)
+    ao.mcts(game, tree, b.copy(), n_sims, evc, noise, None, None, None)
+    eng = azk.Engine("gomoku", 2, n_sims, size=size)
+    eng.set_positions(np.tile(cells, (2, 1)), [player] * 2, [mc] * 2)
+    eng.search(gpu_evaluator(A, "hash"), n_sims, torch.from_numpy(np.tile(noise, (2, 1))).to(dev()))
+    eng.check_error()
+    want = digest(tree.export())
+    assert digest(eng.export_tree(0)) == want and digest(eng.export_tree(1)) == want
+    eng.close()
