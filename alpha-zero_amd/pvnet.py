@@ -231,7 +231,9 @@ class PolicyValueNet:
             Wvn = (Wv * g)                                                                              # [H, dh, D]
             Wcomb = torch.einsum("ohe,hed->hdo", Wo.view(D, H, dh), Wvn).reshape(H * D, D)              # [H*D, D]
             bvn = bi[2 * D:].to(dev) + (Wv @ bta).reshape(-1)
-            f["Wcomb"] = Wcomb.to(torch.bfloat16).contiguous()
+            # the library GEMMs of the tail take the weights in nn.Linear layout [out, in] through a .t() view: measured 10-20 %
+            # faster than a contiguous [in, out] operand at these skinny shapes (hipBLASLt picks its "NT" kernels)
+            f["Wcomb"] = Wcomb.t().contiguous().to(torch.bfloat16).t()                                  # logical [H*D, D], stored [D, H*D]
             f["bias1"] = (x0 + bo + Wo @ bvn).to(torch.bfloat16)
             # policy and value heads as one GEMM ([A+1] outputs, padded to a multiple of 8 columns)
             A = cfg.action_dim
@@ -241,8 +243,8 @@ class PolicyValueNet:
             Wh[:A], bh[:A] = m["policy_head.weight"].to(dev), m["policy_head.bias"].to(dev)
             Wh[A], bh[A] = m["value_head.weight"].to(dev)[0], m["value_head.bias"].to(dev)[0]
             f["Wh"], f["bh"] = Wh.to(torch.bfloat16), bh.to(torch.bfloat16)
-            f["W0T"] = m["blocks.0.mlp.0.weight"].t().contiguous().to(dev, torch.bfloat16)
-            f["W3T"] = m["blocks.0.mlp.3.weight"].t().contiguous().to(dev, torch.bfloat16)
+            f["W0T"] = m["blocks.0.mlp.0.weight"].to(dev, torch.bfloat16).contiguous().t()             # logical [D, 4D], stored [4D, D]
+            f["W3T"] = m["blocks.0.mlp.3.weight"].to(dev, torch.bfloat16).contiguous().t()             # logical [4D, D], stored [D, 4D]
             # the same tail for the hand-written small-M GEMM (azk_nn_gemm_rows): weights in MFMA fragment order, float32 biases
             import azk
             f["WcombP"] = azk.pack_linear_weight(Wcomb.t().contiguous())                               # [D, H*D] as an nn.Linear weight
