@@ -1363,6 +1363,98 @@ __global__ void k_heads_finalize_sum(const float *__restrict__ P, int nsplit, in
         else values[row] = tanhf(v);
     }
 }
+
+// Final LayerNorm + merged heads for embed_dim = 32 KT, LayerNorm's affine folded into the weight (W diag(gamma)) and the bias
+// (W beta + b) by the caller: one wave = 16 rows x 64 output columns; the wave's 16 x K slab of x is fetched ONCE (KT loads in
+// flight together with the first weight fragments), the row statistics come from those registers, the normalised fragments
+// feed the MFMAs - three to four dependent memory round trips per wave instead of eight.
+template <int KT>
+__global__ __launch_bounds__(256) void k_ln_heads(GemmArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, l4 = lane >> 4;
+    const int nvalid = a.count ? min(a.M, *a.count) : a.M;
+    const int rtiles = (nvalid + 15) >> 4, ngroups = a.N >> 6;
+    const int nitems = rtiles * ngroups;
+    constexpr int K = 32 * KT;
+    for (int item = blockIdx.x * 4 + wave; item < nitems; item += gridDim.x * 4) {
+        const int ng = item % ngroups, rt = item / ngroups;
+        const int row = min(16 * rt + l15, nvalid - 1);
+        const unsigned short *ap = a.A + (size_t)row * a.lda + 8 * l4;
+        const uint4 *bp = a.Wp + (size_t)ng * KT * 4 * 64 + lane;
+        uint4 raw[KT];
+#pragma unroll
+        for (int ks = 0; ks < KT; ks++) raw[ks] = *(const uint4 *)(ap + 32 * ks);
+        union BF { uint4 u; bf16x8 v; };
+        BF bf[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) bf[u][c].u = bp[(u * 4 + c) * 64];
+        __builtin_amdgcn_sched_barrier(0);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KT; ks++) {
+            const unsigned w4[4] = {raw[ks].x, raw[ks].y, raw[ks].z, raw[ks].w};
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const float lo = __uint_as_float(w4[q] << 16), hi = __uint_as_float(w4[q] & 0xffff0000u);
+                s1 += lo + hi; s2 += lo * lo + hi * hi;
+            }
+        }
+        s1 += __shfl_xor(s1, 16); s1 += __shfl_xor(s1, 32);
+        s2 += __shfl_xor(s2, 16); s2 += __shfl_xor(s2, 32);
+        const float mean = s1 * (1.0f / K);
+        const float rstd = rsqrtf(fmaxf(s2 * (1.0f / K) - mean * mean, 0.f) + a.ln_eps);
+        const float shift = -mean * rstd;
+        f32x4 acc[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < KT; kb += 4) {
+            BF nb[4][4];
+            if (kb + 4 < KT) {
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+#pragma unroll
+                    for (int c = 0; c < 4; c++) nb[u][c].u = bp[((kb + 4 + u) * 4 + c) * 64];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint4 r = raw[kb + u];
+                const unsigned w4[4] = {r.x, r.y, r.z, r.w};
+                float v[8];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    v[2 * q] = __uint_as_float(w4[q] << 16) * rstd + shift;
+                    v[2 * q + 1] = __uint_as_float(w4[q] & 0xffff0000u) * rstd + shift;
+                }
+                BF af;
+                af.u = pack8(v);
+#pragma unroll
+                for (int c = 0; c < 4; c++) acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af.v, bf[u][c].v, acc[c], 0, 0, 0);
+            }
+            if (kb + 4 < KT) {
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+#pragma unroll
+                    for (int c = 0; c < 4; c++) bf[u][c] = nb[u][c];
+            }
+        }
+        const int col0 = 64 * ng + 4 * l15;
+        const f32x4 bv = *(const f32x4 *)(a.bias + col0);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int orow = 16 * rt + 4 * l4 + j;
+            if (orow >= nvalid) continue;
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const int col = col0 + c;
+                const float x = acc[c][j] + bv[c];
+                if (col < a.action_dim) a.logits[(size_t)orow * a.action_dim + col] = x;
+                else if (col == a.action_dim) a.values[orow] = tanhf(x);
+            }
+        }
+    }
+}
 }  // namespace
 
 extern "C" int32_t azk_nn_gemm_rows(const void *a_bf16_dev, int32_t lda, const void *w_packed_dev, int32_t m, int32_t n_out,
@@ -1389,7 +1481,7 @@ extern "C" int32_t azk_nn_ln_heads(const void *x_bf16_dev, const float *ln_w_dev
                                    const void *w_packed_dev, const float *bias_dev, int32_t n, int32_t embed_dim, int32_t n_out_padded,
                                    int32_t action_dim, float *logits_out_dev, float *values_out_dev, const int32_t *n_valid_dev,
                                    void *stream) {
-    if (!x_bf16_dev || !ln_w_dev || !ln_b_dev || !w_packed_dev || !bias_dev || !logits_out_dev || !values_out_dev) return AZK_ERR_ARG;
+    if (!x_bf16_dev || (ln_w_dev == nullptr) != (ln_b_dev == nullptr) || !w_packed_dev || !bias_dev || !logits_out_dev || !values_out_dev) return AZK_ERR_ARG;
     if (n < 0 || embed_dim < 128 || (embed_dim & 127) || n_out_padded < 64 || (n_out_padded & 63) || action_dim + 1 > n_out_padded) return AZK_ERR_ARG;
     if (n == 0) return AZK_OK;
     GemmArgs a;
@@ -1398,6 +1490,12 @@ extern "C" int32_t azk_nn_ln_heads(const void *x_bf16_dev, const float *ln_w_dev
     a.ln_w = ln_w_dev; a.ln_b = ln_b_dev; a.ln_eps = eps; a.logits = logits_out_dev; a.values = values_out_dev; a.action_dim = action_dim;
     const long long items = (long long)((n + 15) / 16) * (n_out_padded / 64);       // 16-row x 64-column wave tiles
     const unsigned blocks = (unsigned)((items + 3) / 4 < 4096 ? (items + 3) / 4 : 4096);
+    if (!ln_w_dev) {                                                                 // affine folded into weight and bias by the caller
+        if (embed_dim == 512) k_ln_heads<16><<<blocks, 256, 0, (hipStream_t)stream>>>(a);
+        else if (embed_dim == 256) k_ln_heads<8><<<blocks, 256, 0, (hipStream_t)stream>>>(a);
+        else return AZK_ERR_ARG;
+        return hipGetLastError() == hipSuccess ? AZK_OK : AZK_ERR_HIP;
+    }
     k_gemm_rows<2, 1, 4><<<blocks, 256, 0, (hipStream_t)stream>>>(a);
     return hipGetLastError() == hipSuccess ? AZK_OK : AZK_ERR_HIP;
 }

@@ -256,6 +256,12 @@ class PolicyValueNet:
             bhp = torch.zeros(f["WhP"].numel() // D, device=dev)
             bhp[:Ap] = bh
             f["bh_f"] = bhp
+            # final LayerNorm's affine folded into the merged head: Wh (gamma * xn + beta) + bh = (Wh diag(gamma)) xn + (Wh beta + bh)
+            gf, bf_ = m["norm.weight"].to(dev), m["norm.bias"].to(dev)
+            f["WhGP"] = azk.pack_linear_weight(Wh * gf[None, :])
+            bhg = torch.zeros_like(bhp)
+            bhg[:Ap] = Wh @ bf_ + bh
+            f["bhG_f"] = bhg
             self.hip_tail = D in (256, 512) and (H * D) % 256 == 0
             for k_, src in (("ln2_w", b + "norm2.weight"), ("ln2_b", b + "norm2.bias"), ("lnf_w", "norm.weight"),
                             ("lnf_b", "norm.bias"), ("b3", b + "mlp.3.bias")):
@@ -323,7 +329,7 @@ class PolicyValueNet:
             else:
                 lb = torch.empty((n, A), dtype=torch.float32, device=z.device)
                 vb = torch.empty(n, dtype=torch.float32, device=z.device)
-            azk.nn_ln_heads(x2, f["lnf_w"], f["lnf_b"], f["WhP"], f["bh_f"], A, lb, vb, count=self.live_count)
+            azk.nn_ln_heads(x2, None, None, f["WhGP"], f["bhG_f"], A, lb, vb, count=self.live_count)     # affine folded into WhGP / bhG_f
             return lb, (vb if self.out_buffers is not None else vb[:, None])
         out = F.linear(azk.nn_layernorm_rows(x2, f["lnf_w"], f["lnf_b"], 1e-5, count=self.live_count), f["Wh"], f["bh"])   # nn.py:78-83
         if self.out_buffers is not None:

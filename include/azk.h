@@ -305,7 +305,9 @@ int32_t azk_nn_gemm_rows(const void *a_bf16_dev, int32_t lda, const void *w_pack
                          const int32_t *n_valid_dev, void *stream);
 /* azk_nn_ln_heads: final LayerNorm + merged policy/value head + finalize in one launch (nn.py:78-83 for the cls row):
  *   logits[n][A] = LN(x) Wh^T + bh (float32), values[n] = tanh(column A).  w_packed_dev: the merged head weight
- *   [n_out_padded][embed_dim] in azk_nn_gemm_rows' packing; each wave reads whole rows and takes their statistics itself. */
+ *   [n_out_padded][embed_dim] in azk_nn_gemm_rows' packing; each wave reads whole rows and takes their statistics itself.
+ *   ln_w_dev = ln_b_dev = NULL: LayerNorm's affine is already folded into the operands (weight W diag(gamma), bias
+ *   W beta + b); the kernel then fetches its 16-row slab once and normalises from registers (embed_dim 256 or 512). */
 int32_t azk_nn_ln_heads(const void *x_bf16_dev, const float *ln_w_dev, const float *ln_b_dev, float eps, const void *w_packed_dev,
                         const float *bias_dev, int32_t n, int32_t embed_dim, int32_t n_out_padded, int32_t action_dim,
                         float *logits_out_dev, float *values_out_dev, const int32_t *n_valid_dev, void *stream);

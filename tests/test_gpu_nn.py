@@ -234,6 +234,15 @@ def test_fused_final_norm_and_heads_vs_torch_fp32():
     vb = torch.full((n,), 5.0, device="cuda")
     azk.nn_ln_heads(x, f["lnf_w"], f["lnf_b"], f["WhP"], f["bh_f"], 225, lb, vb)
     assert (lb - ref_l).abs().max().item() < 2e-2 and (vb - ref_v).abs().max().item() < 5e-3
+    # the default path: LayerNorm's affine folded into the head weight / bias, slab fetched once
+    lbf = torch.full((n, 225), 5.0, device="cuda")
+    vbf = torch.full((n,), 5.0, device="cuda")
+    azk.nn_ln_heads(x, None, None, f["WhGP"], f["bhG_f"], 225, lbf, vbf)
+    assert (lbf - ref_l).abs().max().item() < 2e-2 and (vbf - ref_v).abs().max().item() < 5e-3
+    lbf2 = torch.full((n, 225), 5.0, device="cuda")
+    vbf2 = torch.full((n,), 5.0, device="cuda")
+    azk.nn_ln_heads(x, None, None, f["WhGP"], f["bhG_f"], 225, lbf2, vbf2, count=torch.tensor([live], dtype=torch.int32, device="cuda"))
+    assert torch.equal(lbf2[:live], lbf[:live]) and bool((lbf2[live:] == 5.0).all()) and bool((vbf2[live:] == 5.0).all())
     lb2 = torch.full((n, 225), 5.0, device="cuda")
     vb2 = torch.full((n,), 5.0, device="cuda")
     azk.nn_ln_heads(x, f["lnf_w"], f["lnf_b"], f["WhP"], f["bh_f"], 225, lb2, vb2, count=torch.tensor([live], dtype=torch.int32, device="cuda"))
