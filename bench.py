@@ -232,7 +232,13 @@ def main():
                                     "HBM traffic is 9 KB per board (board in, z out): the kernel is bound by VALU/MFMA issue and LDS, not HBM"})
         dominant = max(kernels, key=lambda k: k["avg_launch_us"]) if kernels else None
         flops = {"cls": cfg.flops_cls(), "full": cfg.flops_full(), "clsfold": flops_clsfold(cfg)}[args.nn_path]
-        evals = leaves_all if args.no_graph else sims_all      # graph mode evaluates the full fixed-size leaf buffer every step
+        evals = leaves_all if args.no_graph else sims_all      # graph mode runs the cls-row tail over the full fixed-size leaf buffer every step
+        nn_flop_total = evals * flops
+        if not args.no_graph and getattr(net, "fused_embed_pool", False) and args.nn_path == "clsfold":
+            # ... but the embedding / pooling kernel honours the live leaf count: only the tail is paid for dead rows
+            kreal_ = cfg.channels * cfg.patch_size ** 2
+            front = 2 * (cfg.tokens - 1) * cfg.embed_dim * kreal_ + 2 * 2 * cfg.tokens * cfg.embed_dim * cfg.num_heads
+            nn_flop_total = leaves_all * front + sims_all * (flops - front)
         out = {
             "metric": "selfplay_games_per_sec", "value": games_per_s, "unit": "games/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt_max / args.steps * 1e3,
@@ -244,7 +250,7 @@ def main():
             "sims_per_sec": sims_all / dt_max, "leaf_evals_per_sec": leaves_all / dt_max,
             "eval_cache": {"entries_per_game": args.cache_entries, "hits_rank0": c.get("cache_hits", 0),
                            "hit_rate_rank0": c.get("cache_hits", 0) / max(1, c.get("cache_hits", 0) + c["leaves_evaluated"])},
-            "nn_tflops_executed": evals * flops / dt_max / 1e12, "nn_flops_per_board": flops, "nn_boards_evaluated": evals,
+            "nn_tflops_executed": nn_flop_total / dt_max / 1e12, "nn_flops_per_board": flops, "nn_boards_evaluated": evals,
             "stepping": "eager+sync" if args.no_graph else f"hipGraph replay, {runner.n_split} game group(s) on separate streams (tree+gather+net per simulation, no host sync)",
             "value_definition": value_src, "games_per_sec_renewal_estimate": est_games_per_s,
             "mean_plies_per_game": mean_plies, "game_length_source": src, "games_finished_in_window": fin_window,
