@@ -251,7 +251,7 @@ def main():
             "eval_cache": {"entries_per_game": args.cache_entries, "hits_rank0": c.get("cache_hits", 0),
                            "hit_rate_rank0": c.get("cache_hits", 0) / max(1, c.get("cache_hits", 0) + c["leaves_evaluated"])},
             "nn_tflops_executed": nn_flop_total / dt_max / 1e12, "nn_flops_per_board": flops, "nn_boards_evaluated": evals,
-            "stepping": "eager+sync" if args.no_graph else f"hipGraph replay, {runner.n_split} game group(s) on separate streams (tree+gather+net per simulation, no host sync)",
+            "stepping": "eager+sync" if args.no_graph else f"hipGraph replay, {runner.n_split} game group(s) (per simulation: k_tree, the network kernels taking the pending leaves straight from the engine, no host sync)",
             "value_definition": value_src, "games_per_sec_renewal_estimate": est_games_per_s,
             "mean_plies_per_game": mean_plies, "game_length_source": src, "games_finished_in_window": fin_window,
             "plies_in_window": plies_all, "counters_rank0": c, "roofline": dominant, "roofline_puct": roof, "kernel_rooflines": kernels,
