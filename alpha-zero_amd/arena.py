@@ -20,12 +20,17 @@ def _game_name(game, size):
 
 
 def compete_batch(game, model1, model2, n_games, model1_mcts_iter=50, model2_mcts_iter=50, sampling=False, size=None,
-                  seed=0, first_global_game=0, device=0, leaf_dtype="float32", noise_fn=None, uniform_fn=None):
-    """n_games independent test.compete games at once -> (winners int array in {0, 1, -1}, final boards)."""
+                  seed=0, first_global_game=0, device=0, leaf_dtype="float32", noise_fn=None, uniform_fn=None, cache_entries=0):
+    """n_games independent test.compete games at once -> (winners int array in {0, 1, -1}, final boards).
+
+    cache_entries > 0 turns on the per-game eval cache, which - like the reference's process-global MCTS.cache (mcts.py:7,
+    38-44: keyed by the position alone) - is shared by BOTH models: whichever model evaluated a position first also answers
+    for the other.  That reproduces the reference's compete games exactly as long as no entry is evicted (direct-mapped
+    table: size it well above the positions a game visits); with 0 every model evaluates its own positions."""
     game, size = _game_name(game, size)
     res = self_play_batch(game, (model1, model2), n_games, (model1_mcts_iter, model2_mcts_iter), size=size, seed=seed,
                           first_global_game=first_global_game, device=device, leaf_dtype=leaf_dtype,
-                          noise_fn=noise_fn, uniform_fn=uniform_fn, sample_until=20 if sampling else 0)
+                          noise_fn=noise_fn, uniform_fn=uniform_fn, sample_until=20 if sampling else 0, cache_entries=cache_entries)
     winners = np.array([r.winner for r in res], np.int64)
     return winners, res
 

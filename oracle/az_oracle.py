@@ -290,20 +290,21 @@ def self_play(game, evaluator, n_sims, noise_fn=None, uniform_fn=None, cache=Non
     winner = None
     while True:
         tree.reset(player, mc)
-        noise = noise_fn(mc) if (evaluator is not None and noise_fn is not None) else None
-        ev_now = evaluator2 if (evaluator2 is not None and (mc & 1)) else evaluator       # test.compete: model1 / model2 by side
+        two_sided = evaluator2 is not None or n_sims2 is not None
+        ev_now = evaluator2 if (two_sided and (mc & 1)) else evaluator                     # test.compete: model1 / model2 by side (either may be None)
+        noise = noise_fn(mc) if (ev_now is not None and noise_fn is not None) else None   # only a network search draws Dirichlet noise
         n_now = n_sims2 if (n_sims2 is not None and (mc & 1)) else n_sims
         mcts(game, tree, board, n_now, ev_now, noise, cache, randint, counters)
         pi = tree.pi()
         pis.append(pi)
         boards.append(board.copy())
         qs.append(tree.root_value / tree.root_visit)
-        if evaluator is not None:
+        if sample_until is not None:
+            sample = mc < sample_until                                  # test.compete: move_count < 20 when sampling, whatever the model
+        elif evaluator is not None:
             sample = (mc < 8) if game.name == "gomoku" else True        # gomoku.py:144 vs tictactoe.py:117
-            if sample_until is not None:
-                sample = mc < sample_until                              # test.compete: move_count < 20 when sampling
         else:
-            sample = False
+            sample = False                                              # self_play(None, ...): max_visit_child
         if sample:
             a = sample_action(pi, uniform_fn(mc))
             cell = tree.cell_for_action(a)

@@ -407,6 +407,40 @@ def gen_games():
 
 
 # =================================================================================
+# 3b. test.compete (test.py:60-105): two agents alternating by side, optional sampling for move_count < 20
+# =================================================================================
+def gen_compete():
+    import importlib
+    ref_test = importlib.import_module("test")          # /root/reference/test.py (sys.path[0] = REF shadows the stdlib package)
+    assert os.path.abspath(ref_test.__file__).startswith(REF)
+    import json
+    out, meta = {}, []
+    specs = [(7, "hash", "uniform", 40, 24, True, 21), (7, "uniform", "hash", 30, 30, False, 22), (15, "hash", "uniform", 60, 40, True, 23),
+             (7, None, "hash", 30, 30, False, 24)]          # last one: vanilla MCTS as player 0 (main.py:76 shape)
+    for ci, (size, v1, v2, it1, it2, sampling, seed) in enumerate(specs):
+        set_gomoku(size)
+        MCTS.cache.clear()
+        MCTS.matched = 0
+        MCTS.mcts_count = 0
+        m1 = FixtureModel(GMK.action_dim, v1) if v1 else None
+        m2 = FixtureModel(GMK.action_dim, v2) if v2 else None
+        np.random.seed(seed)
+        with RngRecorder() as rec, torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+            winner, board = ref_test.compete(GMK, m1, m2, it1, it2, sampling=sampling, display=False)
+        k = f"c{ci}_"
+        out[k + "final_cells"] = cells_of(GMK, board)
+        out[k + "noise"] = np.stack(rec.noise) if rec.noise else np.zeros((0, GMK.action_dim))
+        out[k + "uniforms"] = np.array(rec.uniforms, np.float64)
+        out[k + "randints"] = np.array(rec.randints, np.int32).reshape(-1, 2)
+        m = dict(case=ci, size=size, variant1=v1, variant2=v2, iter1=it1, iter2=it2, sampling=sampling, seed=seed,
+                 winner=int(winner), n_moves=int((board[0] + board[1]).sum()), mcts_count=int(MCTS.mcts_count), matched=int(MCTS.matched))
+        meta.append(m)
+        print("compete", m)
+    out["meta_json"] = np.frombuffer(json.dumps(meta).encode(), np.uint8)
+    return out
+
+
+# =================================================================================
 # 4. network known-answer test (small config; weights committed as data)
 # =================================================================================
 def gen_nn_small():
@@ -493,7 +527,7 @@ def gen_train():
 
 
 def main():
-    which = sys.argv[1:] or ["rules", "search", "games", "nn", "train"]
+    which = sys.argv[1:] or ["rules", "search", "games", "compete", "nn", "train"]
     print("python", sys.version.split()[0], "numpy", np.__version__, "torch", torch.__version__,
           "cpus", os.cpu_count(), "torch threads", torch.get_num_threads())
     if "rules" in which:
@@ -511,6 +545,8 @@ def main():
         np.savez_compressed(os.path.join(HERE, "search.npz"), **gen_search_cases())
     if "games" in which:
         np.savez_compressed(os.path.join(HERE, "games.npz"), **gen_games())
+    if "compete" in which:
+        np.savez_compressed(os.path.join(HERE, "compete.npz"), **gen_compete())
     if "nn" in which:
         np.savez_compressed(os.path.join(HERE, "nn_small.npz"), **gen_nn_small())
     if "train" in which:
