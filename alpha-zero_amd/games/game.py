@@ -106,11 +106,43 @@ class Game:
         from ai import MCTS
         MCTS.mcts(model, board, root, cls, mcts_iterations, dirichlet)
 
+    def _self_play_like_the_reference(self, model, mcts_iter, display):
+        """The reference's own loop (gomoku.py:123-164 / tictactoe.py:99-133 / connect4.py:117-151) over the facade's
+        primitives, one search per move: np.random.dirichlet is drawn once per search and np.random.choice once per sampled
+        move from the GLOBAL stream, exactly where the reference draws them - a caller that seeds np.random gets the
+        reference's game."""
+        from ai import Node
+        cls = type(self)
+        gomoku = cls.engine_name == "gomoku"
+        player, move_count = 0, 0
+        boards, actions, pis, qs = [], [(-1, -1)], [], []
+        while True:
+            root = Node(None, None, player, move_count)
+            cls.mcts(model, self.board, root, mcts_iter)
+            pis.append(root.visit_distribution(cls))                    # utils.get_probablity_distribution_of_children
+            boards.append(self.board.copy())
+            qs.append(root.value / root.visit)
+            sample = move_count < 8 if gomoku else True                 # gomoku.py:144; tictactoe.py:117 / connect4.py:135 (model given)
+            child = root.sample_child(cls) if sample else root.max_visit_child()
+            player = cls.make_move(self.board, player, child.prevAction)
+            move_count += 1
+            actions.append(child.prevAction)
+            winner = cls.check_winner(self.board, root.currentPlayer, child.prevAction)
+            if winner == -1 and move_count == cls.state_dim:
+                break
+            if winner != -1:
+                break
+        if display:
+            cls.display_board(self.board)
+        if gomoku:
+            return boards, actions, pis, qs, winner
+        return boards, pis, winner
+
     # ---- one self-play game (the reference's per-game entry point) -------------------------------------
     def self_play(self, model, mcts_iter, display=False):
-        """One game through the batched engine (G = 1).  Gomoku returns the reference's 5-tuple
-        (boards, actions, pis, qs, winner) (gomoku.py:164); TicTacToe / Connect4 their 3-tuple
-        (boards, pis, winner) (tictactoe.py:133, connect4.py:151).  For throughput call
+        """One game on the engine (G = 1).  Gomoku returns the reference's 5-tuple (boards, actions, pis, qs, winner)
+        (gomoku.py:164); TicTacToe / Connect4 their 3-tuple (boards, pis, winner) (tictactoe.py:133, connect4.py:151).
+        The global np.random stream is consumed exactly as the reference consumes it.  For throughput call
         selfplay.self_play_batch instead - thousands of games per call."""
         from selfplay import self_play_batch
         cls = type(self)
@@ -125,8 +157,7 @@ class Game:
             np.random.set_state(azk.mt_state_to_numpy(eng.vanilla_get_rng()[0], st))
             eng.close()
         else:
-            seed = int(np.random.randint(0, 2 ** 31 - 1))
-            res = self_play_batch(cls.engine_name, model, 1, mcts_iter, size=cls._size(), seed=seed)[0]
+            return self._self_play_like_the_reference(model, mcts_iter, display)
         self.board = res.boards[-1].copy()
         last = res.actions[-1]
         cls.make_move(self.board, (len(res.boards) - 1) % 2, last)

@@ -200,3 +200,41 @@ def test_train_py_facade_collect_and_train():
     assert any(not torch.equal(before[k], after[k]) for k in before)
     logits, v = net(torch.zeros(2, 2, 7, 7, device="cuda"))
     assert logits.shape == (2, 49) and torch.isfinite(logits.float()).all()
+
+
+@pytest.mark.parametrize("gi", [0, 1, 4, 5])
+def test_network_self_play_like_a_seeded_reference_caller(gi):
+    """np.random.seed(s); Game().self_play(model, n) - the reference's own call (train.collect_data) - returns the
+    reference's game: the facade draws np.random.dirichlet / np.random.choice from the global stream exactly where the
+    reference does, so the recorded golden games come out bit for bit (pis, boards, actions, winner)."""
+    from games import Connect4, Gomoku, TicTacToe
+    z = load_golden("games.npz")
+    m = next(x for x in golden_meta(z) if x["game"] == gi)
+    if m["name"] == "gomoku":
+        Gomoku.rows = Gomoku.cols = m["size"]
+        Gomoku.action_dim = Gomoku.state_dim = m["size"] ** 2
+    Game = {"gomoku": Gomoku, "tictactoe": TicTacToe, "connect4": Connect4}[m["name"]]
+    k = f"g{gi}_"
+    np.random.seed(m["seed"])
+    out = Game().self_play(GpuFixtureModel(Game.action_dim, m["variant"]), m["n_sims"])
+    if m["name"] == "gomoku":
+        boards, actions, pis, qs, winner = out
+        assert [a[0] * Game.cols + a[1] for a in actions[1:]] == z[k + "actions"].tolist()
+        assert np.array(qs, np.float64).tobytes() == z[k + "qs"].tobytes()
+    else:
+        boards, pis, winner = out
+    assert winner == m["winner"] and len(boards) == m["n_moves"]
+    assert np.stack(pis).tobytes() == z[k + "pis"].tobytes()
+    got_cells = np.stack([(b[0] + 2 * b[1]).astype(np.int8).reshape(-1) for b in boards])
+    assert np.array_equal(got_cells, z[k + "board_cells"])
+    # and the global stream is where the reference left it: the next draw equals the one after replaying the recorded draws
+    after = np.random.random_sample()
+    rs = np.random.RandomState(m["seed"])
+    A = Game.action_dim
+    ui = 0
+    for t in range(len(z[k + "noise"])):
+        rs.dirichlet([0.03] * A)
+        if ui < len(z[k + "uniforms"]) and (m["name"] != "gomoku" or t < 8):
+            rs.random_sample()
+            ui += 1
+    assert after == rs.random_sample()
