@@ -15,6 +15,7 @@ import numpy as np
 from .node import Node
 
 _ENGINES = {}
+FACADE_CACHE_ENTRIES = 1 << 18      # eval-cache entries per game of the facade's engines (MCTS.cache; exact while nothing is evicted)
 
 
 def _engine(Game, n_games, n_sims):
@@ -25,9 +26,23 @@ def _engine(Game, n_games, n_sims):
         if eng is not None:
             eng.close()
         size = Game.rows if Game.engine_name == "gomoku" else None
-        eng = azk.Engine(Game.engine_name, n_games, max(n_sims, 64), size=size)
+        eng = azk.Engine(Game.engine_name, n_games, max(n_sims, 64), size=size,
+                         cache_entries=FACADE_CACHE_ENTRIES if n_games <= 16 else 0)
+        eng._facade_hits = 0
         _ENGINES[key] = eng
     return eng
+
+
+class _EvalCacheView(dict):
+    """MCTS.cache (mcts.py:7): the reference's process-global dict position -> (policy, value), which every search of every
+    model reads and fills until main.py:55 clears it.  Here it is the eval cache of the facade's engines (keyed by the exact
+    position, shared by whatever models are searched, persistent across calls); clear() is the operation callers use."""
+
+    def clear(self):
+        for eng in _ENGINES.values():
+            if eng.cache_entries:
+                eng.clear_cache()
+        super().clear()
 
 
 def _cells(board):
@@ -35,9 +50,8 @@ def _cells(board):
 
 
 class MCTS:
-    # ai/mcts.py:7-9.  The engine has no eval cache yet (it is semantically transparent),
-    # so `matched` stays 0 and `cache` stays empty; mcts_count counts simulations as the reference does.
-    cache = {}
+    # ai/mcts.py:7-9: cache hits are counted in `matched`, simulations in `mcts_count`, as the reference does
+    cache = _EvalCacheView()
     matched = 0
     mcts_count = 0
 
@@ -84,6 +98,10 @@ class MCTS:
             return logits, value
         eng.search(evaluator, mcts_iterations, nz)
         eng.check_error()
+        if eng.cache_entries:
+            hits = eng.counters()["cache_hits"]
+            MCTS.matched += hits - eng._facade_hits
+            eng._facade_hits = hits
         MCTS.mcts_count += mcts_iterations * G
         MCTS._materialise(eng, roots, Game, f32_prior=not dirichlet)
 

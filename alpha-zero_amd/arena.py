@@ -35,6 +35,31 @@ def compete_batch(game, model1, model2, n_games, model1_mcts_iter=50, model2_mct
     return winners, res
 
 
+def compete(Game, model1, model2, model1_mcts_iter=50, model2_mcts_iter=50, sampling=False, display=False):
+    """test.compete (test.py:60-105) for ONE game, as the reference runs it: the facade's primitives, one search per move,
+    np.random.dirichlet / np.random.choice / np.random.randint from the global stream where the reference draws them, and
+    one eval cache shared by both models (MCTS.cache).  Returns (winner, final board).  Use compete_batch for throughput."""
+    from ai import Node
+    game = Game()
+    player, move_count = 0, 0
+    while True:
+        if display:
+            Game.display_board(game.board)
+        root = Node(None, None, player, move_count)
+        if player == 0:
+            Game.mcts(model1, game.board, root, model1_mcts_iter)
+        else:
+            Game.mcts(model2, game.board, root, model2_mcts_iter)
+        child = root.sample_child(Game) if (sampling and move_count < 20) else root.max_visit_child()
+        player = Game.make_move(game.board, player, child.prevAction)
+        move_count += 1
+        winner = Game.check_winner(game.board, root.currentPlayer, child.prevAction)
+        if winner != -1:
+            return winner, game.board
+        if move_count == Game.state_dim:
+            return -1, game.board
+
+
 def score_like_reference(winners_first_half, winners_second_half, iterations, early_stopping):
     """test.compare's bookkeeping (test.py:107-140) over outcomes given in game order.
     Returns 1 / 0 on an early stop (accepted / rejected) else the contender's win rate."""

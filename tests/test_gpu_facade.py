@@ -48,6 +48,7 @@ def test_mcts_mcts_like_a_reference_caller(m):
     before = board.copy()
     root = Node(None, None, player, len(_SZ[k + "actions"]))
     np.random.seed(1000 + m["case"])                               # the generator's seed: same Dirichlet draw
+    MCTS.cache.clear()                                             # the generator starts every case from an empty MCTS.cache
     count0 = MCTS.mcts_count
     MCTS.mcts(GpuFixtureModel(Game.action_dim, m["variant"]), board, root, Game, m["n_sims"], m["dirichlet"])
     assert np.array_equal(board, before)                           # board restored (mcts.py contract)
@@ -215,6 +216,8 @@ def test_network_self_play_like_a_seeded_reference_caller(gi):
         Gomoku.action_dim = Gomoku.state_dim = m["size"] ** 2
     Game = {"gomoku": Gomoku, "tictactoe": TicTacToe, "connect4": Connect4}[m["name"]]
     k = f"g{gi}_"
+    from ai import MCTS
+    MCTS.cache.clear()            # a different model from the previous test: the reference clears its global cache too (main.py:55)
     np.random.seed(m["seed"])
     out = Game().self_play(GpuFixtureModel(Game.action_dim, m["variant"]), m["n_sims"])
     if m["name"] == "gomoku":
@@ -238,3 +241,28 @@ def test_network_self_play_like_a_seeded_reference_caller(gi):
             rs.random_sample()
             ui += 1
     assert after == rs.random_sample()
+
+
+@pytest.mark.parametrize("ci", [0, 1, 2, 3])
+def test_compete_like_a_seeded_reference_caller(ci):
+    """arena.compete(Game, model1, model2, ...) = test.compete (test.py:60-105) on the global np.random stream and one shared
+    eval cache: the reference's recorded games (tests/golden/compete.npz) come out exactly - winner, final board, the
+    MCTS.mcts_count / MCTS.matched bookkeeping - including a vanilla (None) side."""
+    from ai import MCTS
+    from arena import compete
+    from games import Gomoku
+    z = load_golden("compete.npz")
+    m = golden_meta(z)[ci]
+    Gomoku.rows = Gomoku.cols = m["size"]
+    Gomoku.action_dim = Gomoku.state_dim = m["size"] ** 2
+    A = m["size"] ** 2
+    m1 = GpuFixtureModel(A, m["variant1"]) if m["variant1"] else None
+    m2 = GpuFixtureModel(A, m["variant2"]) if m["variant2"] else None
+    MCTS.cache.clear()
+    MCTS.matched = 0
+    MCTS.mcts_count = 0
+    np.random.seed(m["seed"])
+    winner, board = compete(Gomoku, m1, m2, m["iter1"], m["iter2"], sampling=m["sampling"])
+    assert winner == m["winner"]
+    assert np.array_equal((board[0] + 2 * board[1]).astype(np.int8).reshape(-1), z[f"c{ci}_final_cells"])
+    assert (MCTS.mcts_count, MCTS.matched) == (m["mcts_count"], m["matched"])
