@@ -83,10 +83,41 @@ def score_like_reference(winners_first_half, winners_second_half, iterations, ea
     return win_count[1] / iterations
 
 
+def compare_sequential(Game, best_model, contender_model, best_model_mcts_iter, contender_model_mcts_iter, iterations, sampling,
+                       early_stopping, winners_out=None):
+    """test.compare exactly as the reference runs it (test.py:107-140): the games one after the other through `compete` (global
+    np.random stream, MCTS.cache kept across the games and shared by both models), the models swap sides at half time, the
+    early-stopping rule is applied after every game (so it also decides how many games are played).  Returns 1 / 0 on an
+    early stop, else the contender's win rate.  `winners_out` (a list) receives each game's winner."""
+    win_count = [0, 0, 0]                                      # best model's, contender's, draws
+    for i in range(iterations):
+        first = i < iterations // 2
+        winner, _ = compete(Game, best_model if first else contender_model, contender_model if first else best_model,
+                            best_model_mcts_iter if first else contender_model_mcts_iter,
+                            contender_model_mcts_iter if first else best_model_mcts_iter, sampling=sampling)
+        if winners_out is not None:
+            winners_out.append(int(winner))
+        if winner == 0:
+            win_count[0 if first else 1] += 1
+        elif winner == 1:
+            win_count[1 if first else 0] += 1
+        else:
+            win_count[0] += 0.5
+            win_count[1] += 0.5
+            win_count[2] += 1
+        if early_stopping:
+            if win_count[1] >= int(iterations * 0.55):
+                return 1
+            if win_count[1] + (iterations - (i + 1)) < int(iterations * 0.55):
+                return 0
+    return win_count[1] / iterations
+
+
 def compare(game, best_model, contender_model, best_model_mcts_iter, contender_model_mcts_iter, iterations, sampling,
             early_stopping, size=None, seed=0, device=0, leaf_dtype="float32"):
     """test.compare(Game, best_model, contender_model, best_iter, contender_iter, iterations, sampling, early_stopping)
-    (test.py:107-140); a model of None plays vanilla MCTS (main.py:76)."""
+    (test.py:107-140) with all games of a half played at once; a model of None plays vanilla MCTS (main.py:76).
+    (compare_sequential is the game-by-game form that reproduces the reference's RNG stream and cache history.)"""
     game, size = _game_name(game, size)
     half = iterations // 2
     w1, _ = compete_batch(game, best_model, contender_model, half, best_model_mcts_iter, contender_model_mcts_iter,

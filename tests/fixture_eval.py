@@ -57,6 +57,9 @@ class FixtureModel:
     def __bool__(self):  # the reference tests `if model:`
         return True
 
+    def eval(self):      # test.compare calls model.eval() (test.py:108-111)
+        return self
+
 
 def numpy_softmax_like_reference(logits_f32):
     """The reference's softmax expression, verbatim semantics (ai/mcts.py:48-49):

@@ -436,6 +436,37 @@ def gen_compete():
                  winner=int(winner), n_moves=int((board[0] + board[1]).sum()), mcts_count=int(MCTS.mcts_count), matched=int(MCTS.matched))
         meta.append(m)
         print("compete", m)
+    # test.compare (test.py:107-140): a series of compete games, the models swap sides at half time, MCTS.cache is NOT cleared
+    # in between; recorded: the seed, the per-game winners (by wrapping compete) and the returned value
+    cmeta = []
+    cspecs = [(7, "hash", "uniform", 30, 20, 4, False, False, 31), (7, "uniform", "hash", 24, 24, 6, True, True, 32),
+              (7, None, "hash", 20, 20, 2, False, False, 33)]
+    for ki, (size, vb, vc, itb, itc, iters, sampling, early, seed) in enumerate(cspecs):
+        set_gomoku(size)
+        MCTS.cache.clear()
+        MCTS.matched = 0
+        MCTS.mcts_count = 0
+        mb = FixtureModel(GMK.action_dim, vb) if vb else None
+        mc_ = FixtureModel(GMK.action_dim, vc) if vc else None
+        winners = []
+        real_compete = ref_test.compete
+
+        def spy(*a, **k):
+            w, b = real_compete(*a, **k)
+            winners.append(int(w))
+            return w, b
+        ref_test.compete = spy
+        np.random.seed(seed)
+        try:
+            with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+                value = ref_test.compare(GMK, mb, mc_, itb, itc, iters, sampling, early)
+        finally:
+            ref_test.compete = real_compete
+        cm = dict(case=ki, size=size, best=vb, contender=vc, best_iter=itb, contender_iter=itc, iterations=iters, sampling=sampling,
+                  early_stopping=early, seed=seed, winners=winners, value=float(value), mcts_count=int(MCTS.mcts_count), matched=int(MCTS.matched))
+        cmeta.append(cm)
+        print("compare", cm)
+    out["compare_meta_json"] = np.frombuffer(json.dumps(cmeta).encode(), np.uint8)
     out["meta_json"] = np.frombuffer(json.dumps(meta).encode(), np.uint8)
     return out
 

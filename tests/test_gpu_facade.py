@@ -266,3 +266,31 @@ def test_compete_like_a_seeded_reference_caller(ci):
     assert winner == m["winner"]
     assert np.array_equal((board[0] + 2 * board[1]).astype(np.int8).reshape(-1), z[f"c{ci}_final_cells"])
     assert (MCTS.mcts_count, MCTS.matched) == (m["mcts_count"], m["matched"])
+
+
+@pytest.mark.parametrize("ki", [0, 1, 2])
+def test_compare_like_a_seeded_reference_caller(ki):
+    """arena.compare_sequential = test.compare (test.py:107-140): same games in the same order on the global np.random
+    stream with MCTS.cache kept across them - the reference's per-game winners, returned value (incl. an early stop) and
+    MCTS.mcts_count / MCTS.matched totals (tests/golden/compete.npz, produced by running test.compare)."""
+    import json
+    from ai import MCTS
+    from arena import compare_sequential
+    from games import Gomoku
+    z = load_golden("compete.npz")
+    m = json.loads(bytes(z["compare_meta_json"]).decode())[ki]
+    Gomoku.rows = Gomoku.cols = m["size"]
+    Gomoku.action_dim = Gomoku.state_dim = m["size"] ** 2
+    A = m["size"] ** 2
+    best = GpuFixtureModel(A, m["best"]) if m["best"] else None
+    cont = GpuFixtureModel(A, m["contender"]) if m["contender"] else None
+    MCTS.cache.clear()
+    MCTS.matched = 0
+    MCTS.mcts_count = 0
+    np.random.seed(m["seed"])
+    winners = []
+    value = compare_sequential(Gomoku, best, cont, m["best_iter"], m["contender_iter"], m["iterations"], m["sampling"],
+                               m["early_stopping"], winners_out=winners)
+    assert winners == m["winners"]
+    assert float(value) == m["value"]
+    assert (MCTS.mcts_count, MCTS.matched) == (m["mcts_count"], m["matched"])
