@@ -50,10 +50,21 @@ def save_data_to_buffer(Game, buffer, data):
                     buffer.add(fb, fp, target)
 
 
-def collect_data(Game, model, buffer, iterations, mcts_iter, display=False, seed=None):
-    """train.py:54-83: `iterations` self-play games of Game with `model` into `buffer`; returns [first, second, draw] counts."""
+def collect_data(Game, model, buffer, iterations, mcts_iter, display=False, seed=None, batched=True):
+    """train.py:54-83: `iterations` self-play games of Game with `model` into `buffer`; returns [first, second, draw] counts.
+    batched=False plays the games one after the other through Game().self_play and save_data_to_buffer exactly as the
+    reference does (global np.random stream: a seeded caller gets the reference's buffer); the default plays them as one
+    engine batch with the engine's own counter-based RNG."""
     from azk import DeviceReplay
     from selfplay import self_play_batch
+    if not batched:
+        results = [0, 0, 0]
+        for _ in range(iterations):
+            game = Game()
+            boards, actions, pis, qs, winner = game.self_play(model, mcts_iter, display)
+            results[2 if winner == -1 else winner] += 1
+            save_data_to_buffer(Game, buffer, (boards, actions, pis, qs, winner, 0 if winner == -1 else 1))
+        return results
     if seed is None:
         seed = int(np.random.randint(0, 2 ** 31 - 1))
     on_device = isinstance(buffer, DeviceReplay)

@@ -294,3 +294,37 @@ def test_compare_like_a_seeded_reference_caller(ki):
     assert winners == m["winners"]
     assert float(value) == m["value"]
     assert (MCTS.mcts_count, MCTS.matched) == (m["mcts_count"], m["matched"])
+
+
+def test_collect_data_like_a_seeded_reference_caller():
+    """train.collect_data(..., batched=False): Game().self_play + save_data_to_buffer game by game on the global stream - the
+    buffer of a seeded call is the reference's (sha256 recorded from the reference's ReplayBuffer, games.npz)."""
+    import hashlib, struct
+    import train as az_train
+    from ai import MCTS
+    from games import Gomoku
+    z = load_golden("games.npz")
+    m = next(x for x in golden_meta(z) if x["game"] == 0)
+    Gomoku.rows = Gomoku.cols = m["size"]
+    Gomoku.action_dim = Gomoku.state_dim = m["size"] ** 2
+
+    class HostBuffer:
+        def __init__(self):
+            self.buffer = []
+
+        def add(self, s, p, r):
+            self.buffer.append((np.array(s, np.float32), np.array(p, np.float64), list(r)))
+
+        def size(self):
+            return len(self.buffer)
+    buf = HostBuffer()
+    MCTS.cache.clear()
+    np.random.seed(m["seed"])
+    res = az_train.collect_data(Gomoku, GpuFixtureModel(49, m["variant"]), buf, 1, m["n_sims"], batched=False)
+    assert sum(res) == 1 and res[m["winner"] if m["winner"] >= 0 else 2] == 1
+    h = hashlib.sha256()
+    for s, p, zz in buf.buffer:
+        h.update(np.ascontiguousarray(s, np.float32).tobytes())
+        h.update(np.ascontiguousarray(p, np.float64).tobytes())
+        h.update(struct.pack("<d", float(zz[0])))
+    assert buf.size() == m["buffer_len"] and h.hexdigest() == m["buffer_digest"]
