@@ -273,8 +273,8 @@ class Engine:
         self._chk(self.L.azk_recycle_finished(self.h, _p(stats), _stream()))
 
     def emit_finished(self, replay):
-        """Append the (state, pi, z) tuples of every just-finished game to a DeviceReplay; returns int32 [G] first indices."""
-        base = self.torch.empty(self.G, dtype=self.torch.int32, device=self.device)
+        """Append the (state, pi, z) tuples of every just-finished game to a DeviceReplay; returns int64 [G] first indices (-1: not emitted)."""
+        base = self.torch.empty(self.G, dtype=self.torch.int64, device=self.device)
         self._chk(self.L.azk_emit_finished(self.h, _p(replay.states), _p(replay.pis), _p(replay.zs), replay.capacity,
                                            _p(replay.cursor), _p(base), _stream()))
         return base
@@ -569,6 +569,20 @@ def nn_embed_pool_leaves(src, wt_ext, cpos_frag, score_frag, score_msum, score_r
     return z
 
 
+class _ReplayUnpickler(__import__("pickle").Unpickler):
+    """pickle.Unpickler limited to the globals of replay_buffer.py's file format (replay_buffer.py:37-65)."""
+    _ALLOWED = {("collections", "deque"), ("numpy", "ndarray"), ("numpy", "dtype"),
+                ("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"),
+                ("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar"),
+                ("numpy.core.numeric", "_frombuffer"), ("numpy._core.numeric", "_frombuffer")}
+
+    def find_class(self, module, name):
+        if (module, name) in self._ALLOWED:
+            return super().find_class(module, name)
+        import pickle
+        raise pickle.UnpicklingError(f"replay file refers to {module}.{name}: not part of the replay format, refused")
+
+
 class DeviceReplay:
     """HBM-resident ring of (state, pi, z) tuples: the device form of replay_buffer.ReplayBuffer (deque(maxlen),
     replay_buffer.py:7-13).  Filled by Engine.emit_finished; `sample` draws uniformly without replacement
@@ -588,6 +602,8 @@ class DeviceReplay:
 
     def sample(self, batch_size):
         n = self.size()
+        if batch_size > n:          # np.random.choice(len, batch_size, replace=False) raises the same way (replay_buffer.py:16)
+            raise ValueError(f"cannot sample {batch_size} tuples without replacement from a ring holding {n}")
         idx = self.torch.randperm(n, device=self.states.device)[:batch_size]
         return self.states[idx], self.pis[idx].float(), self.zs[idx][:, None]
 
@@ -620,11 +636,11 @@ class DeviceReplay:
             pickle.dump(self.to_reference_deque(), fh)
 
     def load_pickle(self, filename):
-        """Refill the ring from a file in that format (one this class or the reference's ReplayBuffer wrote).  pickle executes
-        what the file says: only load files you produced."""
-        import pickle
+        """Refill the ring from a file in that format (one this class or the reference's ReplayBuffer wrote).  The file is
+        read by a restricted unpickler that can only build what the format holds - a deque of (ndarray, ndarray, list of
+        float) - and refuses every other global, so a crafted file cannot run code."""
         with open(filename, "rb") as fh:
-            items = list(pickle.load(fh))[-self.capacity:]
+            items = list(_ReplayUnpickler(fh).load())[-self.capacity:]
         self.cursor.zero_()
         if items:
             torch = self.torch

@@ -50,7 +50,7 @@ struct Dev {               // device view of the engine, passed to kernels by va
     int *leaf_cache;                       // [G] >= 0: pending leaf was a cache hit (entry index); < 0: miss, insert at -(x)-1
     int16_t *traj_action;  // [G][state_dim] cell played at each ply of the current game (square boards only, else null)
     double *traj_pi;       // [G][state_dim][A] visit distribution recorded at each ply
-    int *emit_base;        // [G] first tuple index of a game being emitted
+    long long *emit_base;  // [G] first tuple index (64-bit: the stream never wraps) of a game being emitted, -1 = not emitting
     long long *counters;   // [CNT_N][G]
     int *err;              // sticky error word
     int ablate;            // debug only (AZK_TREE_ABLATE): timing experiments that break parity on purpose
@@ -839,14 +839,14 @@ __global__ __launch_bounds__(AZK_WAVE) void k_advance(Dev d, const double *unifo
 // positions 0 and 1 once, the others 8 times in the order rot0, lr(rot0), tb(rot0), rot90, lr(rot90), tb(rot90),
 // rot180, rot270 (np.rot90 is counter-clockwise).  Tuple t of the stream lands in slot t % capacity (deque(maxlen)).
 // ------------------------------------------------------------------------------------------------
-__global__ void k_emit_alloc(Dev d, unsigned long long *cursor, int *game_base_out) {
+__global__ void k_emit_alloc(Dev d, unsigned long long *cursor, long long *game_base_out) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= d.G) return;
-    int base = -1;
+    long long base = -1;                                          // the stream index stays 64-bit end to end (2^31 tuples = hours of self-play)
     if (d.done[g] == 1) {
         const int n = d.move_count[g];
         const int tuples = n <= 2 ? n : 2 + 8 * (n - 2);
-        base = (int)atomicAdd(cursor, (unsigned long long)tuples);
+        base = (long long)atomicAdd(cursor, (unsigned long long)tuples);
     }
     d.emit_base[g] = base;
     if (game_base_out) game_base_out[g] = base;
@@ -872,7 +872,7 @@ __global__ __launch_bounds__(AZK_WAVE) void k_emit_tuples(Dev d, float *states, 
                                                             const unsigned long long *cursor) {
     const int S = d.g.state_dim, A = d.g.action_dim, rc = d.g.rc, F = d.g.planes, N = d.g.rows;
     const int g = blockIdx.x / S, i = blockIdx.x - g * S, lane = azk_lane();
-    const int base = d.emit_base[g];
+    const long long base = d.emit_base[g];
     if (base < 0 || i >= d.move_count[g]) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
     uint8_t *cells = sm;                                          // board before ply i
@@ -885,7 +885,7 @@ __global__ __launch_bounds__(AZK_WAVE) void k_emit_tuples(Dev d, float *states, 
     const float z = winner == -1 ? 0.0f : (side == winner ? 1.0f : -1.0f);
     const double *pi = d.traj_pi + ((size_t)g * S + i) * A;
     const int ntr = i < 2 ? 1 : 8;
-    const long long first = (long long)base + (i < 2 ? i : 2 + 8 * (i - 2));
+    const long long first = base + (i < 2 ? i : 2 + 8 * (i - 2));
     const long long stream_end = (long long)*cursor;              // after k_emit_alloc: one past the newest tuple of this call
     for (int t = 0; t < ntr; t++) {
         if (first + t < stream_end - capacity) continue;          // already pushed out of the ring by newer tuples (deque(maxlen))
@@ -1352,12 +1352,12 @@ int32_t azk_leaf_source_of(azk_engine *e, int32_t *n_leaf_dev, azk_leaf_source *
 }
 
 int32_t azk_emit_finished(azk_engine *e, float *states_dev, double *pis_dev, float *zs_dev, int64_t capacity,
-                          int64_t *cursor_dev, int32_t *game_base_dev, void *stream) {
+                          int64_t *cursor_dev, int64_t *game_base_dev, void *stream) {
     if (!e || !states_dev || !pis_dev || !zs_dev || !cursor_dev || capacity < 1) return AZK_ERR_ARG;
     const Dev &d = e->d;
     if (!d.traj_pi) { e->err = "azk_emit_finished: (state, pi, z) emission needs a square board with one action per cell"; return AZK_ERR_ARG; }
     hipStream_t st = (hipStream_t)stream;
-    k_emit_alloc<<<(unsigned)((d.G + 255) / 256), 256, 0, st>>>(d, (unsigned long long *)cursor_dev, game_base_dev);
+    k_emit_alloc<<<(unsigned)((d.G + 255) / 256), 256, 0, st>>>(d, (unsigned long long *)cursor_dev, (long long *)game_base_dev);
     k_emit_tuples<<<(unsigned)(d.G * d.g.state_dim), AZK_WAVE, up16(d.g.rc), st>>>(d, states_dev, pis_dev, zs_dev, (long long)capacity,
                                                                                   (const unsigned long long *)cursor_dev);
     k_emit_mark<<<(unsigned)((d.G + 255) / 256), 256, 0, st>>>(d);

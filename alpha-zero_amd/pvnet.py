@@ -25,9 +25,10 @@ import torch.nn.functional as F
 
 
 class NetConfig:
-    def __init__(self, rows, cols, channels, action_dim, patch_size=5, embed_dim=512, num_heads=8, depth=1):
+    def __init__(self, rows, cols, channels, action_dim, patch_size=5, embed_dim=512, num_heads=8, depth=1, dropout=0.0):
         self.rows, self.cols, self.channels, self.action_dim = rows, cols, channels, action_dim
         self.patch_size, self.embed_dim, self.num_heads, self.depth = patch_size, embed_dim, num_heads, depth
+        self.dropout = dropout      # Net(..., dropout=) of nn.py:64: active in training mode only (train.py:92), never in self-play
 
     @property
     def tokens(self):
@@ -392,7 +393,11 @@ class PolicyValueNet:
     def _ln(self, x, name):
         return F.layer_norm(x, (self.cfg.embed_dim,), self.w[name + ".weight"], self.w[name + ".bias"], 1e-5)
 
-    def block_full(self, x, i):
+    def block_full(self, x, i, dropout_p=0.0):
+        """nn.py:52-61.  dropout_p > 0 is the block in model.train() mode: the three dropouts of the reference block in
+        its order and on tensors of its shapes - attention probabilities [n*H, T, T] (nn.MultiheadAttention's need_weights
+        path: softmax -> dropout -> bmm), after GELU [n, T, 4D], after mlp.3 [n, T, D] - so that on the CPU a caller
+        seeded like the reference draws the reference's masks (tests/test_trainer.py)."""
         w, cfg = self.w, self.cfg
         b = f"blocks.{i}."
         n, T, D = x.shape
@@ -400,11 +405,23 @@ class PolicyValueNet:
         h = self._ln(x, b + "norm1")
         qkv = F.linear(h, w[b + "attn.in_proj_weight"], w[b + "attn.in_proj_bias"])
         q, k, v = qkv.view(n, T, 3, H, D // H).permute(2, 0, 3, 1, 4)
-        a = F.scaled_dot_product_attention(q, k, v)                            # softmax(q k^T / sqrt(d)) v
+        if dropout_p > 0.0:
+            dh = D // H
+            qs = (q * math.sqrt(1.0 / float(dh))).reshape(n * H, T, dh)
+            aw = torch.softmax(torch.bmm(qs, k.reshape(n * H, T, dh).transpose(1, 2)), dim=-1)
+            aw = F.dropout(aw, dropout_p, training=True)
+            a = torch.bmm(aw, v.reshape(n * H, T, dh)).view(n, H, T, dh)
+        else:
+            a = F.scaled_dot_product_attention(q, k, v)                        # softmax(q k^T / sqrt(d)) v
         a = a.transpose(1, 2).reshape(n, T, D)
         x = x + F.linear(a, w[b + "attn.out_proj.weight"], w[b + "attn.out_proj.bias"])   # nn.py:54-56
         h = self._ln(x, b + "norm2")
-        h = F.linear(F.gelu(F.linear(h, w[b + "mlp.0.weight"], w[b + "mlp.0.bias"])), w[b + "mlp.3.weight"], w[b + "mlp.3.bias"])
+        h = F.gelu(F.linear(h, w[b + "mlp.0.weight"], w[b + "mlp.0.bias"]))
+        if dropout_p > 0.0:
+            h = F.dropout(h, dropout_p, training=True)
+        h = F.linear(h, w[b + "mlp.3.weight"], w[b + "mlp.3.bias"])
+        if dropout_p > 0.0:
+            h = F.dropout(h, dropout_p, training=True)
         return x + h                                                           # nn.py:59-60
 
     def block_cls(self, x, i, h=None, x0=None):
@@ -460,9 +477,12 @@ class PolicyValueNet:
     def forward(self, x, path=None):
         return self.forward_impl(x, path)
 
-    def forward_impl(self, x, path=None):
-        """The forward without the no_grad guard (the training step differentiates the plain 'full' path)."""
+    def forward_impl(self, x, path=None, dropout_p=0.0):
+        """The forward without the no_grad guard (the training step differentiates the plain 'full' path; dropout_p > 0 =
+        model.train() mode of a Net built with dropout, 'full' path only)."""
         path = path or self.path
+        if dropout_p > 0.0 and path != "full":
+            raise ValueError("training-mode dropout runs on the 'full' path only")
         x = x.to(self.device)
         self.last_value_pre_tanh = False     # set by the one path that hands back the raw value column (fast_outputs)
         depth = self.cfg.depth
@@ -509,7 +529,7 @@ class PolicyValueNet:
         x = self.embed(x)
         if path == "full":
             for i in range(depth):
-                x = self.block_full(x, i)
+                x = self.block_full(x, i, dropout_p)
             x0 = x[:, 0]
         elif path == "cls":
             for i in range(depth - 1):

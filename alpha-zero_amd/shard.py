@@ -33,3 +33,15 @@ def reduce_measurement(elapsed_s, work, dist=None, device=None):
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dist.all_reduce(w, op=dist.ReduceOp.SUM)
     return float(t[0]), [float(x) for x in w]
+
+
+def agree_min(value, dist=None, device=None):
+    """The smallest `value` over the ranks (an integer every rank then uses to decide how many collective-bearing steps
+    to run).  A quantity that depends on a rank's own games - its replay fill, its number of finished games - must never
+    decide the NUMBER of collectives a rank issues: ranks that disagree deadlock in RCCL.  One tiny all-reduce(MIN)."""
+    import torch
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return int(value)
+    t = torch.tensor([int(value)], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return int(t[0])

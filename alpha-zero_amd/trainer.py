@@ -19,22 +19,23 @@ from pvnet import PolicyValueNet, reference_key_shapes
 
 
 class Trainer:
-    def __init__(self, cfg, weights, device="cpu", dropout=0.0):
-        self.cfg, self.device, self.dropout = cfg, torch.device(device), dropout
+    def __init__(self, cfg, weights, device="cpu", dropout=None):
+        # dropout: Net(..., dropout=) of the reference (main.py:134 trains with 0.1 under model.train(), train.py:92);
+        # default = the configuration's own value
+        self.cfg, self.device = cfg, torch.device(device)
+        self.dropout = float(getattr(cfg, "dropout", 0.0) if dropout is None else dropout)
         order = list(reference_key_shapes(cfg))                       # == named_parameters() order of the reference Net
         self.params = {k: torch.nn.Parameter(torch.as_tensor(weights[k]).detach().to(self.device, torch.float32).clone())
                        for k in order}
         self.net = PolicyValueNet(cfg, weights={k: v.detach().cpu() for k, v in self.params.items()}, device="cpu",
                                   dtype=torch.float32, path="full")
         self.net.device, self.net.w = self.device, self.params        # the forward reads these tensors directly
-        if dropout:
-            raise NotImplementedError("dropout > 0 follows torch's RNG stream inside nn.MultiheadAttention; train with 0")
 
     def state_dict(self):
         return {k: v.detach().cpu().clone() for k, v in self.params.items()}
 
     def loss_terms(self, states, pis, rewards):
-        logits, values = self.net.forward_impl(states.to(self.device, torch.float32), "full")
+        logits, values = self.net.forward_impl(states.to(self.device, torch.float32), "full", dropout_p=self.dropout)
         l2 = 0.0
         for name, p in self.params.items():                           # train.py:101-108
             if "bias" in name or "LayerNorm" in name:

@@ -10,9 +10,17 @@ games per GPU, policy-value net = the reference's training config (ai/nn.py Net(
 A STEP is one move of the whole resident batch: 2048 searches x 800 simulations (tree kernels + leaf
 compaction + network evaluation + expansion/backup), move selection, state advance, the per-move records
 (board, pi, q, action) copied to the host, and finished games restarted (continuous self-play).
-value = self-play games/sec = games COMPLETED inside the timed region / seconds.  All games start in phase, so the
-default warm-up (40 moves, about two game lengths) lets the phases decorrelate before timing; the renewal estimate
-(plies per second / mean game length) is reported next to it and is used only when the window is too short to count.
+value = self-play games/sec = games COMPLETED inside the timed region / seconds.  All slots start in phase (empty
+boards), and a completion count is only meaningful for a stationary process, so an UNTIMED pre-roll that does not depend
+on --warmup de-phases the slots first: `--preroll-cheap` moves at `--preroll-sims` simulations (cheap: scrambles the
+ages of the games) and then `--preroll-full` moves at the full simulation count (one mean game length: the games alive
+when timing starts were played under the benchmark's own search).  After that the completion rate does not depend on
+the window (--steps 20 --warmup 5 and --steps 40 --warmup 40 agree within noise) and the lengths of the games that
+complete in the window are an unbiased sample, so the renewal estimate (plies / mean length / s) printed next to the
+value agrees with it.
+
+`python bench.py --gpus N` started WITHOUT torch.distributed.run spawns its N ranks itself (children, before any GPU
+call); a world size that disagrees with --gpus is an error (non-zero exit), never a silent one-GPU run.
 
 One JSON line on rank 0.  Extra objects:
   roofline      k_tree (PUCT scan + expand + backup), HBM-bound: algorithmic bytes per launch from the engine's
@@ -45,16 +53,21 @@ def algorithmic_bytes(c, action_dim):
             + c["leaves_evaluated"] * (4 * action_dim + action_dim) + 8 * c["trace_nodes"])
 
 
-def cpu_baseline(n_sims, budget_s, mean_plies):
-    """The oracle (kind 'port'): sequential search in C, batch-1 float32 ViT through PyTorch CPU, eval cache on,
-    numpy softmax - the reference's algorithm and evaluator shape.  Bounded by wall-clock."""
+# the reference itself (pure Python + batch-1 fp32 torch), timed at survey time in the build container:
+# it cannot travel to the GPU box, so it is quoted, not re-measured
+REFERENCE_PYTHON = {"games_per_sec": 0.0157, "sims_per_sec": 340.0, "seconds_per_game": 63.6,
+                    "hardware": "8 vCPU Intel Xeon 2.10 GHz (build container), 8 torch intra-op threads",
+                    "source": "BASELINE.md section 2: Gomoku 15x15, 800 sims/move, one 27-move game, seed 0; survey-time measurement, not this box"}
+
+
+def cpu_port_sample(n_sims, budget_s, threads):
+    """One bounded sample of the oracle (kind 'port'): sequential search in C, batch-1 float32 ViT through PyTorch CPU,
+    eval cache on, numpy softmax - the reference's algorithm and evaluator shape.  Returns (sims, evals, hits, moves, seconds)."""
     import numpy as np
     import torch
     from oracle import az_oracle as ao
     from pvnet import NetConfig, PolicyValueNet
-    # batch-1 evaluation does not scale past a few threads (128 threads measured 45-64 sims/s on this class of
-    # host, 8 threads several times that); 8 is also what the survey's reference measurement used
-    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    torch.set_num_threads(threads)
     cfg = NetConfig(15, 15, 2, 225, 5, 512, 8, 1)
     net = PolicyValueNet(cfg, seed=0, device="cpu", dtype=torch.float32, path="full")
     game = ao.OracleGame("gomoku", 15)
@@ -69,20 +82,101 @@ def cpu_baseline(n_sims, budget_s, mean_plies):
     t0 = time.time()
     out = ao.self_play(game, ev, n_sims, noise_fn=lambda mc: rng.dirichlet([0.03] * 225),
                        uniform_fn=lambda mc: rng.random_sample(), cache=cache, counters=cnt, time_budget=budget_s)
-    dt = time.time() - t0
-    sims_per_s = cnt.mcts_count / dt
+    return cnt.mcts_count, cnt.evals, cnt.matched, len(out["cells"]), time.time() - t0
+
+
+def cpu_baseline(n_sims, budget_s, mean_plies):
+    """cpu_baseline object of the JSON line.  Two legs on this box's host cores, each a bounded sample of the same workload:
+    (1) one process, 8 intra-op threads (batch-1 evaluation does not scale past a few threads; 8 is what the survey's
+    reference measurement used) - the headline `value`; (2) one single-threaded process per core of this box's CPU share
+    (16 per GPU), the 'all host cores' figure of SURVEY 8(d).  games/s = sims/s / (sims per move x mean plies per game),
+    with the same mean game length the GPU line reports."""
+    import subprocess
+    import torch
+    threads = min(8, os.cpu_count() or 1)
+    sims, evals, hits, moves, dt = cpu_port_sample(n_sims, budget_s * 0.5, threads)
+    sims_per_s = sims / dt
     games_per_s = sims_per_s / (n_sims * mean_plies)
-    return {"value": games_per_s, "unit": "games/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sims_per_sec": sims_per_s, "host_cpus": os.cpu_count(),
-            "sample": f"first {len(out['cells'])} moves of one Gomoku 15x15 game, {n_sims} sims/move: {cnt.mcts_count} sims "
-                      f"({cnt.evals} net evals, {cnt.matched} cache hits) in {dt:.1f} s; games/s = sims/s / ({n_sims} x {mean_plies:.1f} plies)"}
+    out = {"value": games_per_s, "unit": "games/s", "cores": threads, "kind": "port",
+           "sims_per_sec": sims_per_s, "host_cpus": os.cpu_count(),
+           "sample": f"first {moves} moves of one Gomoku 15x15 game, {n_sims} sims/move: {sims} sims "
+                     f"({evals} net evals, {hits} cache hits) in {dt:.1f} s; games/s = sims/s / ({n_sims} x {mean_plies:.1f} plies)",
+           "reference_python": REFERENCE_PYTHON}
+    # leg 2: independent single-threaded processes, one per core of the CPU share; children never touch the GPU
+    nproc = min(16, os.cpu_count() or 1)
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="-1", ROCR_VISIBLE_DEVICES="-1", OMP_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", str(budget_s * 0.5), "--sims", str(n_sims)]
+    t0 = time.time()
+    procs = [subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for _ in range(nproc)]
+    tot, ok = 0.0, 0
+    for pr in procs:
+        try:
+            so, _ = pr.communicate(timeout=budget_s * 0.5 + 240)
+            r = json.loads(so.strip().splitlines()[-1])
+            tot += r["sims"] / r["seconds"]
+            ok += 1
+        except Exception:
+            pr.kill()
+    out["all_cores"] = {"processes": ok, "threads_per_process": 1, "sims_per_sec": tot, "games_per_sec": tot / (n_sims * mean_plies),
+                        "wall_s": time.time() - t0,
+                        "note": "independent games, one single-threaded process per core of this box's CPU share (16 per GPU); summed"}
+    return out
+
+
+class StubRunner:
+    """Engine-shaped stand-in (launcher / reduction tests on hosts without a GPU, `--stub-engine`): the SelfPlayRunner
+    surface bench.py uses, with deterministic per-rank work.  Its JSON line says data = "stub"; it measures nothing."""
+
+    def __init__(self, games, sims, first_global_game):
+        self.G, self.n_sims, self.first, self.n_split = games, sims, first_global_game, 1
+        self.plies_played = self.games_finished = self.finished_plies = self.move_idx = 0
+        self._c = {"sims": 0, "edges_scanned": 0, "trace_nodes": 0, "edges_created": 0, "leaves_evaluated": 0, "cache_hits": 0}
+
+    def play_move(self):
+        self.move_idx += 1
+        self.plies_played += self.G
+        fin = (self.first + self.move_idx) % 7 + 1            # depends on the shard: ranks report different work
+        self.games_finished += fin
+        self.finished_plies += 20 * fin
+        self._c["sims"] += self.G * self.n_sims
+        self._c["leaves_evaluated"] += self.G * self.n_sims // 2
+
+    def counters(self):
+        return dict(self._c)
+
+    def reset_counters(self):
+        self._c = {k: 0 for k in self._c}
+
+    def check_error(self):
+        pass
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks as a child job (the driver's own
+    command line) before this process has touched the GPU, and exit with its code."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(cmd, env=env)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--preroll-cheap", type=int, default=128, help="untimed de-phasing moves at --preroll-sims simulations")
+    ap.add_argument("--preroll-sims", type=int, default=16)
+    ap.add_argument("--preroll-full", type=int, default=26, help="untimed moves at the full simulation count after the cheap pre-roll")
+    ap.add_argument("--stub-engine", action="store_true", help="TEST ONLY: gloo on the CPU with a stub runner (launcher / reduction tests)")
+    ap.add_argument("--cpu-worker", type=float, default=0.0, help="internal: one single-threaded CPU-baseline sample of this many seconds")
     ap.add_argument("--games", type=int, default=2048, help="concurrent games per GPU")
     ap.add_argument("--sims", type=int, default=800)
     ap.add_argument("--size", type=int, default=15)
@@ -97,52 +191,92 @@ def main():
                          "all-reduced over RCCL) after every move, fed from the device-resident replay ring")
     args = ap.parse_args()
 
+    if args.cpu_worker > 0:              # child of cpu_baseline's all-cores leg: CPU only, prints one JSON line
+        sims, evals, hits, moves, dt = cpu_port_sample(args.sims, args.cpu_worker, 1)
+        print(json.dumps({"sims": sims, "evals": evals, "hits": hits, "moves": moves, "seconds": dt}))
+        return 0
+
+    from shard import agree_min, env_world, shard_range
+    rank, local_rank, world = env_world()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return spawn_ranks(args.gpus, sys.argv[1:])             # children; this process never touches the GPU
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a {world}-rank run as {args.gpus} GPUs", file=sys.stderr)
+        return 2
+
     import torch
     import torch.distributed as dist
-    from shard import env_world, shard_range
-    rank, local_rank, world = env_world()
+    stub = args.stub_engine
+    if not stub and torch.cuda.device_count() < max(1, local_rank + 1):
+        print(f"bench.py: rank {rank} needs cuda:{local_rank} but {torch.cuda.device_count()} GPU(s) are visible", file=sys.stderr)
+        return 3
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    torch.cuda.set_device(local_rank)
+        if stub:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     torch.set_num_threads(min(8, os.cpu_count() or 1))       # the host only launches kernels; N ranks must not each spawn 128 threads
+    rdev = "cpu" if stub else "cuda"
 
-    from pvnet import NetConfig, PolicyValueNet
-    from selfplay import KernelTimer, SelfPlayRunner
+    from pvnet import NetConfig
     A = args.size * args.size
     cfg = NetConfig(args.size, args.size, 2, A, 5, 512, 8, 1)
-    net = PolicyValueNet(cfg, seed=0, device=f"cuda:{local_rank}", dtype=torch.bfloat16, path=args.nn_path)
-    kt = KernelTimer(stride=16)
     replay = trainer = None
-    if args.train_step:
-        from azk import DeviceReplay
-        from trainer import Trainer
-        replay = DeviceReplay(400000, cfg.channels, cfg.rows, cfg.cols, cfg.action_dim, device=torch.device("cuda", local_rank))
-        trainer = Trainer(cfg, net.state_dict(), device=f"cuda:{local_rank}")
-    runner = SelfPlayRunner("gomoku", net, args.games, args.sims, size=args.size, seed=args.seed,
-                            first_global_game=shard_range(args.games, rank)[0], device=local_rank, leaf_dtype="bfloat16",
-                            recycle=True, kernel_timer=kt, use_graph=not args.no_graph, n_split=args.split, cache_entries=args.cache_entries,
-                            replay=replay)
     train_ms = []
+    if stub:
+        class _NoTimer:
+            enabled, pairs, children = False, [], {}
+
+            def mean_ms(self):
+                return None
+        kt, net = _NoTimer(), None
+        runner = StubRunner(args.games, args.sims, shard_range(args.games, rank)[0])
+    else:
+        torch.cuda.set_device(local_rank)
+        from pvnet import PolicyValueNet
+        from selfplay import KernelTimer, SelfPlayRunner
+        net = PolicyValueNet(cfg, seed=0, device=f"cuda:{local_rank}", dtype=torch.bfloat16, path=args.nn_path)
+        kt = KernelTimer(stride=16)
+        if args.train_step:
+            from azk import DeviceReplay
+            from trainer import Trainer
+            replay = DeviceReplay(400000, cfg.channels, cfg.rows, cfg.cols, cfg.action_dim, device=torch.device("cuda", local_rank))
+            trainer = Trainer(cfg, net.state_dict(), device=f"cuda:{local_rank}", dropout=0.1)      # main.py:134 trains with dropout 0.1
+        runner = SelfPlayRunner("gomoku", net, args.games, args.sims, size=args.size, seed=args.seed,
+                                first_global_game=shard_range(args.games, rank)[0], device=local_rank, leaf_dtype="bfloat16",
+                                recycle=True, kernel_timer=kt, use_graph=not args.no_graph, n_split=args.split, cache_entries=args.cache_entries,
+                                replay=replay)
 
     def train_one():
-        """train.train with one iteration (train.py:85-123): fresh Adam, the reference's loss, gradient bucket all-reduce."""
-        if replay.size() < 512:
+        """train.train with one iteration (train.py:85-123): fresh Adam, the reference's loss, gradient bucket all-reduce.
+        Whether a step runs is agreed by ALL ranks (MIN of 'my ring holds a batch'): the step carries an all-reduce, and a
+        rank's replay fill depends on its own game lengths."""
+        if not agree_min(1 if replay.size() >= 512 else 0, dist if world > 1 else None, rdev):
             return
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         trainer.train([replay.sample(512)], 0.00025, dist=dist if world > 1 else None)
         b.record()
         train_ms.append((a, b))
-    eng = runner.eng
 
     def sync_all():
-        torch.cuda.synchronize()
+        if not stub:
+            torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-            torch.cuda.synchronize()
+            if not stub:
+                torch.cuda.synchronize()
 
+    # ---- untimed pre-roll (always, whatever --warmup says): de-phase the slots, then one game length under the real search ----
+    if args.preroll_cheap > 0:
+        full = runner.n_sims
+        runner.n_sims = min(full, max(8, args.preroll_sims))
+        for _ in range(args.preroll_cheap):
+            runner.play_move()
+        runner.n_sims = full
+    for _ in range(args.preroll_full):
+        runner.play_move()
     for _ in range(args.warmup):
         runner.play_move()
         if args.train_step:
@@ -167,19 +301,25 @@ def main():
 
     # max time / summed work over ranks (the only collectives: measurement, never the generation path)
     from shard import reduce_measurement
-    dt_max, (plies_all, fin_window, fin_all, finp_all, sims_all, leaves_all) = reduce_measurement(
-        dt, [plies, fin - fin0, fin, finp, c["sims"], c["leaves_evaluated"]], dist if world > 1 else None, "cuda")
+    dt_max, (plies_all, fin_window, finp_window, sims_all, leaves_all) = reduce_measurement(
+        dt, [plies, fin - fin0, finp - finp0, c["sims"], c["leaves_evaluated"]], dist if world > 1 else None, rdev)
 
     if rank == 0:
-        if fin_all > 0:
-            mean_plies, src = finp_all / fin_all, f"{int(fin_all)} games finished in this run"
+        # after the pre-roll the process is stationary: the games that COMPLETE in the window are an unbiased sample of the
+        # game-length distribution (it is the games ALIVE at an instant that are length-biased, not the ones ending in a window)
+        if fin_window > 0:
+            mean_plies, src = finp_window / fin_window, f"{int(fin_window)} games completed inside the timed window"
         else:
-            mean_plies, src = 30.0, "no game finished in this run: assumed 30 plies"
+            mean_plies, src = 26.0, "no game completed in the window: assumed 26 plies"
         est_games_per_s = plies_all / mean_plies / dt_max          # renewal estimate: plies per second / mean game length
-        if fin_window >= 0.25 * args.games * world:
-            games_per_s, value_src = fin_window / dt_max, "games completed inside the timed window / seconds"
-        else:   # window too short for completions to be meaningful (all games start in phase): fall back to the estimate
-            games_per_s, value_src = est_games_per_s, "plies in window / mean plies per finished game / seconds (window too short for a direct count)" 
+        games_per_s, value_src = fin_window / dt_max, "games completed inside the timed window / seconds (slots de-phased by the untimed pre-roll)"
+        if stub:
+            print(json.dumps({"metric": "selfplay_games_per_sec", "value": games_per_s, "unit": "games/s", "n_gpus": world, "steps": args.steps,
+                              "warmup": args.warmup, "ms_per_step": dt_max / args.steps * 1e3, "data": "stub", "sims_per_sec": sims_all / dt_max,
+                              "games_finished_in_window": fin_window, "plies_in_window": plies_all}))
+            if world > 1:
+                dist.destroy_process_group()
+            return 0
         tree_ms = kt.mean_ms()
         launches = args.steps * args.sims * runner.n_split      # k_tree launches (one per game group per simulation)
         alg_bytes = algorithmic_bytes(c, A) / launches
@@ -242,6 +382,8 @@ def main():
         out = {
             "metric": "selfplay_games_per_sec", "value": games_per_s, "unit": "games/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt_max / args.steps * 1e3,
+            "preroll": {"cheap_moves": args.preroll_cheap, "cheap_sims": args.preroll_sims, "full_moves": args.preroll_full,
+                        "note": "untimed, independent of --warmup: de-phases the slots so the completion count is window-independent"},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"Gomoku {args.size}x{args.size}, {args.sims} sims/move, {args.games} concurrent self-play games per GPU "
                                    f"(BASELINE.json configs[2]), continuous self-play", "games_per_gpu": args.games,
@@ -269,7 +411,8 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

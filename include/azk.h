@@ -129,10 +129,10 @@ int32_t azk_recycle_finished(azk_engine *e, int64_t *stats_dev, void *stream);
  * azk_advance, z = +1 / -1 / 0; positions 0 and 1 once, the rest 8 times in the reference's order (rot0, lr, tb, rot90,
  * lr, tb, rot180, rot270).  The engine appends at *cursor_dev (uint64, monotonically increasing) and writes tuple t to
  * slot t % capacity of the caller's ring buffers - the device-resident form of ReplayBuffer's deque(maxlen)
- * (replay_buffer.py:7-13).  game_base_dev (optional, int32 [G]) receives each emitted game's first tuple index, -1 for
+ * (replay_buffer.py:7-13).  game_base_dev (optional, int64 [G]) receives each emitted game's first tuple index, -1 for
  * the others.  Square boards with one action per cell only (Gomoku, TicTacToe); others return AZK_ERR_ARG. */
 int32_t azk_emit_finished(azk_engine *e, float *states_dev, double *pis_dev, float *zs_dev, int64_t capacity,
-                          int64_t *cursor_dev, int32_t *game_base_dev, void *stream);
+                          int64_t *cursor_dev, int64_t *game_base_dev, void *stream);
 
 /* MCTS.cache.clear() (main.py:55-57): must be called whenever the evaluator's weights change. */
 int32_t azk_clear_cache(azk_engine *e, void *stream);

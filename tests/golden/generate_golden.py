@@ -518,12 +518,14 @@ def gen_nn_small():
 # =================================================================================
 # 5. train step (train.py:85-123): loss, L2 quirk, Adam - small net, dropout 0 (deterministic)
 # =================================================================================
-def gen_train():
+def gen_train(dropout=0.0, torch_seed_for_masks=None):
+    """dropout > 0: the reference's actual training configuration (main.py:134 dropout=0.1, model.train() at train.py:92);
+    torch is re-seeded right before train.train so that the dropout masks are a function of `torch_seed_for_masks` alone."""
     import json
     out = {}
     torch.manual_seed(3)
     cfg = dict(img_size=7, patch_size=5, embed_dim=32, action_dim=49, num_heads=4, depth=2, channels=2)
-    net = RefNet(dropout=0.0, **cfg)
+    net = RefNet(dropout=dropout, **cfg)
     rng = np.random.RandomState(5)
     B = 24
     states = (rng.rand(B, 2, 7, 7) < 0.2).astype(np.float32)
@@ -544,6 +546,11 @@ def gen_train():
         return r
     np.random.choice = rec_choice
     np.random.seed(11)
+    if torch_seed_for_masks is not None:
+        torch.manual_seed(torch_seed_for_masks)
+        out["torch_seed_for_masks"] = np.array(torch_seed_for_masks)
+        out["torch_threads"] = np.array(torch.get_num_threads())
+    out["dropout"] = np.array(dropout)
     with contextlib.redirect_stdout(io.StringIO()):
         losses = ref_train.train(net, B, buf, 3, 0.00025, "cpu")
     np.random.choice = orig_choice
@@ -558,7 +565,7 @@ def gen_train():
 
 
 def main():
-    which = sys.argv[1:] or ["rules", "search", "games", "compete", "nn", "train"]
+    which = sys.argv[1:] or ["rules", "search", "games", "compete", "nn", "train", "train_dropout"]
     print("python", sys.version.split()[0], "numpy", np.__version__, "torch", torch.__version__,
           "cpus", os.cpu_count(), "torch threads", torch.get_num_threads())
     if "rules" in which:
@@ -582,6 +589,8 @@ def main():
         np.savez_compressed(os.path.join(HERE, "nn_small.npz"), **gen_nn_small())
     if "train" in which:
         np.savez_compressed(os.path.join(HERE, "train_small.npz"), **gen_train())
+    if "train_dropout" in which:
+        np.savez_compressed(os.path.join(HERE, "train_dropout.npz"), **gen_train(dropout=0.1, torch_seed_for_masks=21))
     assert not os.path.exists(os.path.join(REF, "logs")), "reference tree was written to!"
     assert not os.path.exists(os.path.join(REF, "__pycache__"))
 

@@ -52,6 +52,53 @@ def test_ring_overwrites_oldest_and_sampling():
     assert set(np.unique(z.cpu().numpy()).tolist()) <= {-1.0, 0.0, 1.0}
 
 
+def test_stream_index_past_2_to_31():
+    """The tuple stream index is 64-bit end to end: a ring whose cursor has passed 2^31 (hours of self-play) keeps
+    receiving tuples at slot (index % capacity) and reports 64-bit bases (a 32-bit base went negative and the
+    ring silently stopped filling)."""
+    import azk
+    from selfplay import self_play_batch
+    A, cap = 49, 1000
+    start = (1 << 31) - 5
+    replay = azk.DeviceReplay(cap, 2, 7, 7, A)
+    replay.cursor.fill_(start)
+    replay.zs.fill_(7.0)                                                      # sentinel: every written slot gets z in {-1, 0, 1}
+    res = self_play_batch("gomoku", lambda x: fixture_logits_value(x, A, "hash"), 4, 32, size=7, seed=2, replay=replay)
+    total = sum((len(r.cells) if len(r.cells) <= 2 else 2 + 8 * (len(r.cells) - 2)) for r in res)
+    assert total < cap
+    assert int(replay.cursor.item()) == start + total
+    bases = sorted(r.replay_base for r in res)
+    assert bases[0] == start and bases[-1] > (1 << 31) and all(b >= start for b in bases)
+    zs = replay.zs.cpu().numpy()
+    written = {(start + t) % cap for t in range(total)}
+    assert all((zs[i] != 7.0) == (i in written) for i in range(cap))
+    from oracle import replay_oracle as ro
+    states, pis = replay.states.cpu().numpy(), replay.pis.cpu().numpy()
+    for r in res:
+        n = len(r.cells) if len(r.cells) <= 2 else 2 + 8 * (len(r.cells) - 2)
+        got = [(states[(r.replay_base + t) % cap], pis[(r.replay_base + t) % cap], float(zs[(r.replay_base + t) % cap])) for t in range(n)]
+        assert ro.digest(got) == ro.digest(ro.emit_tuples(r.boards, r.pis, r.winner))
+
+
+def test_sample_more_than_held_raises():
+    import azk
+    replay = azk.DeviceReplay(64, 2, 7, 7, 49)
+    replay.add(np.zeros((2, 7, 7), np.float32), np.full(49, 1 / 49), [1.0])
+    with pytest.raises(ValueError):                                           # np.random.choice(replace=False) raises too (replay_buffer.py:16)
+        replay.sample(8)
+
+
+def test_load_pickle_refuses_foreign_globals(tmp_path):
+    import pickle
+    import azk
+    replay = azk.DeviceReplay(8, 2, 7, 7, 49)
+    bad = tmp_path / "bad.pkl"
+    with open(bad, "wb") as fh:
+        pickle.dump({"x": print}, fh)                                         # a global outside the replay format
+    with pytest.raises(pickle.UnpicklingError):
+        replay.load_pickle(str(bad))
+
+
 def test_rectangular_board_is_rejected():
     import azk
     eng = azk.Engine("connect4", 2, 8)

@@ -52,6 +52,64 @@ def test_three_iterations_match_reference():
     assert abs(float(l2_0) - l2) / l2 < 1e-5
 
 
+def test_dropout_training_matches_reference_masks():
+    """The reference trains Net(..., dropout=0.1) under model.train() (main.py:134, train.py:92).  The trainer's dropout
+    path draws torch's masks on tensors of the reference's shapes in the reference's order, so a caller seeded like the
+    reference run (tests/golden/train_dropout.npz) reproduces its losses and weights on the CPU."""
+    from pvnet import NetConfig
+    from trainer import Trainer
+    ZD = load_golden("train_dropout.npz")
+    c = json.loads(bytes(ZD["cfg_json"]).decode())
+    p = float(ZD["dropout"])
+    assert p == 0.1
+    cfg = NetConfig(c["img_size"], c["img_size"], c["channels"], c["action_dim"], c["patch_size"], c["embed_dim"], c["num_heads"],
+                    c["depth"], dropout=p)
+    init = {k[5:]: torch.from_numpy(ZD[k]) for k in ZD.files if k.startswith("init_")}
+    states, pis, zs = torch.from_numpy(ZD["states"]), torch.from_numpy(ZD["pis"]), torch.from_numpy(ZD["zs"])
+
+    def batches():
+        for order in ZD["batch_order"]:
+            idx = torch.from_numpy(order.astype(np.int64))
+            yield states[idx], pis[idx].float(), zs[idx].float()[:, None]
+    tr = Trainer(cfg, init)                                                   # dropout taken from the configuration
+    assert tr.dropout == 0.1
+    torch.manual_seed(int(ZD["torch_seed_for_masks"]))
+    losses = tr.train(batches(), lr=0.00025)
+    np.testing.assert_allclose(losses, ZD["losses_after_3"], rtol=5e-5)
+    sd = tr.state_dict()
+    D = cfg.embed_dim
+    for k in (k for k in ZD.files if k.startswith("final_")):
+        got, want = sd[k[6:]].numpy(), ZD[k]
+        if k.endswith("attn.in_proj_bias"):            # key-bias slice: zero true gradient, see above
+            got, want = np.delete(got, np.s_[D:2 * D]), np.delete(want, np.s_[D:2 * D])
+        np.testing.assert_allclose(got, want, rtol=0, atol=4e-6, err_msg=k)
+    # a different mask seed gives a different loss (the masks are live), dropout 0 gives the deterministic loss
+    torch.manual_seed(22)
+    other = Trainer(cfg, init).train(batches(), lr=0.00025)
+    assert abs(other[0] - losses[0]) > 1e-4
+
+
+def test_dropout_properties():
+    """Mask rate and scaling of the training-mode forward; eval-mode (dropout_p = 0) is unaffected by cfg.dropout."""
+    from pvnet import NetConfig, PolicyValueNet
+    cfg = NetConfig(7, 7, 2, 49, 5, 32, 4, 1, dropout=0.1)
+    net = PolicyValueNet(cfg, seed=1, path="full")
+    x = (torch.rand(16, 2, 7, 7) < 0.2).float()
+    a = net.forward_impl(x, "full")
+    b = net.forward_impl(x, "full")
+    assert torch.equal(a[0], b[0])                                            # self-play / eval never drops anything
+    torch.manual_seed(0)
+    d1 = net.forward_impl(x, "full", dropout_p=0.1)
+    d2 = net.forward_impl(x, "full", dropout_p=0.1)
+    assert not torch.equal(d1[0], d2[0]) and not torch.equal(d1[0], a[0])
+    # the mean over many masks approaches the eval-mode output (inverted dropout keeps expectations)
+    torch.manual_seed(1)
+    acc = sum(net.forward_impl(x, "full", dropout_p=0.1)[0] for _ in range(200)) / 200
+    assert float((acc - a[0]).abs().mean()) < 0.25 * float((d1[0] - a[0]).abs().mean())
+    with __import__("pytest").raises(ValueError):
+        net.forward_impl(x, "cls", dropout_p=0.1)
+
+
 def _worker(rank, world, port, q):
     sys.path[:0] = [ROOT, os.path.join(ROOT, "alpha-zero_amd"), os.path.join(ROOT, "tests")]
     from trainer import Trainer
