@@ -28,7 +28,7 @@ SYMBOLS = [
     "azk_step_tree", "azk_step_gather", "azk_recycle_finished", "azk_nn_patch_embed", "azk_nn_cls_attention", "azk_nn_patch_embed_scores", "azk_nn_cls_pool", "azk_debug_stamps", "azk_emit_finished", "azk_clear_cache", "azk_nn_heads_finalize", "azk_nn_layernorm_rows",
     "azk_vanilla_set_rng", "azk_vanilla_get_rng", "azk_vanilla_search", "azk_nn_embed_pool",
     "azk_nn_gemm_rows", "azk_nn_layernorm_sum", "azk_nn_heads_finalize_sum", "azk_nn_ln_heads",
-    "azk_leaf_source_of", "azk_nn_embed_pool_leaves",
+    "azk_leaf_source_of", "azk_nn_embed_pool_leaves", "azk_nn_embed_pool_compact", "azk_nn_embed_pool_compact_leaves",
 ]
 
 
@@ -47,6 +47,14 @@ class LeafSource(C.Structure):
     _fields_ = [("leaf_flag", C.c_void_p), ("leaf_cells", C.c_void_p), ("to_move", C.c_void_p), ("leaf_depth", C.c_void_p),
                 ("leaf_slot", C.c_void_p), ("n_leaf", C.c_void_p), ("n_games", C.c_int32), ("rows", C.c_int32), ("cols", C.c_int32),
                 ("rc", C.c_int32), ("rc_pad", C.c_int32), ("planes", C.c_int32), ("flag_bytes", C.c_int32)]
+
+
+class EmbedPoolConsts(C.Structure):
+    """azk_embed_pool_consts (include/azk.h): the per-token tables of the compacting embedding + pooling kernel."""
+    _fields_ = [("wt_frag", C.c_void_p), ("cpos_tok", C.c_void_p), ("score_tok", C.c_void_p), ("wconst_tok", C.c_void_p),
+                ("xnconst_tok", C.c_void_p), ("z_all", C.c_void_p), ("l_all", C.c_void_p), ("score_msum", C.c_void_p),
+                ("score_ref", C.c_void_p), ("num_heads", C.c_int32), ("ksize", C.c_int32), ("kp", C.c_int32),
+                ("embed_dim", C.c_int32), ("ln_eps", C.c_float)]
 
 
 class Counters(C.Structure):
@@ -129,6 +137,8 @@ def lib():
     L.azk_nn_embed_pool.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, C.c_float, vp, vp]
     L.azk_leaf_source_of.argtypes = [vp, vp, C.POINTER(LeafSource)]
     L.azk_nn_embed_pool_leaves.argtypes = [C.POINTER(LeafSource), vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, C.c_float, vp]
+    L.azk_nn_embed_pool_compact.argtypes = [vp, i32, C.POINTER(EmbedPoolConsts), vp, i32, i32, i32, i32, vp, vp, vp]
+    L.azk_nn_embed_pool_compact_leaves.argtypes = [C.POINTER(LeafSource), C.POINTER(EmbedPoolConsts), vp, vp, vp]
     L.azk_nn_ln_heads.argtypes = [vp, vp, vp, C.c_float, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]
     L.azk_nn_gemm_rows.argtypes = [vp, i32, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]
     L.azk_nn_layernorm_sum.argtypes = [vp, i32, i32, vp, vp, vp, vp, C.c_float, vp, vp, vp, i32, i32, vp, vp]
@@ -566,6 +576,76 @@ def nn_embed_pool_leaves(src, wt_ext, cpos_frag, score_frag, score_msum, score_r
         timers[0].stop()
     if rc != 0:
         raise AzkError(f"azk_nn_embed_pool_leaves failed ({rc})")
+    return z
+
+
+class EmbedPoolTables:
+    """The tables of azk_nn_embed_pool_compact, kept alive together with their ctypes descriptor.
+    t: dict of CUDA tensors (wt_ext bf16 [D+16, kp]; cpos_tok f32 [T+1, D]; score_tok, wconst_tok f32 [T+1, 16]; xnconst_tok bf16
+    [T+1, D]; z_all f32 [4, 8, 64, 4]; l_all, score_msum, score_ref f32 [16])."""
+
+    def __init__(self, t, num_heads, ksize, embed_dim, eps=1e-5):
+        torch = _torch()
+        self.t = {k: v.contiguous() for k, v in t.items()}
+        T1 = self.t["cpos_tok"].shape[0]
+        for k, (shape, dt) in dict(cpos_tok=((T1, embed_dim), torch.float32), score_tok=((T1, 16), torch.float32),
+                                   wconst_tok=((T1, 16), torch.float32), xnconst_tok=((T1, embed_dim), torch.bfloat16),
+                                   z_all=((4, 8, 64, 4), torch.float32), l_all=((16,), torch.float32), score_msum=((16,), torch.float32),
+                                   score_ref=((16,), torch.float32)).items():
+            assert tuple(self.t[k].shape) == shape and self.t[k].dtype == dt and self.t[k].is_cuda, k
+        assert self.t["wt_ext"].dtype == torch.bfloat16 and self.t["wt_ext"].shape[0] == embed_dim + 16 and embed_dim == 512
+        # MFMA fragment order [33 column tiles][kp/32][64 lanes][8] (include/azk.h)
+        w = self.t["wt_ext"]
+        kp = w.shape[1]
+        ct, l = torch.arange(33, device=w.device)[:, None], torch.arange(64, device=w.device)[None, :]
+        col = torch.where(ct < 32, 128 * (ct >> 3) + 8 * (l & 15) + (ct & 7), 512 + (l & 15))           # [33, 64]
+        kidx = (32 * torch.arange(kp // 32, device=w.device)[:, None, None] + 8 * (l[0] >> 4)[None, :, None]
+                + torch.arange(8, device=w.device)[None, None, :])                                      # [KS, 64, 8]
+        self.t["wt_frag"] = w[col[:, None, :, None], kidx[None]].contiguous()                           # [33, KS, 64, 8]
+        self.tokens, self.num_heads, self.embed_dim = T1 - 1, num_heads, embed_dim
+        self.c = EmbedPoolConsts(*[self.t[k].data_ptr() for k in ("wt_frag", "cpos_tok", "score_tok", "wconst_tok", "xnconst_tok", "z_all",
+                                                                 "l_all", "score_msum", "score_ref")],
+                                 num_heads, ksize, self.t["wt_ext"].shape[1], embed_dim, float(eps))
+
+
+def new_sched(device):
+    """The work-queue words of the compacting kernel: int32 [2], zero; one buffer per stream that may run it concurrently."""
+    return _torch().zeros(2, dtype=_torch().int32, device=device)
+
+
+def nn_embed_pool_compact(boards, tables, rows, cols, sched, count=None, timers=None):
+    """azk_nn_embed_pool_compact: boards [n, C, R, Cc] bf16 / f32 -> z bf16 [n, H, D], evaluating only the tokens a stone can reach."""
+    torch = _torch()
+    assert boards.is_cuda and boards.is_contiguous() and boards.dtype in (torch.bfloat16, torch.float32)
+    assert rows * cols + 1 == tables.tokens and sched.dtype == torch.int32 and sched.numel() >= 2
+    n, Cc = boards.shape[0], boards.shape[1]
+    z = torch.empty((n, tables.num_heads, tables.embed_dim), dtype=torch.bfloat16, device=boards.device)
+    fn = lib().azk_nn_embed_pool_compact
+    args = (_p(boards), 1 if boards.dtype == torch.float32 else 0, C.byref(tables.c), _p(z), n, Cc, rows, cols, _p(count), _p(sched), _stream())
+    if timers is not None:
+        timers[0].start()
+    rc = fn(*args)
+    if timers is not None:
+        timers[0].stop()
+    if rc != 0:
+        raise AzkError(f"azk_nn_embed_pool_compact failed ({rc})")
+    return z
+
+
+def nn_embed_pool_compact_leaves(src, tables, sched, timers=None):
+    """azk_nn_embed_pool_compact over an engine's pending leaves (LeafSource): z bf16 [G, H, D], rows [0, n_leaf) valid."""
+    torch = _torch()
+    assert src.rows * src.cols + 1 == tables.tokens and sched.dtype == torch.int32 and sched.numel() >= 2
+    z = torch.empty((src.n_games, tables.num_heads, tables.embed_dim), dtype=torch.bfloat16, device=sched.device)
+    fn = lib().azk_nn_embed_pool_compact_leaves
+    args = (C.byref(src), C.byref(tables.c), _p(z), _p(sched), _stream())
+    if timers is not None:
+        timers[0].start()
+    rc = fn(*args)
+    if timers is not None:
+        timers[0].stop()
+    if rc != 0:
+        raise AzkError(f"azk_nn_embed_pool_compact_leaves failed ({rc})")
     return z
 
 

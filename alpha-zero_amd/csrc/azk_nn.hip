@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_bf16.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <type_traits>
@@ -1133,6 +1134,479 @@ extern "C" int32_t azk_nn_embed_pool_leaves(const azk_leaf_source *src, const vo
     if (src->n_games < 1 || src->rows * src->cols != src->rc || src->flag_bytes < src->n_games) return AZK_ERR_ARG;
     return embed_pool_impl(nullptr, 0, src, wt_ext_bf16_dev, cpos_frag_dev, score_frag_dev, score_msum_dev, score_ref_dev,
                            z_out_bf16_dev, num_heads, src->n_games, src->planes, src->rows, src->cols, ksize, kp, embed_dim, ln_eps, nullptr, stream);
+}
+
+// =====================================================================================================
+// k_embed_pool_c: k_embed_pool that only computes the tokens a stone can reach.
+//   A token whose k x k patch holds no stone is a constant of the weights: x_t = cpos[t], so its normalised row xn_t, its
+//   head scores and - with the static softmax reference - its weights w_t[h] = exp(s_t[h] - ref[h]) do not depend on the
+//   board.  With  ZALL[h] = sum_t wc_t[h] xnc_t  and  LALL[h] = sum_t wc_t[h]  over ALL tokens taken as empty-patch tokens,
+//       Z[h] = ZALL[h] + sum_{t dirty} (w_t[h] xn_t - wc_t[h] xnc_t),     L[h] = LALL[h] + sum_{t dirty} (w_t[h] - wc_t[h])
+//   exactly (the softmax reference is the same constant on both sides).  On a 15x15 board with ~20 stones ~100 of the 226
+//   tokens are dirty: 7 sixteen-token tiles instead of 15.  Per board: patch bits of all tokens (one per thread), the
+//   dirty ones compacted through LDS (ballot + prefix), then the tile loop of k_embed_pool over the compacted list with
+//   the per-token constants GATHERED by token index ([token][...] tables, L2 resident); the subtraction rides on the same
+//   MFMA: v_mfma_f32_16x16x32_bf16 with k-slots 0..3 of a lane group = its four tokens (A: w, B: xn) and k-slots 4..7 = the
+//   same tokens as constants (A: -wc, B: xnc).
+//   Scheduling: a workgroup's first board is blockIdx.x; further boards come from a device-side queue head (one atomic per
+//   board, issued behind the first tile's loads so its round trip hides under the tile), because boards now differ in
+//   cost.  Exactly n_valid tickets are drawn per launch (every workgroup with a board draws until one fails), so the
+//   workgroup holding ticket n_valid - 1 knows the queue is finished and leaves the counter zero for the next launch.
+// =====================================================================================================
+namespace {
+
+struct EmbedPoolCArgs {
+    const void *boards;
+    int boards_f32;
+    const void *wt_frag;           // conv weight (+ the 16 extra columns) in MFMA fragment order [33][KS][64] x 16 bytes
+    const float *cposT;            // [T + 1][D]   bias + positional term per token; row T (the null token) = 0
+    const float *scoreT;           // [T + 1][16]  score constants per token (column 15: row mean); row T: -1e30 in the head columns
+    const float *wcT;              // [T + 1][16]  softmax weight of the token taken as an empty-patch token; row T = 0
+    const __hip_bfloat16 *xncT;    // [T + 1][D]   normalised empty-patch token (bf16); row T = 0
+    const float *zall;             // accumulator order [4 waves][8][64 lanes][4]: ZALL[head 4 (lane>>4) + j][128 w + 8 (lane&15) + q]
+    const float *lall;             // [16]
+    const float *msum, *sref;      // [16]
+    __hip_bfloat16 *z;             // [n][NH][D]
+    const int *count;
+    int *sched;                    // [1]: ticket counter of the board queue; zero between launches
+    long long *dbg;                // debug only (AZK_EMBED_POOL_STAMPS): [8] cycle sums per phase, wave 0 of every workgroup
+    int n, R, Cc, T;
+    float eps;
+    azk_leaf_source src;
+};
+
+template <int NC, int KSZ, int NH, bool SRC>
+__global__ __launch_bounds__(256, 2) void k_embed_pool_c(EmbedPoolCArgs a) {
+    constexpr int KS = (NC * KSZ * KSZ + 31) / 32;
+    constexpr int D = 512, KP = 32 * KS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint4 *alut = (uint4 *)smem;                                  // [256] A fragment of 8 patch bits
+    float *part = (float *)(alut + 256);                          // [2 parities][16 rows][4 waves] partial sums of squares
+    uint4 *pbits = (uint4 *)(part + 128);                         // [256 + 16] patch bits of the compacted dirty tokens
+    int *dlist = (int *)(pbits + 272);                            // [256 + 16] their token indices (null token = T past the end)
+    int *scan = dlist + 272;                                      // [4] SRC wave totals, [4] dirty counts per wave, [8] next board, [9] game
+    uint4 *bimg = (uint4 *)(scan + 16);                           // [33 column tiles][KS][64 lanes] weight B fragments (the wave's 8 tiles + the extra one)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    int nvalid, my_first = 0, my_count = 0, my_lo = 0, my_per = 0;
+    unsigned long long myflags = 0ull;
+    if (SRC) {
+        // exclusive prefix of the leaf flags over the workgroup's 256 threads (thread t owns games [t per, (t+1) per))
+        my_per = ((((a.src.n_games + 255) >> 8) + 7) >> 3) << 3;
+        my_lo = tid * my_per;
+        for (int w = 0; w < my_per; w += 8)
+            if (my_lo + w < a.src.flag_bytes) {
+                const unsigned long long f = *(const unsigned long long *)(a.src.leaf_flag + my_lo + w);
+                if (w == 0) myflags = f;
+                my_count += __popcll(f);
+            }
+        int incl = my_count;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(incl, off); if (lane >= off) incl += v; }
+        if (lane == 63) scan[wave] = incl;
+        __syncthreads();
+        int before = 0;
+        for (int w = 0; w < wave; w++) before += scan[w];
+        my_first = before + incl - my_count;
+        nvalid = scan[0] + scan[1] + scan[2] + scan[3];
+        if (blockIdx.x == 0 && tid == 0) *a.src.n_leaf = nvalid;
+    } else {
+        nvalid = a.count ? min(a.n, *a.count) : a.n;
+    }
+    int board = blockIdx.x;
+#ifdef AZK_EP_STAMPS          // diagnosis build only (make EXTRA=-DAZK_EP_STAMPS): the stamps cost registers, the product kernel has none
+    const bool stamp = a.dbg != nullptr && tid == 0;
+    long long tp = stamp ? clock64() : 0, tacc[5] = {0, 0, 0, 0, 0}, nt_acc = 0, nb_acc = 0;     // sums stay in registers until the end
+#define AZK_STAMP(i) do { if (stamp) { const long long tn_ = clock64(); tacc[i] += tn_ - tp; tp = tn_; } } while (0)
+#else
+    constexpr bool stamp = false;
+    long long nt_acc = 0, nb_acc = 0;
+#define AZK_STAMP(i) do { } while (0)
+#endif
+    if (board < nvalid) {                                         // (workgroups without a board go straight to the sign-off below)
+    union BF { uint4 u; bf16x8 v; };
+    // the conv weight arrives in MFMA fragment order (wt_frag [33 column tiles][KS][64 lanes] x 16 bytes: fragment (tile, s)
+    // of lane l = wt[col(tile, l)][32 s + 8 (l>>4) .. +8], column tile 32 = the extra columns): a straight copy into LDS,
+    // every load of a thread in flight before its first LDS store
+    {
+        constexpr int NF = 33 * KS * 64, PER = (NF + 255) / 256, CH = 9;
+#pragma unroll
+        for (int i0 = 0; i0 < PER; i0 += CH) {
+            uint4 wv[CH];
+#pragma unroll
+            for (int i = 0; i < CH; i++) wv[i] = ((const uint4 *)a.wt_frag)[min(tid + 256 * (i0 + i), NF - 1)];
+#pragma unroll
+            for (int i = 0; i < CH; i++) if (i0 + i < PER && tid + 256 * (i0 + i) < NF) bimg[tid + 256 * (i0 + i)] = wv[i];
+        }
+    }
+    const uint4 *bwv = bimg + (size_t)wave * 8 * KS * 64 + lane, *bev = bimg + (size_t)32 * KS * 64 + lane;
+    {
+        unsigned r[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) r[i] = (((tid >> (2 * i)) & 1) ? 0x3F80u : 0u) | (((tid >> (2 * i + 1)) & 1) ? 0x3F800000u : 0u);
+        alut[tid] = make_uint4(r[0], r[1], r[2], r[3]);
+    }
+    constexpr int ksz = KSZ, kk = KSZ * KSZ, pad = KSZ / 2;
+    const int RC = a.R * a.Cc, T = a.T, ncell = NC * RC;
+    const float msum = a.msum[l15], sref = a.sref[l15];
+    const int colofs = 128 * wave + 8 * l15;
+    // this thread's token (t = tid): where its patch rows sit in the board bit string - the same for every board
+    const int tj = tid - 1, tr = tj / a.Cc, tc = tj - tr * a.Cc;
+    const bool tlive = tid >= 1 && tid < T;
+    unsigned colmask = 0;
+#pragma unroll
+    for (int kx = 0; kx < ksz; kx++) { const int cc = tc + kx - pad; if (cc >= 0 && cc < a.Cc) colmask |= 1u << kx; }
+    int par = 0, nxt = 0;
+    __syncthreads();
+    AZK_STAMP(0);                                                 // prologue: weights staged
+
+    while (board < nvalid) {
+        int game = 0, player = 0;
+        if (SRC) {
+            // the game behind leaf `board`: the thread whose flag range holds the board-th flagged game finds it (its first
+            // eight flags are in a register), records the slot the next expansion reads and posts the game index
+            if (board >= my_first && board < my_first + my_count) {
+                int kq = board - my_first, g = my_lo;
+                for (int w = 0; w < my_per; w++) {
+                    const int f = w < 8 ? (int)((myflags >> (8 * w)) & 0xffull) : (int)a.src.leaf_flag[my_lo + w];
+                    if (f && kq-- == 0) { g = my_lo + w; break; }
+                }
+                scan[9] = g;
+                a.src.leaf_slot[g] = board;
+            }
+            __syncthreads();
+            game = scan[9];
+        }
+        // the workgroup's Z starts at the constant part (fetched here, under the board's own loads)
+        f32x4 Z[8];
+        if (l4 < (NH + 3) / 4) {
+            const f32x4 *zp = (const f32x4 *)a.zall + (size_t)wave * 8 * 64 + lane;
+#pragma unroll
+            for (int q = 0; q < 8; q++) Z[q] = zp[q * 64];
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8; q++) Z[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        unsigned wbits = 0;                             // lane i holds bits [32 (i-1), 32 i) of the board bit string (lane 0: zeros)
+        constexpr int NQ = 8;                           // boards of up to 512 plane cells: every load of the board in ONE round trip
+        if (ncell <= 64 * NQ) {
+            bool on[NQ];
+            if (SRC) {
+                // canonical planes from the cell codes (gomoku.py:34-40; 3-plane: mcts.py:126-137); the code loads do not
+                // depend on the side to move, so they travel together with the two words that give it
+                int code[NQ], chq[NQ];
+#pragma unroll
+                for (int q = 0; q < NQ; q++) {
+                    const int e = min(q * 64 + lane, ncell - 1);
+                    chq[q] = (e >= RC) + (e >= 2 * RC);
+                    code[q] = a.src.leaf_cells[(size_t)game * a.src.rc_pad + (e - chq[q] * RC)];
+                }
+                player = (a.src.to_move[game] + a.src.leaf_depth[game]) & 1;     // node.currentPlayer at the leaf
+#pragma unroll
+                for (int q = 0; q < NQ; q++)
+                    on[q] = q * 64 + lane < ncell && (chq[q] == 2 ? player != 0 : ((code[q] >> (chq[q] ^ player)) & 1) != 0);
+            } else if (a.boards_f32) {
+                float raw[NQ];
+#pragma unroll
+                for (int q = 0; q < NQ; q++) raw[q] = ((const float *)a.boards)[(size_t)board * ncell + min(q * 64 + lane, ncell - 1)];
+#pragma unroll
+                for (int q = 0; q < NQ; q++) on[q] = q * 64 + lane < ncell && raw[q] != 0.0f;
+            } else {
+                unsigned short raw[NQ];
+#pragma unroll
+                for (int q = 0; q < NQ; q++) raw[q] = ((const unsigned short *)a.boards)[(size_t)board * ncell + min(q * 64 + lane, ncell - 1)];
+#pragma unroll
+                for (int q = 0; q < NQ; q++) on[q] = q * 64 + lane < ncell && (raw[q] & 0x7fff) != 0;
+            }
+#pragma unroll
+            for (int q = 0; q < NQ; q++) {
+                const unsigned long long m = __ballot(on[q]);
+                if ((lane - 1) >> 1 == q && lane >= 1) wbits = ((lane - 1) & 1) ? (unsigned)(m >> 32) : (unsigned)m;
+            }
+        } else {
+            if (SRC) player = (a.src.to_move[game] + a.src.leaf_depth[game]) & 1;
+            for (int q = 0; q * 64 < ncell; q++) {
+                const int e = q * 64 + lane;
+                bool on = false;
+                if (SRC) {
+                    if (e < ncell) {
+                        const int ch = (e >= RC) + (e >= 2 * RC), cell = e - ch * RC;
+                        const int code = a.src.leaf_cells[(size_t)game * a.src.rc_pad + cell];
+                        on = ch == 2 ? player != 0 : ((code >> (ch ^ player)) & 1) != 0;
+                    }
+                } else if (e < ncell)
+                    on = a.boards_f32 ? ((const float *)a.boards)[(size_t)board * ncell + e] != 0.0f
+                                      : (((const unsigned short *)a.boards)[(size_t)board * ncell + e] & 0x7fff) != 0;
+                const unsigned long long m = __ballot(on);
+                if ((lane - 1) >> 1 == q && lane >= 1) wbits = ((lane - 1) & 1) ? (unsigned)(m >> 32) : (unsigned)m;
+            }
+        }
+        AZK_STAMP(1);                                             // board resolved, loaded, bit string built
+        // ---- patch bits of this thread's token; dirty = some stone in the patch ----
+        unsigned long long plo = 0, phi = 0;
+        {
+            // compile-time trip counts: all 2 NC KSZ cross-lane reads of the bit string are issued together
+            unsigned lo[NC * KSZ], hi[NC * KSZ];
+#pragma unroll
+            for (int ch = 0; ch < NC; ch++)
+#pragma unroll
+                for (int ky = 0; ky < KSZ; ky++) {
+                    const int rr = tr + ky - pad;
+                    int off = 32 + ch * RC + (rr < 0 ? 0 : (rr >= a.R ? a.R - 1 : rr)) * a.Cc + (tc - pad);
+                    if (!tlive) off = 32;
+                    lo[ch * KSZ + ky] = __shfl(wbits, off >> 5); hi[ch * KSZ + ky] = __shfl(wbits, (off >> 5) + 1);
+                }
+#pragma unroll
+            for (int ch = 0; ch < NC; ch++)
+#pragma unroll
+                for (int ky = 0; ky < KSZ; ky++) {
+                    const int rr = tr + ky - pad;
+                    int off = 32 + ch * RC + (rr < 0 ? 0 : (rr >= a.R ? a.R - 1 : rr)) * a.Cc + (tc - pad);
+                    if (!tlive) off = 32;
+                    unsigned bits = __funnelshift_r(lo[ch * KSZ + ky], hi[ch * KSZ + ky], off & 31) & colmask;
+                    if (!tlive || rr < 0 || rr >= a.R) bits = 0;
+                    constexpr int dummy = 0; (void)dummy;
+                    const int p0 = ch * kk + ky * ksz;
+                    if (p0 < 64) { plo |= (unsigned long long)bits << p0; if (p0 + ksz > 64) phi |= (unsigned long long)bits >> (64 - p0); }
+                    else phi |= (unsigned long long)bits << (p0 - 64);
+                }
+        }
+        const bool dirty = (plo | phi) != 0ull;
+        const unsigned long long dm = __ballot(dirty);
+        if (lane == 0) scan[4 + wave] = __popcll(dm);
+        __syncthreads();                                  // (also: every wave is done with the previous board's lists)
+        int dpos = __popcll(dm & ((1ull << lane) - 1ull));
+        for (int w = 0; w < wave; w++) dpos += scan[4 + w];
+        const int nd = scan[4] + scan[5] + scan[6] + scan[7];
+        const int ntile = (nd + 15) >> 4;
+        if (dirty) {
+            dlist[dpos] = tid;
+            pbits[dpos] = make_uint4((unsigned)plo, (unsigned)(plo >> 32), (unsigned)phi, (unsigned)(phi >> 32));
+        }
+        if (tid < 16 && nd + tid < ntile * 16) { dlist[nd + tid] = T; pbits[nd + tid] = make_uint4(0u, 0u, 0u, 0u); }   // null tokens fill the last tile
+        __syncthreads();
+
+        AZK_STAMP(2);                                             // patch bits + compaction
+        if (stamp) nt_acc += ntile;
+        float L = 0.f;                                    // per head (lane&15 < NH): this lane>>4 group's share of sum (w - wc)
+        for (int tile = 0; tile < ntile; tile++) {
+            // ---- gathers: the four tokens of this lane's accumulator rows ----
+            const int4 tk = *(const int4 *)(dlist + 16 * tile + 4 * l4);
+            const int tks[4] = {tk.x, tk.y, tk.z, tk.w};
+            // 32-bit element offsets from the (uniform) table bases: one VGPR per token instead of a 64-bit address per table
+            unsigned orow[4], osc[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) { orow[r] = (unsigned)tks[r] * (unsigned)D + (unsigned)colofs; osc[r] = (unsigned)tks[r] * 16u + (unsigned)l15; }
+            f32x4 acc[8];
+            f32x4 acce, wc;
+            {
+                f32x4 c0[4], c1[4];
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    c0[r] = *(const f32x4 *)(a.cposT + orow[r]); c1[r] = *(const f32x4 *)(a.cposT + orow[r] + 4);
+                    acce[r] = a.scoreT[osc[r]];
+                    wc[r] = a.wcT[osc[r]];
+                }
+                if (tile == 0 && tid == 0) {              // next board: the round trip hides under this tile
+                    __builtin_amdgcn_sched_barrier(0);
+                    nxt = atomicAdd(a.sched, 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    acc[0][r] = c0[r][0]; acc[1][r] = c0[r][1]; acc[2][r] = c0[r][2]; acc[3][r] = c0[r][3];
+                    acc[4][r] = c1[r][0]; acc[5][r] = c1[r][1]; acc[6][r] = c1[r][2]; acc[7][r] = c1[r][3];
+                }
+            }
+            uint4 xr[4];                                  // the constant rows are needed last: fetched into the registers c0 / c1 just left
+#pragma unroll
+            for (int r = 0; r < 4; r++) xr[r] = *(const uint4 *)((const unsigned short *)a.xncT + orow[r]);
+            // ---- A fragments: 8 patch bits of this lane's token (row lane&15) per k-step -> table ----
+            const uint4 pb = pbits[tile * 16 + l15];
+            const unsigned pw[4] = {pb.x, pb.y, pb.z, pb.w};
+            bf16x8 afrag[KS];
+#pragma unroll
+            for (int s = 0; s < KS; s++) {
+                union { uint4 u; bf16x8 v; } af;
+                af.u = alut[(pw[s] >> (8 * l4)) & 0xffu];
+                afrag[s] = af.v;
+            }
+#pragma unroll
+            for (int s = 0; s < KS; s++) { BF b; b.u = bev[s * 64]; acce = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[s], b.v, acce, 0, 0, 0); }
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+#pragma unroll
+                for (int s = 0; s < KS; s++) { BF b; b.u = bwv[(q * KS + s) * 64]; acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[s], b.v, acc[q], 0, 0, 0); }
+                if ((q & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // B-fragment prefetch depth: 4 accumulators (VGPR budget)
+            }
+            // ---- LayerNorm statistics of the full rows (mean = GEMM column 15 of the extra tile) ----
+            float mean[4];
+#pragma unroll
+            for (int r4 = 0; r4 < 4; r4++) mean[r4] = __shfl(acce[r4], (lane & 48) | 15);
+            f32x2 q01 = {0.f, 0.f}, q23 = {0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const f32x2 lo = {acc[q][0], acc[q][1]}, hi = {acc[q][2], acc[q][3]};
+                q01 = __builtin_elementwise_fma(lo, lo, q01);
+                q23 = __builtin_elementwise_fma(hi, hi, q23);
+            }
+            const f32x2 pq01 = {row16_sum(q01[0]), row16_sum(q01[1])}, pq23 = {row16_sum(q23[0]), row16_sum(q23[1])};
+            f32x2 *part2 = (f32x2 *)part;                             // [parity][8 row pairs][4 waves]
+            if (l15 == 0) {
+                part2[(par * 8 + 2 * l4) * 4 + wave] = pq01;
+                part2[(par * 8 + 2 * l4 + 1) * 4 + wave] = pq23;
+            }
+            __syncthreads();
+            const f32x4 *pp = (const f32x4 *)(part2 + (par * 8 + 2 * l4) * 4);
+            const f32x4 a0 = pp[0], a1 = pp[1], b0 = pp[2], b1 = pp[3];
+            const f32x2 s01 = (f32x2{a0[0], a0[1]} + f32x2{a0[2], a0[3]}) + (f32x2{a1[0], a1[1]} + f32x2{a1[2], a1[3]});
+            const f32x2 s23 = (f32x2{b0[0], b0[1]} + f32x2{b0[2], b0[3]}) + (f32x2{b1[0], b1[1]} + f32x2{b1[2], b1[3]});
+            const f32x2 mean01 = {mean[0], mean[1]}, mean23 = {mean[2], mean[3]};
+            const f32x2 invD = {1.0f / (float)D, 1.0f / (float)D};
+            const f32x2 v01 = __builtin_elementwise_fma(-mean01, mean01, s01 * invD), v23 = __builtin_elementwise_fma(-mean23, mean23, s23 * invD);
+            const f32x2 r01 = {__builtin_amdgcn_rsqf(fmaxf(v01[0], 0.f) + a.eps), __builtin_amdgcn_rsqf(fmaxf(v01[1], 0.f) + a.eps)};
+            const f32x2 r23 = {__builtin_amdgcn_rsqf(fmaxf(v23[0], 0.f) + a.eps), __builtin_amdgcn_rsqf(fmaxf(v23[1], 0.f) + a.eps)};
+            const f32x2 h01 = -mean01 * r01, h23 = -mean23 * r23;    // xn = x * rstd + shift
+            par ^= 1;
+            // ---- scores (head = lane&15, tokens = rows) and softmax weights against the static reference ----
+            const f32x2 ms2 = {msum, msum};
+            const f32x2 sc01 = r01 * __builtin_elementwise_fma(-mean01, ms2, f32x2{acce[0], acce[1]});
+            const f32x2 sc23 = r23 * __builtin_elementwise_fma(-mean23, ms2, f32x2{acce[2], acce[3]});
+            float w[4];
+            w[0] = __expf(sc01[0] - sref); w[1] = __expf(sc01[1] - sref); w[2] = __expf(sc23[0] - sref); w[3] = __expf(sc23[1] - sref);
+            L += ((w[0] - wc[0]) + (w[1] - wc[1])) + ((w[2] - wc[2]) + (w[3] - wc[3]));
+            // ---- Z += W^T Xn - Wc^T Xnc as ONE 16x16x32 MFMA per column: k-slots 0..3 actual, 4..7 constant ----
+            union { bf16x8 v; s16x4 h[2]; } wa;
+            wa.h[0] = pack4_bf16(f32x2{w[0], w[1]}, f32x2{w[2], w[3]});
+            wa.h[1] = pack4_bf16(f32x2{-wc[0], -wc[1]}, f32x2{-wc[2], -wc[3]});
+            const unsigned xw[4][4] = {{xr[0].x, xr[0].y, xr[0].z, xr[0].w}, {xr[1].x, xr[1].y, xr[1].z, xr[1].w},
+                                       {xr[2].x, xr[2].y, xr[2].z, xr[2].w}, {xr[3].x, xr[3].y, xr[3].z, xr[3].w}};
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const f32x2 lo = {acc[q][0], acc[q][1]}, hi = {acc[q][2], acc[q][3]};
+                const f32x2 vlo = __builtin_elementwise_fma(lo, r01, h01), vhi = __builtin_elementwise_fma(hi, r23, h23);   // (x - mean) * rstd
+                union { bf16x8 v; struct { s16x4 h; unsigned c01, c23; } p; } xb;
+                xb.p.h = pack4_bf16(vlo, vhi);
+                const unsigned sel = (q & 1) ? 0x07060302u : 0x05040100u;                  // bf16 element q of each token's 16-byte row
+                xb.p.c01 = __builtin_amdgcn_perm(xw[1][q >> 1], xw[0][q >> 1], sel);
+                xb.p.c23 = __builtin_amdgcn_perm(xw[3][q >> 1], xw[2][q >> 1], sel);
+                Z[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa.v, xb.v, Z[q], 0, 0, 0);
+            }
+        }
+        AZK_STAMP(3);                                             // tile loop
+        if (ntile == 0 && tid == 0) nxt = atomicAdd(a.sched, 1);
+        // ---- z[b][h][:] = (ZALL + Z)[h][:] / (LALL + L)[h] ----
+        float Lt = L + __shfl_xor(L, 16);
+        Lt += __shfl_xor(Lt, 32);
+        Lt += a.lall[l15];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int head = 4 * l4 + j;
+            const float Lh = __shfl(Lt, head & 15);
+            if (head < NH) {
+                const float inv = 1.0f / Lh;
+                float v[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) v[q] = Z[q][j] * inv;
+                *(uint4 *)(a.z + ((size_t)board * NH + head) * D + colofs) = pack8(v);
+            }
+        }
+        if (tid == 0) {
+            // every workgroup that got a board draws tickets until one fails, so exactly nvalid tickets are drawn per launch:
+            // whoever holds the last one (nvalid - 1) knows the queue is finished for this launch and leaves it zero
+            if (nxt == nvalid - 1) a.sched[0] = 0;
+            scan[8] = (int)gridDim.x + nxt;
+        }
+        __syncthreads();
+        board = scan[8];
+        AZK_STAMP(4);                                             // epilogue + next board known
+        if (stamp) nb_acc += 1;
+    }
+    }
+#undef AZK_STAMP
+#ifdef AZK_EP_STAMPS
+    if (stamp) {
+        for (int i = 0; i < 5; i++) atomicAdd((unsigned long long *)a.dbg + i, (unsigned long long)tacc[i]);
+        atomicAdd((unsigned long long *)a.dbg + 6, (unsigned long long)nt_acc);
+        atomicAdd((unsigned long long *)a.dbg + 7, (unsigned long long)nb_acc);
+    }
+#endif
+    (void)nt_acc; (void)nb_acc;
+}
+
+template <int NC, int KSZ, int NH, bool SRC>
+int launch_embed_pool_c2(const EmbedPoolCArgs &a, hipStream_t st) {
+    constexpr int KS = (NC * KSZ * KSZ + 31) / 32;
+    const int lds = 256 * 16 + 512 + 272 * 16 + 272 * 4 + 64 + 33 * KS * 64 * 16;      // 77 KB at KS = 2: two workgroups per CU
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void *)k_embed_pool_c<NC, KSZ, NH, SRC>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return AZK_ERR_HIP;
+        attr_set = true;
+    }
+    const int blocks = a.n < 512 ? a.n : 512;                      // two resident workgroups per CU; each pulls boards until the queue is dry
+    k_embed_pool_c<NC, KSZ, NH, SRC><<<blocks, 256, lds, st>>>(a);
+    return hipGetLastError() == hipSuccess ? AZK_OK : AZK_ERR_HIP;
+}
+}  // namespace
+
+static int32_t embed_pool_c_impl(const void *boards_dev, int32_t boards_are_f32, const azk_leaf_source *src, const azk_embed_pool_consts *k,
+                                 void *z_out_bf16_dev, int32_t n, int32_t channels, int32_t rows, int32_t cols,
+                                 const int32_t *n_valid_dev, int32_t *sched_dev, void *stream) {
+    if ((!boards_dev && !src) || !k || !z_out_bf16_dev || !sched_dev) return AZK_ERR_ARG;
+    if (!k->wt_frag || !k->cpos_tok || !k->score_tok || !k->wconst_tok || !k->xnconst_tok || !k->z_all || !k->l_all || !k->score_msum || !k->score_ref) return AZK_ERR_ARG;
+    const int ksize = k->ksize, kp = k->kp;
+    if (n < 0 || channels < 1 || rows < 1 || cols < 1 || ksize < 1 || (ksize & 1) == 0 || ksize > 7) return AZK_ERR_ARG;
+    if (kp < channels * ksize * ksize || kp % 32 != 0 || kp > 96) return AZK_ERR_ARG;
+    if (channels * rows * cols > 62 * 32 || k->embed_dim != 512) return AZK_ERR_ARG;
+    if (rows * cols + 1 > 256) return AZK_ERR_ARG;                 // one thread per token
+    if (k->num_heads != 8 && k->num_heads != 4) return AZK_ERR_ARG;
+    if (n == 0) return AZK_OK;
+    EmbedPoolCArgs a;
+    memset(&a, 0, sizeof a);
+    a.boards = boards_dev; a.boards_f32 = boards_are_f32; a.wt_frag = k->wt_frag; a.cposT = k->cpos_tok;
+    a.scoreT = k->score_tok; a.wcT = k->wconst_tok; a.xncT = (const __hip_bfloat16 *)k->xnconst_tok; a.zall = k->z_all; a.lall = k->l_all;
+    a.msum = k->score_msum; a.sref = k->score_ref; a.z = (__hip_bfloat16 *)z_out_bf16_dev; a.count = n_valid_dev; a.sched = sched_dev;
+    a.n = n; a.R = rows; a.Cc = cols; a.T = rows * cols + 1; a.eps = k->ln_eps;
+    if (src) a.src = *src;
+    {
+        static long long *dbg_buf = nullptr;
+        const char *ds = getenv("AZK_EMBED_POOL_STAMPS");
+        if (ds && atoi(ds)) {
+            if (!dbg_buf && (hipMalloc((void **)&dbg_buf, 64) != hipSuccess || hipMemset(dbg_buf, 0, 64) != hipSuccess)) return AZK_ERR_HIP;
+            a.dbg = dbg_buf;
+            if (atoi(ds) == 2) {          // print-and-reset request
+                long long h[8];
+                if (hipMemcpy(h, dbg_buf, 64, hipMemcpyDeviceToHost) != hipSuccess) return AZK_ERR_HIP;
+                fprintf(stderr, "[embed_pool_c stamps] boards %lld tiles %lld | cycles per board: prologue(total) %lld, load %.0f, patch+compact %.0f, tiles %.0f (%.0f per tile), epilogue %.0f\n",
+                        h[7], h[6], h[0], (double)h[1] / (double)(h[7] ? h[7] : 1), (double)h[2] / (double)(h[7] ? h[7] : 1), (double)h[3] / (double)(h[7] ? h[7] : 1),
+                        (double)h[3] / (double)(h[6] ? h[6] : 1), (double)h[4] / (double)(h[7] ? h[7] : 1));
+                if (hipMemset(dbg_buf, 0, 64) != hipSuccess) return AZK_ERR_HIP;
+            }
+        }
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int nh = k->num_heads;
+    if (kp != (channels * ksize * ksize + 31) / 32 * 32) return AZK_ERR_ARG;
+#define CASE(NC_, KSZ_, NH_) if (channels == NC_ && ksize == KSZ_ && nh == NH_) \
+        return src ? launch_embed_pool_c2<NC_, KSZ_, NH_, true>(a, st) : launch_embed_pool_c2<NC_, KSZ_, NH_, false>(a, st)
+    CASE(2, 5, 8); CASE(2, 5, 4); CASE(3, 5, 8); CASE(3, 5, 4); CASE(2, 3, 8); CASE(2, 3, 4); CASE(3, 3, 8); CASE(3, 3, 4);
+#undef CASE
+    return AZK_ERR_ARG;
+}
+
+extern "C" int32_t azk_nn_embed_pool_compact(const void *boards_dev, int32_t boards_are_f32, const azk_embed_pool_consts *consts,
+                                             void *z_out_bf16_dev, int32_t n, int32_t channels, int32_t rows, int32_t cols,
+                                             const int32_t *n_valid_dev, int32_t *sched_dev, void *stream) {
+    if (!boards_dev) return AZK_ERR_ARG;
+    return embed_pool_c_impl(boards_dev, boards_are_f32, nullptr, consts, z_out_bf16_dev, n, channels, rows, cols, n_valid_dev, sched_dev, stream);
+}
+
+extern "C" int32_t azk_nn_embed_pool_compact_leaves(const azk_leaf_source *src, const azk_embed_pool_consts *consts, void *z_out_bf16_dev,
+                                                    int32_t *sched_dev, void *stream) {
+    if (!src || !src->leaf_flag || !src->leaf_cells || !src->to_move || !src->leaf_depth || !src->leaf_slot || !src->n_leaf) return AZK_ERR_ARG;
+    if (src->n_games < 1 || src->rows * src->cols != src->rc || src->flag_bytes < src->n_games) return AZK_ERR_ARG;
+    return embed_pool_c_impl(nullptr, 0, src, consts, z_out_bf16_dev, src->n_games, src->planes, src->rows, src->cols, nullptr, sched_dev, stream);
 }
 
 // =====================================================================================================

@@ -124,6 +124,9 @@ class PolicyValueNet:
         self.leaf_source = None         # azk.LeafSource of the engine being stepped: the fused kernel reads the pending leaves itself
         self.fuse_ln_heads = True       # final LayerNorm + heads + finalize as one hand-written launch (needs hip_tail's packed weights)
         self.fused_embed_pool = False   # set by _prepare_folded when azk_nn_embed_pool covers this configuration
+        self._compact = None            # azk.EmbedPoolTables when the compacting kernel covers this configuration (static softmax reference)
+        self.use_compact = True
+        self._scheds = {}               # work-queue words of the compacting kernel, one buffer per board source (= per stepping stream)
         self.kernel_timers = None   # optional (embed_timer, pool_timer) with start()/stop(): HIP-event timing of the two kernels
         self.live_count = None      # optional int32 CUDA tensor: number of valid rows at the head of the batch (graph stepping)
         self.to(device, dtype)
@@ -223,6 +226,10 @@ class PolicyValueNet:
             ref[:H] = bound
             f["score_ref"] = ref if float(bound.max()) <= 40.0 else None
             self.fused_embed_pool = D == 512 and H in (4, 8) and hp["wt"].shape[1] <= 96
+            self._compact = None
+            if (self.fused_embed_pool and f["score_ref"] is not None and cfg.tokens <= 256 and cfg.channels in (2, 3)
+                    and cfg.patch_size in (3, 5)):
+                self._compact = self._prepare_compact(f, hp, sc, ms, ref)
             Wv = Wi[2 * D:].reshape(H, dh, D).to(dev)
             f["WvT_n"] = (Wv * g).transpose(1, 2).contiguous().to(torch.bfloat16)                      # [H, D, dh]
             f["bv_n"] = (bi[2 * D:].to(dev) + (Wv @ bta).reshape(-1)).to(torch.bfloat16)
@@ -276,6 +283,39 @@ class PolicyValueNet:
             except Exception:
                 self._gelu_epilogue = False
         self._fold = f
+
+    def _prepare_compact(self, f, hp, sc, ms, ref):
+        """Tables of azk_nn_embed_pool_compact (csrc/azk_nn.hip k_embed_pool_c): a token whose patch is empty is a constant of
+        the weights - x_t = cpos[t] - so with the static softmax reference its weight wc_t[h] = exp(s_t[h] - ref[h]) and its
+        normalised row xnc_t are precomputed, together with their sums over ALL tokens (z_all, l_all); the kernel evaluates
+        only the tokens a stone can reach and swaps their constant contribution for the real one.  The statistics follow the
+        kernel's own arithmetic (mean, E[x^2] - mean^2, rsqrt) in float32."""
+        import azk
+        cfg = self.cfg
+        D, H, T = cfg.embed_dim, cfg.num_heads, cfg.tokens
+        dev = self.device
+        cpos = hp["cpos"]                                                     # [T, D] float32
+        mean = sc[:, 15]                                                      # the kernel's mean = score column 15 = cpos.mean(1)
+        var = ((cpos * cpos).sum(1) / D - mean * mean).clamp_min(0.0)
+        rstd = torch.rsqrt(var + 1e-5)
+        xnc = cpos * rstd[:, None] + (-mean * rstd)[:, None]
+        s_c = rstd[:, None] * (sc - mean[:, None] * ms[None, :])               # [T, 16]
+        wc = torch.zeros(T, 16, device=dev)
+        wc[:, :H] = torch.exp(s_c[:, :H] - ref[None, :H])
+        xnc_b = xnc.to(torch.bfloat16)
+        zall = (wc.to(torch.bfloat16).double().t() @ xnc_b.double())           # [16, D], exact products summed in float64
+        lall = wc.double().sum(0)
+        t = dict(wt_ext=f["wt_ext"], score_msum=ms, score_ref=ref)
+        t["cpos_tok"] = torch.cat([cpos, torch.zeros(1, D, device=dev)])
+        null_sc = torch.zeros(1, 16, device=dev)
+        null_sc[:, :H] = -1e30
+        t["score_tok"] = torch.cat([sc, null_sc])
+        t["wconst_tok"] = torch.cat([wc, torch.zeros(1, 16, device=dev)])
+        t["xnconst_tok"] = torch.cat([xnc_b, torch.zeros(1, D, device=dev, dtype=torch.bfloat16)])
+        # accumulator order [w][q][lane = 16 l4 + l15][j]: head 4 l4 + j, column 128 w + 8 l15 + q
+        t["z_all"] = zall.float().view(4, 4, 4, 16, 8).permute(2, 4, 0, 3, 1).reshape(4, 8, 64, 4).contiguous()
+        t["l_all"] = lall.float()
+        return azk.EmbedPoolTables(t, H, cfg.patch_size, D)
 
     def tail_hip(self, z):
         """tail_fast on the hand-written kernels: every launch honours the device-side live count, split-K partial sums are
@@ -360,6 +400,13 @@ class PolicyValueNet:
         self._hip = dict(wt=wt.to(dev, torch.bfloat16).contiguous(), cpos=cpos.to(dev, torch.float32).contiguous(),
                          ln_w=m["blocks.0.norm1.weight"].to(dev, torch.float32).contiguous(),
                          ln_b=m["blocks.0.norm1.bias"].to(dev, torch.float32).contiguous())
+
+    def _sched_for(self, src):
+        key = id(src) if src is not None else None
+        if key not in self._scheds:
+            import azk
+            self._scheds[key] = azk.new_sched(self.device)
+        return self._scheds[key]
 
     def eval(self):
         return self
@@ -496,7 +543,15 @@ class PolicyValueNet:
                 if self.cfg.num_heads in (4, 8):
                     if x.dtype not in (torch.bfloat16, torch.float32):
                         x = x.float()
-                    if self.fused_embed_pool and self.leaf_source is not None:
+                    if self.fused_embed_pool and self._compact is not None and self.use_compact:
+                        # only the tokens a stone can reach are evaluated (k_embed_pool_c); boards pulled from a device queue
+                        if self.leaf_source is not None:
+                            z = azk.nn_embed_pool_compact_leaves(self.leaf_source, self._compact, self._sched_for(self.leaf_source),
+                                                                 timers=self.kernel_timers)
+                        else:
+                            z = azk.nn_embed_pool_compact(x.contiguous(), self._compact, self.cfg.rows, self.cfg.cols, self._sched_for(None),
+                                                          count=self.live_count, timers=self.kernel_timers)
+                    elif self.fused_embed_pool and self.leaf_source is not None:
                         # boards straight from the engine's pending leaves (no compaction launch, no evaluator batch)
                         z = azk.nn_embed_pool_leaves(self.leaf_source, f["wt_ext"], f["cpos_frag"], f["score_frag"], f["score_msum"],
                                                      f["score_ref"], self.cfg.patch_size, self.cfg.embed_dim, self.cfg.num_heads,

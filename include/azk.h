@@ -290,6 +290,37 @@ int32_t azk_nn_embed_pool_leaves(const azk_leaf_source *src, const void *wt_ext_
                                  void *z_out_bf16_dev, int32_t num_heads, int32_t ksize, int32_t kp, int32_t embed_dim,
                                  float ln_eps, void *stream);
 
+/* azk_nn_embed_pool_compact(_leaves) - azk_nn_embed_pool restricted to the tokens a stone can reach (static softmax
+ * reference only).  A token whose k x k patch is empty is a constant of the weights, so its contribution to the weighted
+ * token sum and to the softmax denominator is precomputed over ALL tokens (z_all, l_all) and the kernel only evaluates the
+ * "dirty" tokens - adding their real contribution and subtracting their constant one in the same MFMA.  The per-token
+ * tables are indexed by token (T = rows*cols + 1 tokens; row T is the null token that pads the last tile):
+ *   cpos_tok    f32  [T+1][512]  bias + positional term (row 0: cls + pos[0]); row T = 0
+ *   score_tok   f32  [T+1][16]   score constants (column 15: row mean of cpos); row T = -1e30 in the head columns, 0 elsewhere
+ *   wconst_tok  f32  [T+1][16]   exp(score - ref) of the token taken as an empty-patch token; 0 beyond num_heads and in row T
+ *   xnconst_tok bf16 [T+1][512]  LayerNorm (no affine) of cpos_tok; row T = 0
+ *   z_all       f32  [4][8][64][4] sum_t bf16(wconst)[t][h] * xnconst[t][col] at [w][q][lane][j]: h = 4 (lane>>4) + j, col = 128 w + 8 (lane&15) + q
+ *   l_all       f32  [16]        sum_t wconst[t][h]
+ *   wt_frag     bf16 the conv weight with its 16 extra rows (azk_nn_embed_pool's wt_ext [512+16][kp]) in MFMA fragment order:
+ *               [33 column tiles][kp/32][64 lanes][8]: element [ct][s][l][i] = wt_ext[col(ct, l)][32 s + 8 (l>>4) + i],
+ *               col(ct, l) = 128 (ct>>3) + 8 (l&15) + (ct&7) for ct < 32, 512 + (l&15) for ct = 32
+ * sched_dev: int32 [2] work-queue words, zero before the first launch (each launch leaves them zero); one buffer per
+ * stream that may run the kernel concurrently.  Boards differ in cost, so workgroups pull them from that queue.
+ * Channels x ksize in {2, 3} x {3, 5}; kp = 32 ceil(channels ksize^2 / 32). */
+typedef struct azk_embed_pool_consts {
+    const void *wt_frag;
+    const float *cpos_tok, *score_tok, *wconst_tok;
+    const void *xnconst_tok;
+    const float *z_all, *l_all, *score_msum, *score_ref;
+    int32_t num_heads, ksize, kp, embed_dim;
+    float ln_eps;
+} azk_embed_pool_consts;
+int32_t azk_nn_embed_pool_compact(const void *boards_dev, int32_t boards_are_f32, const azk_embed_pool_consts *consts,
+                                  void *z_out_bf16_dev, int32_t n, int32_t channels, int32_t rows, int32_t cols,
+                                  const int32_t *n_valid_dev, int32_t *sched_dev, void *stream);
+int32_t azk_nn_embed_pool_compact_leaves(const azk_leaf_source *src, const azk_embed_pool_consts *consts, void *z_out_bf16_dev,
+                                         int32_t *sched_dev, void *stream);
+
 /* ---- cls-row tail (nn.py:54-60, 78-83 for the row the heads read): small-M GEMMs with a device-side row count.
  * azk_nn_gemm_rows: C = A W^T for A bf16 [m][lda] (first k columns), W = an nn.Linear weight [n_out][k] packed in MFMA
  *   B-fragment order: Wp[n_out/64][k/32][4][64][8] with element [g][s][c][lane][i] = W[64 g + 4 (lane&15) + c][32 s + 8 (lane>>4) + i]

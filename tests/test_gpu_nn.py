@@ -311,3 +311,96 @@ def test_embed_pool_from_engine_leaves_equals_gathered_batch():
     a, b = play(True), play(False)
     for (pa, ca), (pb, cb) in zip(a, b):
         assert np.array_equal(ca, cb) and pa.tobytes() == pb.tobytes()
+
+
+def _stone_boards(n, seed):
+    """Boards shaped like the benchmark's leaves (a cluster of ~5-40 stones) plus the edge cases: empty board, one stone in a
+    corner, a nearly full board (every token dirty)."""
+    rng = np.random.RandomState(seed)
+    x = np.zeros((n, 2, 15, 15), np.float32)
+    for b in range(3, n):
+        k = rng.randint(1, 45)
+        cells = [(7, 7)]
+        for _ in range(k):
+            r, c = cells[rng.randint(len(cells))]
+            r2, c2 = np.clip(r + rng.randint(-1, 2), 0, 14), np.clip(c + rng.randint(-1, 2), 0, 14)
+            cells.append((int(r2), int(c2)))
+        for i, (r, c) in enumerate(dict.fromkeys(cells)):
+            x[b, i & 1, r, c] = 1
+    x[1, 0, 0, 0] = 1
+    u = rng.rand(15, 15)
+    x[2, 0] = u < 0.45
+    x[2, 1] = (u >= 0.45) & (u < 0.9)
+    return torch.from_numpy(x)
+
+
+def test_compact_embed_pool_vs_torch_fp32_and_full_kernel():
+    """azk_nn_embed_pool_compact (only the tokens a stone can reach are evaluated; the empty-patch tokens enter as
+    precomputed constants) against the plain fp32 computation and against azk_nn_embed_pool, which evaluates every token.
+    Same tolerance as the full kernel (bf16 operands of the second MFMA, bf16 output): 1e-2 max / 1e-3 mean absolute on
+    O(0.1) values; the two kernels differ by fp32 reassociation and the constant tokens' host-side fp32 statistics only."""
+    import azk
+    cfg = NetConfig(15, 15, 2, 225, 5, 512, 8, 1)
+    net = PolicyValueNet(cfg, seed=5, device="cuda", dtype=torch.bfloat16, path="clsfold")
+    assert net.fused_embed_pool and net._compact is not None
+    f, hp = net._fold, net._hip
+    n = 700                                                         # more boards than resident workgroups: the queue is exercised
+    x = _stone_boards(n, 4).cuda().to(torch.bfloat16).contiguous()
+    cols = F.unfold(x.float(), kernel_size=5, padding=2).transpose(1, 2)
+    W = f["wt_ext"][:512, :50].float()
+    tok = torch.cat([torch.zeros(n, 1, 512, device="cuda"), cols @ W.t()], 1) + hp["cpos"]
+    xn = F.layer_norm(tok, (512,))
+    ref = torch.einsum("bth,btd->bhd", torch.softmax(xn @ f["m_n"].t(), 1), xn)
+    sched = azk.new_sched("cuda")
+    z = azk.nn_embed_pool_compact(x, net._compact, 15, 15, sched)
+    err = (z.float() - ref).abs()
+    assert err.max().item() < 1e-2 and err.mean().item() < 1e-3, (err.max().item(), err.mean().item())
+    zfull = azk.nn_embed_pool(x, f["wt_ext"], f["cpos_frag"], f["score_frag"], f["score_msum"], f["score_ref"], 15, 15, 5, 512, 8)
+    d = (z.float() - zfull.float()).abs()
+    assert d.max().item() < 6e-3 and d.mean().item() < 3e-4, (d.max().item(), d.mean().item())
+    torch.cuda.synchronize()
+    assert sched.tolist() == [0, 0]                                 # the queue words are left zero for the next launch
+    # scheduling does not change a bit: boards are independent work items
+    for _ in range(3):
+        assert torch.equal(azk.nn_embed_pool_compact(x, net._compact, 15, 15, sched), z)
+    assert torch.equal(azk.nn_embed_pool_compact(x.float().contiguous(), net._compact, 15, 15, sched), z)
+    # device-side count: rows past it are not produced
+    cnt = torch.tensor([301], dtype=torch.int32, device="cuda")
+    z2 = torch.full_like(z, 3.0)
+    rc = azk.lib().azk_nn_embed_pool_compact(x.data_ptr(), 0, azk.C.byref(net._compact.c), z2.data_ptr(), n, 2, 15, 15, cnt.data_ptr(),
+                                             sched.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    assert torch.equal(z2[:301], z[:301]) and bool((z2[301:] == 3.0).all())
+    torch.cuda.synchronize()
+    assert sched.tolist() == [0, 0]
+    # a permutation of the batch permutes the rows (no cross-board state)
+    perm = torch.randperm(n, device="cuda")
+    assert torch.equal(azk.nn_embed_pool_compact(x[perm].contiguous(), net._compact, 15, 15, sched), z[perm])
+
+
+def test_compact_embed_pool_from_engine_leaves_equals_gathered_batch():
+    """azk_nn_embed_pool_compact_leaves against azk_step_gather + azk_nn_embed_pool_compact on the same engine state."""
+    import azk
+    cfg = NetConfig(15, 15, 2, 225, 5, 512, 8, 1)
+    net = PolicyValueNet(cfg, seed=6, device="cuda", dtype=torch.bfloat16, path="clsfold")
+    G, A = 700, 225
+    eng = azk.Engine("gomoku", G, 64, size=15, leaf_dtype="bfloat16", cache_entries=64)
+    eng.reset_games()
+    noise, uni = eng.gen_noise(3, 0, 0)
+    eng.begin_search(noise)
+    logits = values = None
+    for s in range(24):
+        eng.step_tree(logits, values)
+        eng.step_gather()
+        logits, values = torch.randn(G, A, device="cuda") * 0.3, torch.tanh(torch.randn(G, device="cuda"))
+    n = int(eng.n_leaf.item())
+    assert 0 < n <= G
+    sched = azk.new_sched("cuda")
+    z_ref = azk.nn_embed_pool_compact(eng.leaf_boards[:n].contiguous(), net._compact, 15, 15, sched)
+    slots_ref = eng.leaf_slot.clone() if hasattr(eng, "leaf_slot") else None
+    eng.n_leaf.zero_()
+    z_new = azk.nn_embed_pool_compact_leaves(eng.leaf_source(), net._compact, sched)
+    torch.cuda.synchronize()
+    assert int(eng.n_leaf.item()) == n and sched.tolist() == [0, 0]
+    assert torch.equal(z_new[:n], z_ref)
+    eng.close()
