@@ -103,6 +103,40 @@ __device__ __forceinline__ void wave_argmax_first_lane63(T &v, int &idx) {
     }
 }
 
+// Wave-wide maximum without LDS-crossbar shuffles (four in-row DPP steps, row_bcast:15, row_bcast:31); the result is valid
+// in LANE 63 ONLY and is returned from there through readlane.  Inputs must not be NaN.
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ float dpp_keep_f32(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), CTRL, ROWMASK, 0xF, false));
+}
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double dpp_keep_f64(double v) {
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)b, (int)(unsigned)b, CTRL, ROWMASK, 0xF, false);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)(b >> 32), (int)(unsigned)(b >> 32), CTRL, ROWMASK, 0xF, false);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ float wave_max_f32(float v) {
+    v = fmaxf(v, dpp_keep_f32<0xB1, 0xF>(v));
+    v = fmaxf(v, dpp_keep_f32<0x4E, 0xF>(v));
+    v = fmaxf(v, dpp_keep_f32<0x141, 0xF>(v));
+    v = fmaxf(v, dpp_keep_f32<0x140, 0xF>(v));
+    v = fmaxf(v, dpp_keep_f32<0x142, 0xA>(v));
+    v = fmaxf(v, dpp_keep_f32<0x143, 0xC>(v));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ double wave_max_f64(double v) {
+    v = fmax(v, dpp_keep_f64<0xB1, 0xF>(v));
+    v = fmax(v, dpp_keep_f64<0x4E, 0xF>(v));
+    v = fmax(v, dpp_keep_f64<0x141, 0xF>(v));
+    v = fmax(v, dpp_keep_f64<0x140, 0xF>(v));
+    v = fmax(v, dpp_keep_f64<0x142, 0xA>(v));
+    v = fmax(v, dpp_keep_f64<0x143, 0xC>(v));
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, 63), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), 63);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
 __device__ __forceinline__ int wave_sum_i32(int v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);

@@ -142,15 +142,19 @@ __device__ __forceinline__ void backup_path(const Dev &d, size_t base, const int
 //   EXPAND: mcts.py:46-60 for the leaf selected by the previous step (softmax, noise, expand, backup)
 //   SELECT: mcts.py:18-37 (PUCT walk, terminal test + backup, valid moves, leaf hand-off)
 // ================================================================================================
-template <bool EXPAND, bool SELECT>
-__global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev d, const float *__restrict__ logits, const float *__restrict__ values) {
+// DBG: the AZK_TREE_ABLATE experiments and cycle stamps exist only in the <.., true> instantiation; the product kernel
+// (DBG = false) carries none of their branches.
+template <bool EXPAND, bool SELECT, bool DBG>
+__global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev dd, const float *__restrict__ logits, const float *__restrict__ values) {
+    const Dev &d = dd;
+    const int ablate = DBG ? dd.ablate : 0;
     const int g = blockIdx.x;
     const int lane = azk_lane();
     const GameDesc &gd = d.g;
     const int A = gd.action_dim, rc = gd.rc;
     const size_t base = (size_t)g * (size_t)d.cap;
     LdsView L = carve(gd, d.path_cap, d.table_size);
-    const bool stamp = (d.ablate & 16) != 0;
+    const bool stamp = (ablate & 16) != 0;
     long long t0 = stamp ? clock64() : 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
 
     // ---- every load whose address depends only on the game index is issued here, together: ONE memory round trip for
@@ -178,7 +182,7 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev d, const float *__restric
     if (EXPAND) {
         const int node = uniform_i32(e_node);
         if (node >= 0) {
-            const bool xst = (d.ablate & 1024) != 0;              // debug only: cycle stamps of the expansion's sub-phases
+            const bool xst = (ablate & 1024) != 0;              // debug only: cycle stamps of the expansion's sub-phases
             long long x0 = 0, x1 = 0, x2 = 0, x3 = 0, x4 = 0;
             if (xst) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); x0 = clock64(); }
             const int slot = uniform_i32(e_slot);
@@ -219,7 +223,7 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev d, const float *__restric
             for (int k4 = 0; k4 < KSL; k4++) {
                 if (AZK_WAVE * k4 >= A) break;
                 const int i = lane + AZK_WAVE * k4;
-                const float ev = (d.ablate & 1) ? 1.0f : azk_exp_det(lgv[k4]);
+                const float ev = (ablate & 1) ? 1.0f : azk_exp_det(lgv[k4]);
                 if (i < A) L.e[i] = ev;
             }
             __syncthreads();
@@ -299,13 +303,43 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev d, const float *__restric
         long long seg_a = 0, seg_b = 0, seg_c = 0, seg_d = 0, seg_t = 0;      // debug only (ablate & 64)
         for (;;) {                                                    // mcts.py:20-23
             const int nch = meta_nch(nmeta);
-            if (nch <= 0 || (d.ablate & 2)) break;
-            if (d.ablate & 64) seg_t = clock64();
+            if (nch <= 0 || (ablate & 2)) break;
+            if (ablate & 64) seg_t = clock64();
             const bool f64 = node == 0 && root_f64;
             double bu64 = 0.0;
             float bu32 = 0.f;
             int best = 0x7fffffff, bN = 0, bfc = -1;
             uint32_t bmeta = 0;
+            if (nch <= AZK_WAVE && !(ablate & 2048)) {
+                // the common case (a Gomoku position has ~50 candidate moves): one candidate per lane, one load per column, the
+                // argmax as a DPP maximum + ballot - "first maximum wins" (node.py:47) is the lowest lane holding the maximum
+                const bool valid = lane < nch;
+                const size_t ci = base + fc + (valid ? lane : 0);
+                const int Nc = d.N[ci];
+                const double Wc = d.W[ci];
+                const uint32_t mc = d.meta[ci];
+                const int fcc = d.first_child[ci];
+                const float P32 = d.P[ci];
+                unsigned long long winners;
+                if (f64) {                                            // root after Dirichlet mixing: float64 priors => float64 UCB
+                    const double P64 = d.rootP[(size_t)g * rc + (valid ? lane : 0)];
+                    const double s = sqrt((double)Np);
+                    const double u0 = P64 * s / (double)(Nc + 1);
+                    const double q = Wc / (double)Nc;                 // N = 0: inf/nan, discarded by the select
+                    const double u = valid ? (Nc != 0 ? q + u0 : u0) : -__builtin_huge_val();
+                    const double um = wave_max_f64(u);               // (all lanes take part: never under the short-circuit below)
+                    winners = __ballot(valid & (u == um));
+                } else {                                              // float32 priors => float32 UCB (numpy >= 2)
+                    const float s = (float)sqrt((double)Np);
+                    const float u0 = (P32 * s) / (float)(Nc + 1);
+                    const float q = (float)(Wc / (double)Nc);
+                    const float u = valid ? (Nc != 0 ? q + u0 : u0) : -__builtin_huge_valf();
+                    const float um = wave_max_f32(u);
+                    winners = __ballot(valid & (u == um));
+                }
+                best = __ffsll((long long)winners) - 1;
+                bN = Nc; bmeta = mc; bfc = fcc;
+            } else {
             // all of this level's loads are issued before any arithmetic: 4 candidates per lane per 256-child chunk
             for (int c0 = 0; c0 < nch; c0 += 4 * AZK_WAVE) {
                 int Nc[4], fcc[4];
@@ -327,7 +361,7 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev d, const float *__restric
                         P64[k] = d.rootP[(size_t)g * rc + (i < nch ? i : 0)];
                     }
                 }
-                if (d.ablate & 64) {   // debug only: time the level's memory round trip separately from its arithmetic
+                if (ablate & 64) {   // debug only: time the level's memory round trip separately from its arithmetic
                     const long long ta = clock64();
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     seg_a += clock64() - ta;
@@ -363,17 +397,18 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev d, const float *__restric
                     }
                 }
             }
-            if (d.ablate & 64) { const long long tn = clock64(); seg_b += tn - seg_t; seg_t = tn; }
+            if (ablate & 64) { const long long tn = clock64(); seg_b += tn - seg_t; seg_t = tn; }
             if (f64) wave_argmax_first_lane63<double>(bu64, best);
             else wave_argmax_first_lane63<float>(bu32, best);
             best = __builtin_amdgcn_readlane(best, 63);               // DPP reduction: the wave's result lives in lane 63
+            }
             const int wl = best & 63;                                 // the lane whose own best candidate won
             scanned += nch;
             const int child = fc + best;
             Np = __builtin_amdgcn_readlane(bN, wl);
             nmeta = (uint32_t)__builtin_amdgcn_readlane((int)bmeta, wl);
             fc = __builtin_amdgcn_readlane(bfc, wl);
-            if (d.ablate & 64) { const long long tn = clock64(); seg_c += tn - seg_t; seg_t = tn; }
+            if (ablate & 64) { const long long tn = clock64(); seg_c += tn - seg_t; seg_t = tn; }
             const int cellc = meta_cell(nmeta);
             const int mover = (root_player + depth) & 1;
             depth++;
@@ -387,7 +422,7 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev d, const float *__restric
             }
             if (depth + 1 >= d.path_cap) break;
         }
-        if ((d.ablate & 64) && lane == 0) {
+        if ((ablate & 64) && lane == 0) {
             long long *qq = d.dbg + (size_t)g * 8;
             qq[0] += seg_a; qq[1] += seg_b; qq[2] += seg_c; qq[3] += seg_d; qq[5] += depth; qq[6] += 1;
         }
@@ -416,8 +451,8 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev d, const float *__restric
         }
         if (stamp) t3 = clock64();
         int nv;
-        if (d.ablate & 4) { nv = 1; if (lane == 0) L.moves[0] = (int16_t)(gd.rc / 2); __syncthreads(); }
-        else nv = azk_valid_moves(L.board, gd, L.moves, L.ms, (d.ablate & 8) != 0, (d.ablate & 32) ? d.dbg + (size_t)g * 8 : nullptr);  // mcts.py:34
+        if (ablate & 4) { nv = 1; if (lane == 0) L.moves[0] = (int16_t)(gd.rc / 2); __syncthreads(); }
+        else nv = azk_valid_moves(L.board, gd, L.moves, L.ms, (ablate & 8) != 0, (ablate & 32) ? d.dbg + (size_t)g * 8 : nullptr);  // mcts.py:34
         if (stamp) t4 = clock64();
         for (int i = lane; i < nv; i += AZK_WAVE) d.leaf_moves[(size_t)g * rc + i] = L.moves[i];
         for (int i = lane; i < rc; i += AZK_WAVE) d.leaf_cells[(size_t)g * d.rc_pad + i] = L.board[i];
@@ -454,7 +489,7 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev d, const float *__restric
                 long long *q = d.dbg + (size_t)g * 8;
                 const long long tend = clock64();
                 q[0] += t1 - t0; q[1] += t2 - t1; q[2] += t3 - t2; q[3] += t4 - t3; q[4] += tend - t4; q[5] += depth; q[6] += 1;
-                if (!(d.ablate & 64) && tend - t0 > q[7]) q[7] = tend - t0;   // slowest simulation of this game
+                if (!(ablate & 64) && tend - t0 > q[7]) q[7] = tend - t0;   // slowest simulation of this game
             }
         }
     }
@@ -1242,9 +1277,13 @@ static int32_t launch_tree(azk_engine *e, bool expand, bool select, const float 
     const Dev &d = e->d;
     if (expand && (!logits || !values)) { e->err = "expand needs logits_dev and values_dev"; return AZK_ERR_ARG; }
     if (select && (!leaf_boards || !n_leaf)) { e->err = "select needs leaf_boards_dev and n_leaf_dev"; return AZK_ERR_ARG; }
-    if (expand && select) k_tree<true, true><<<d.G, AZK_WAVE, d.lds_bytes, st>>>(d, logits, values);
-    else if (expand) k_tree<true, false><<<d.G, AZK_WAVE, d.lds_bytes, st>>>(d, logits, values);
-    else k_tree<false, true><<<d.G, AZK_WAVE, d.lds_bytes, st>>>(d, logits, values);
+    if (d.ablate) {
+        if (expand && select) k_tree<true, true, true><<<d.G, AZK_WAVE, d.lds_bytes, st>>>(d, logits, values);
+        else if (expand) k_tree<true, false, true><<<d.G, AZK_WAVE, d.lds_bytes, st>>>(d, logits, values);
+        else k_tree<false, true, true><<<d.G, AZK_WAVE, d.lds_bytes, st>>>(d, logits, values);
+    } else if (expand && select) k_tree<true, true, false><<<d.G, AZK_WAVE, d.lds_bytes, st>>>(d, logits, values);
+    else if (expand) k_tree<true, false, false><<<d.G, AZK_WAVE, d.lds_bytes, st>>>(d, logits, values);
+    else k_tree<false, true, false><<<d.G, AZK_WAVE, d.lds_bytes, st>>>(d, logits, values);
     HIPCHK(e, hipGetLastError());
     if (select) {
         k_gather<<<d.G, AZK_WAVE, 0, st>>>(d, leaf_boards, n_leaf);
@@ -1274,8 +1313,11 @@ int32_t azk_step_tree(azk_engine *e, const float *logits_dev, const float *value
     const Dev &d = e->d;
     hipStream_t st = (hipStream_t)stream;
     if (logits_dev && !values_dev) { e->err = "values_dev missing"; return AZK_ERR_ARG; }
-    if (logits_dev) k_tree<true, true><<<d.G, AZK_WAVE, d.lds_bytes, st>>>(d, logits_dev, values_dev);
-    else k_tree<false, true><<<d.G, AZK_WAVE, d.lds_bytes, st>>>(d, nullptr, nullptr);
+    if (d.ablate) {
+        if (logits_dev) k_tree<true, true, true><<<d.G, AZK_WAVE, d.lds_bytes, st>>>(d, logits_dev, values_dev);
+        else k_tree<false, true, true><<<d.G, AZK_WAVE, d.lds_bytes, st>>>(d, nullptr, nullptr);
+    } else if (logits_dev) k_tree<true, true, false><<<d.G, AZK_WAVE, d.lds_bytes, st>>>(d, logits_dev, values_dev);
+    else k_tree<false, true, false><<<d.G, AZK_WAVE, d.lds_bytes, st>>>(d, nullptr, nullptr);
     HIPCHK(e, hipGetLastError());
     return AZK_OK;
 }
