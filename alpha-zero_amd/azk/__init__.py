@@ -29,6 +29,7 @@ SYMBOLS = [
     "azk_vanilla_set_rng", "azk_vanilla_get_rng", "azk_vanilla_search", "azk_nn_embed_pool",
     "azk_nn_gemm_rows", "azk_nn_layernorm_sum", "azk_nn_heads_finalize_sum", "azk_nn_ln_heads",
     "azk_leaf_source_of", "azk_nn_embed_pool_leaves", "azk_nn_embed_pool_compact", "azk_nn_embed_pool_compact_leaves",
+    "azk_nn_tail_gemm",
 ]
 
 
@@ -55,6 +56,16 @@ class EmbedPoolConsts(C.Structure):
                 ("xnconst_tok", C.c_void_p), ("z_all", C.c_void_p), ("l_all", C.c_void_p), ("score_msum", C.c_void_p),
                 ("score_ref", C.c_void_p), ("num_heads", C.c_int32), ("ksize", C.c_int32), ("kp", C.c_int32),
                 ("embed_dim", C.c_int32), ("ln_eps", C.c_float)]
+
+
+class TailGemm(C.Structure):
+    """azk_tail_gemm (include/azk.h): one link of the cls-row tail."""
+    _fields_ = [("a_bf16", C.c_void_p), ("lda", C.c_int32), ("a_batch_stride", C.c_int32), ("w_packed", C.c_void_p),
+                ("m", C.c_int32), ("n_out", C.c_int32), ("k", C.c_int32), ("nbatch", C.c_int32), ("n_valid", C.c_void_p),
+                ("bias", C.c_void_p), ("layernorm_a", C.c_int32), ("epilogue", C.c_int32), ("ln_eps", C.c_float),
+                ("a_stats", C.c_void_p), ("a_stats_groups", C.c_int32), ("stats_out", C.c_void_p),
+                ("out_bf16", C.c_void_p), ("ldo", C.c_int32), ("resid_bf16", C.c_void_p), ("ldr", C.c_int32),
+                ("logits_out", C.c_void_p), ("values_out", C.c_void_p), ("action_dim", C.c_int32)]
 
 
 class Counters(C.Structure):
@@ -139,6 +150,7 @@ def lib():
     L.azk_nn_embed_pool_leaves.argtypes = [C.POINTER(LeafSource), vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, C.c_float, vp]
     L.azk_nn_embed_pool_compact.argtypes = [vp, i32, C.POINTER(EmbedPoolConsts), vp, i32, i32, i32, i32, vp, vp, vp]
     L.azk_nn_embed_pool_compact_leaves.argtypes = [C.POINTER(LeafSource), C.POINTER(EmbedPoolConsts), vp, vp, vp]
+    L.azk_nn_tail_gemm.argtypes = [C.POINTER(TailGemm), vp]
     L.azk_nn_ln_heads.argtypes = [vp, vp, vp, C.c_float, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]
     L.azk_nn_gemm_rows.argtypes = [vp, i32, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]
     L.azk_nn_layernorm_sum.argtypes = [vp, i32, i32, vp, vp, vp, vp, C.c_float, vp, vp, vp, i32, i32, vp, vp]
@@ -647,6 +659,41 @@ def nn_embed_pool_compact_leaves(src, tables, sched, timers=None):
     if rc != 0:
         raise AzkError(f"azk_nn_embed_pool_compact_leaves failed ({rc})")
     return z
+
+
+TAIL_BF16, TAIL_GELU, TAIL_RESID, TAIL_HEADS = 0, 1, 2, 3
+
+
+def nn_tail_gemm(a, w_packed, n_out, k, epilogue=TAIL_BF16, nbatch=1, a_batch_stride=0, bias=None, out=None, resid=None,
+                 a_stats=None, stats_out=None, logits=None, values=None, action_dim=0, count=None, eps=1e-5):
+    """One link of the cls-row tail (azk_nn_tail_gemm): a bf16 [m, lda] x packed weights -> out bf16 [m, nbatch * n_out] (or the
+    heads' float32 logits / values).  a_stats [m, groups, 2]: A is LayerNorm(a) (affine folded by the caller), its row statistics
+    coming from the producer's stats_out."""
+    torch = _torch()
+    assert a.dtype == torch.bfloat16 and a.stride(-1) == 1 and a.dim() == 2
+    d = TailGemm()
+    d.a_bf16, d.lda, d.a_batch_stride, d.w_packed = a.data_ptr(), a.stride(0), int(a_batch_stride), w_packed.data_ptr()
+    d.m, d.n_out, d.k, d.nbatch = a.shape[0], int(n_out), int(k), int(nbatch)
+    d.n_valid = count.data_ptr() if count is not None else None
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.layernorm_a, d.epilogue, d.ln_eps = (1 if a_stats is not None else 0), int(epilogue), float(eps)
+    if a_stats is not None:
+        assert a_stats.dtype == torch.float32 and a_stats.dim() == 3 and a_stats.shape[2] == 2 and a_stats.is_contiguous()
+        d.a_stats, d.a_stats_groups = a_stats.data_ptr(), a_stats.shape[1]
+    if stats_out is not None:
+        assert stats_out.dtype == torch.float32 and tuple(stats_out.shape) == (a.shape[0], nbatch * n_out // 64, 2) and stats_out.is_contiguous()
+        d.stats_out = stats_out.data_ptr()
+    if out is not None:
+        assert out.dtype == torch.bfloat16 and out.stride(-1) == 1
+        d.out_bf16, d.ldo = out.data_ptr(), out.stride(0)
+    if resid is not None:
+        d.resid_bf16, d.ldr = resid.data_ptr(), resid.stride(0)
+    if logits is not None:
+        assert logits.dtype == torch.float32 and values.dtype == torch.float32 and logits.is_contiguous()
+        d.logits_out, d.values_out, d.action_dim = logits.data_ptr(), values.data_ptr(), int(action_dim)
+    rc = lib().azk_nn_tail_gemm(C.byref(d), _stream())
+    if rc != 0:
+        raise AzkError(f"azk_nn_tail_gemm failed ({rc})")
 
 
 class _ReplayUnpickler(__import__("pickle").Unpickler):

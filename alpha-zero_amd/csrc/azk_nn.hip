@@ -1999,3 +1999,249 @@ extern "C" int32_t azk_nn_heads_finalize_sum(const float *partials_dev, int32_t 
                                                                values_out_dev, n_valid_dev);
     return hipGetLastError() == hipSuccess ? AZK_OK : AZK_ERR_HIP;
 }
+
+// =====================================================================================================
+// k_tail_gemm: the cls-row tail (nn.py:54-60, 78-83 for the one row the heads read) as a chain of latency-shaped small
+// GEMMs.  At ~1000 live rows every GEMM of the tail is a few MFLOP per CU: what costs time is the number of dependent
+// memory round trips, so a wave issues EVERY load of its K chunk (A rows and weight fragments) before its first MFMA -
+// one round trip per 256..512 columns of K - and a second chunk is already in flight while the first is multiplied.
+//   wave tile 16 RT rows x 64 columns, no LDS, no barriers; A fragments straight from the row-major activations, B
+//   fragments from weights packed in fragment order (pack_linear_weight: one 16-byte load per fragment);
+//   AMODE 1: A = LayerNorm(rows) with the affine folded into weight and bias by the caller.  The row statistics come from the
+//            PRODUCING GEMM: its epilogue leaves, per row and 64-column group, the (sum, sum of squares) of the bf16 values it
+//            stored; the consumer adds the groups in a fixed order (deterministic, no atomics) and normalises its fragments on
+//            the fly - LayerNorm costs no pass over the rows at all;
+//   batched (block-diagonal) form: batch b reads A columns [b a_batch, b a_batch + K), its own weight block, and writes output
+//            columns [b N, (b+1) N) - the per-head value projection (8 heads x [64 x 512]) in one launch;
+//   epilogues: bf16 (+ bias), bf16 GELU(+ bias), bf16 (+ bias + residual), merged policy / value heads (float32 logits, tanh).
+// Rows at or beyond *count are neither read nor written; the grid is sized for the full buffer and idle workgroups exit.
+// =====================================================================================================
+namespace {
+
+struct TailArgs {
+    const unsigned short *A; int lda, a_batch;
+    const uint4 *Wp; long long w_batch;          // uint4 elements between batches
+    int M, N, nbatch;                            // N = output columns per batch (multiple of 64 * NWC)
+    const int *count;
+    const float *bias;                           // [nbatch * N] or null
+    unsigned short *out; int ldo;
+    const unsigned short *resid; int ldr;
+    float ln_eps;
+    const float *stats_in; int stats_groups;     // AMODE 1: [M][stats_groups][2] partial (sum, sum of squares) of every A row, written by the producer
+    float *stats_out;                            // optional: this GEMM's own partials [M][nbatch * N / 64][2] of the bf16-rounded output rows
+    float *logits, *values; int action_dim;
+};
+
+enum { TAIL_EPI_BF16 = 0, TAIL_EPI_GELU = 1, TAIL_EPI_RESID = 2, TAIL_EPI_HEADS = 3 };
+
+// nn.GELU (erf form) with erf from Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below the bf16 result's resolution):
+// a dozen instructions instead of libm's erff.
+__device__ __forceinline__ float gelu_erf(float x) {
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float erf_abs = 1.0f - poly * __expf(-z * z);
+    return 0.5f * x * (1.0f + copysignf(erf_abs, x));
+}
+
+// NWK > 1: the K range is split over NWK waves of the workgroup (every load of the whole K in flight at once, one round trip),
+// their partial accumulators meet in LDS and wave 0 runs the epilogue.
+template <int RT, int KCH, int NCH, int AMODE, int EPI, int NWR, int NWC, int NWK>
+__global__ __launch_bounds__(64 * NWR * NWC * NWK, 1) void k_tail_gemm(TailArgs a) {
+    constexpr int K = 32 * KCH * NCH * NWK, KS = KCH * NCH * NWK;
+    static_assert(NWK == 1 || (NWR == 1 && NWC == 1), "split-K workgroups hold one wave tile");
+    __shared__ f32x4 kred[NWK > 1 ? (NWK - 1) * RT * 4 * 64 : 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, l4 = lane >> 4;
+    const int wk = NWK > 1 ? wave : 0, wrc = NWK > 1 ? 0 : wave;
+    const int wr = wrc / NWC, wc = wrc - wr * NWC;
+    constexpr int WROWS = 16 * RT * NWR;
+    // the items cover the live rows only (measured: letting the dead half of the buffer issue its loads too costs 40-60 % - these
+    // GEMMs move ~100 KB per wave through L2 and are bound by that traffic, not by the count's extra round trip)
+    const int nvalid = a.count ? min(a.M, *a.count) : a.M;
+    const int rtiles = (nvalid + WROWS - 1) / WROWS, ctiles = a.N / (64 * NWC);
+    const int nitems = rtiles * ctiles * a.nbatch;
+    union BF { uint4 u; bf16x8 v; };
+    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+        if (NWK > 1 && item != (int)blockIdx.x) __syncthreads();      // wave 0 is done with the previous item's partial sums
+        const int ct = item % ctiles, r2 = item / ctiles, rt = r2 % rtiles, b = r2 / rtiles;
+        const int row0 = rt * WROWS + wr * 16 * RT, g = ct * NWC + wc;
+        const unsigned short *ap[RT];
+#pragma unroll
+        for (int i = 0; i < RT; i++) ap[i] = a.A + (size_t)min(row0 + 16 * i + l15, a.M - 1) * a.lda + (size_t)b * a.a_batch + 8 * l4 + 32 * KCH * NCH * wk;
+        const uint4 *bp = a.Wp + (size_t)b * a.w_batch + ((size_t)g * KS + (size_t)KCH * NCH * wk) * 4 * 64 + lane;
+        f32x4 acc[RT][4];
+#pragma unroll
+        for (int i = 0; i < RT; i++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) acc[i][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        BF af[2][RT][KCH], bf[2][KCH][4];
+        auto fetch = [&](int ch, int buf) {
+#pragma unroll
+            for (int s = 0; s < KCH; s++) {
+#pragma unroll
+                for (int i = 0; i < RT; i++) af[buf][i][s].u = *(const uint4 *)(ap[i] + 32 * (ch * KCH + s));
+#pragma unroll
+                for (int c = 0; c < 4; c++) bf[buf][s][c].u = bp[((ch * KCH + s) * 4 + c) * 64];
+            }
+        };
+        fetch(0, 0);
+        // AMODE 1: the row statistics were left by the producing GEMM as per-column-group partial sums (of the bf16 values this
+        // wave now reads): summed here in a fixed order - deterministic, no atomics, no second pass over the rows
+        float rstd[RT], shift[RT];
+        if (AMODE == 1) {
+#pragma unroll
+            for (int i = 0; i < RT; i++) {
+                const float *sp = a.stats_in + (size_t)min(row0 + 16 * i + l15, a.M - 1) * a.stats_groups * 2;
+                float s1 = 0.f, s2 = 0.f;
+                for (int q = 0; q < a.stats_groups; q++) { s1 += sp[2 * q]; s2 += sp[2 * q + 1]; }
+                const float mean = s1 * (1.0f / K);
+                rstd[i] = rsqrtf(fmaxf(s2 * (1.0f / K) - mean * mean, 0.f) + a.ln_eps);
+                shift[i] = -mean * rstd[i];
+            }
+        }
+#pragma unroll
+        for (int ch = 0; ch < NCH; ch++) {
+            const int cur = ch & 1;
+            if (ch + 1 < NCH) fetch(ch + 1, cur ^ 1);
+            __builtin_amdgcn_sched_barrier(0);            // the next chunk's loads are issued before this chunk's first MFMA
+            if (AMODE == 1) {
+#pragma unroll
+                for (int i = 0; i < RT; i++)
+#pragma unroll
+                    for (int s = 0; s < KCH; s++) {
+                        const unsigned w4[4] = {af[cur][i][s].u.x, af[cur][i][s].u.y, af[cur][i][s].u.z, af[cur][i][s].u.w};
+                        float v[8];
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            v[2 * q] = __uint_as_float(w4[q] << 16) * rstd[i] + shift[i];
+                            v[2 * q + 1] = __uint_as_float(w4[q] & 0xffff0000u) * rstd[i] + shift[i];
+                        }
+                        af[cur][i][s].u = pack8(v);
+                    }
+            }
+#pragma unroll
+            for (int s = 0; s < KCH; s++)
+#pragma unroll
+                for (int i = 0; i < RT; i++)
+#pragma unroll
+                    for (int c = 0; c < 4; c++) acc[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[cur][i][s].v, bf[cur][s][c].v, acc[i][c], 0, 0, 0);
+        }
+        if (row0 >= nvalid) continue;                          // (uniform per wave tile; with NWK > 1 per workgroup)
+        if (NWK > 1) {
+            if (wave > 0) {
+#pragma unroll
+                for (int i = 0; i < RT; i++)
+#pragma unroll
+                    for (int c = 0; c < 4; c++) kred[((wave - 1) * RT * 4 + i * 4 + c) * 64 + lane] = acc[i][c];
+            }
+            __syncthreads();
+            if (wave > 0) continue;
+#pragma unroll
+            for (int w = 1; w < NWK; w++)
+#pragma unroll
+                for (int i = 0; i < RT; i++)
+#pragma unroll
+                    for (int c = 0; c < 4; c++) acc[i][c] += kred[((w - 1) * RT * 4 + i * 4 + c) * 64 + lane];
+        }
+        const int col0 = b * a.N + 64 * g + 4 * l15;          // a lane's four accumulators of a row are four consecutive output columns
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (a.bias) bv = *(const f32x4 *)(a.bias + col0);
+#pragma unroll
+        for (int i = 0; i < RT; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int row = row0 + 16 * i + 4 * l4 + j;
+                if (row >= nvalid) continue;
+                f32x4 v = {acc[i][0][j] + bv[0], acc[i][1][j] + bv[1], acc[i][2][j] + bv[2], acc[i][3][j] + bv[3]};
+                if (EPI == TAIL_EPI_HEADS) {                          // nn.py:82-83
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        const int col = col0 + c;
+                        if (col < a.action_dim) a.logits[(size_t)row * a.action_dim + col] = v[c];
+                        else if (col == a.action_dim) a.values[row] = tanhf(v[c]);
+                    }
+                } else {
+                    if (EPI == TAIL_EPI_GELU) {
+#pragma unroll
+                        for (int c = 0; c < 4; c++) v[c] = gelu_erf(v[c]);                                      // nn.GELU (erf form)
+                    }
+                    if (EPI == TAIL_EPI_RESID) {
+                        const uint2 rr = *(const uint2 *)(a.resid + (size_t)row * a.ldr + col0);
+                        v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
+                        v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
+                    }
+                    union { bf16x4 b4; uint2 u; } o;
+                    o.b4 = __builtin_convertvector(v, bf16x4);
+                    *(uint2 *)(a.out + (size_t)row * a.ldo + col0) = o.u;
+                }
+            }
+        if (EPI != TAIL_EPI_HEADS && a.stats_out) {
+            // partial LayerNorm statistics of the rows just written, over this wave's 64 columns, from the ROUNDED values
+            const int ngr = a.nbatch * (a.N >> 6), gr = b * (a.N >> 6) + g;
+#pragma unroll
+            for (int i = 0; i < RT; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int row = row0 + 16 * i + 4 * l4 + j;
+                    f32x4 v = {acc[i][0][j] + bv[0], acc[i][1][j] + bv[1], acc[i][2][j] + bv[2], acc[i][3][j] + bv[3]};
+                    if (EPI == TAIL_EPI_GELU) {
+#pragma unroll
+                        for (int c = 0; c < 4; c++) v[c] = gelu_erf(v[c]);
+                    }
+                    if (EPI == TAIL_EPI_RESID && row < nvalid) {
+                        const uint2 rr = *(const uint2 *)(a.resid + (size_t)row * a.ldr + col0);
+                        v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
+                        v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
+                    }
+                    const bf16x4 rb = __builtin_convertvector(v, bf16x4);
+                    const f32x4 vr = __builtin_convertvector(rb, f32x4);
+                    const float p1 = row16_sum((vr[0] + vr[1]) + (vr[2] + vr[3]));
+                    const float p2 = row16_sum((vr[0] * vr[0] + vr[1] * vr[1]) + (vr[2] * vr[2] + vr[3] * vr[3]));
+                    if (l15 == 0 && row < nvalid) *(f32x2 *)(a.stats_out + ((size_t)row * ngr + gr) * 2) = f32x2{p1, p2};
+                }
+        }
+    }
+}
+
+template <int RT, int KCH, int NCH, int AMODE, int EPI, int NWR, int NWC, int NWK = 1>
+int launch_tail(const TailArgs &a, hipStream_t st) {
+    const long long items = (long long)((a.M + 16 * RT * NWR - 1) / (16 * RT * NWR)) * (a.N / (64 * NWC)) * a.nbatch;
+    const unsigned blocks = (unsigned)(items < 8192 ? items : 8192);
+    k_tail_gemm<RT, KCH, NCH, AMODE, EPI, NWR, NWC, NWK><<<blocks, 64 * NWR * NWC * NWK, 0, st>>>(a);
+    return hipGetLastError() == hipSuccess ? AZK_OK : AZK_ERR_HIP;
+}
+}  // namespace
+
+extern "C" int32_t azk_nn_tail_gemm(const azk_tail_gemm *t, void *stream) {
+    if (!t || !t->a_bf16 || !t->w_packed || t->m < 0 || t->n_out < 64 || (t->n_out & 63) || t->nbatch < 1) return AZK_ERR_ARG;
+    if ((t->k != 512 && t->k != 2048) || t->lda < t->k || (t->lda & 7) || (t->a_batch_stride & 7)) return AZK_ERR_ARG;
+    if (t->epilogue < 0 || t->epilogue > 3 || (t->layernorm_a && (t->k != 512 || !t->a_stats || t->a_stats_groups < 1))) return AZK_ERR_ARG;
+    if (t->epilogue == TAIL_EPI_HEADS ? (!t->logits_out || !t->values_out || t->action_dim + 1 > t->n_out * t->nbatch) : (!t->out_bf16 || t->ldo < t->n_out * t->nbatch || (t->ldo & 3)))
+        return AZK_ERR_ARG;
+    if (t->epilogue == TAIL_EPI_RESID && (!t->resid_bf16 || (t->ldr & 3))) return AZK_ERR_ARG;
+    if (t->m == 0) return AZK_OK;
+    TailArgs a;
+    a.A = (const unsigned short *)t->a_bf16; a.lda = t->lda; a.a_batch = t->a_batch_stride; a.Wp = (const uint4 *)t->w_packed;
+    a.w_batch = (long long)(t->n_out / 64) * (t->k / 32) * 4 * 64;
+    a.M = t->m; a.N = t->n_out; a.nbatch = t->nbatch; a.count = t->n_valid; a.bias = t->bias; a.out = (unsigned short *)t->out_bf16; a.ldo = t->ldo;
+    a.resid = (const unsigned short *)t->resid_bf16; a.ldr = t->ldr; a.ln_eps = t->ln_eps; a.logits = t->logits_out; a.values = t->values_out;
+    a.action_dim = t->action_dim; a.stats_in = t->a_stats; a.stats_groups = t->a_stats_groups; a.stats_out = t->stats_out;
+    hipStream_t st = (hipStream_t)stream;
+    const bool wide = t->n_out % 128 == 0 && t->n_out >= 1024;          // many column groups: 2 x 2 waves share A rows and weight fragments in L1
+    if (t->k == 512) {
+        if (t->layernorm_a) {
+            if (t->epilogue == TAIL_EPI_GELU) return wide ? launch_tail<2, 16, 1, 1, TAIL_EPI_GELU, 2, 2>(a, st) : launch_tail<2, 16, 1, 1, TAIL_EPI_GELU, 1, 1>(a, st);
+            if (t->epilogue == TAIL_EPI_HEADS) return launch_tail<1, 16, 1, 1, TAIL_EPI_HEADS, 1, 1>(a, st);
+            if (t->epilogue == TAIL_EPI_BF16) return launch_tail<2, 16, 1, 1, TAIL_EPI_BF16, 1, 1>(a, st);
+            return AZK_ERR_ARG;
+        }
+        if (t->epilogue == TAIL_EPI_BF16) return launch_tail<2, 16, 1, 0, TAIL_EPI_BF16, 1, 1>(a, st);
+        if (t->epilogue == TAIL_EPI_GELU) return wide ? launch_tail<2, 16, 1, 0, TAIL_EPI_GELU, 2, 2>(a, st) : launch_tail<2, 16, 1, 0, TAIL_EPI_GELU, 1, 1>(a, st);
+        if (t->epilogue == TAIL_EPI_RESID) return launch_tail<2, 16, 1, 0, TAIL_EPI_RESID, 1, 1>(a, st);
+        return launch_tail<2, 16, 1, 0, TAIL_EPI_HEADS, 1, 1>(a, st);
+    }
+    // k = 2048: four waves of a workgroup take 512 columns of K each
+    if (t->epilogue == TAIL_EPI_RESID) return launch_tail<2, 16, 1, 0, TAIL_EPI_RESID, 1, 1, 4>(a, st);
+    if (t->epilogue == TAIL_EPI_BF16) return launch_tail<2, 16, 1, 0, TAIL_EPI_BF16, 1, 1, 4>(a, st);
+    return AZK_ERR_ARG;
+}

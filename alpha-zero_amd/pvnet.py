@@ -124,6 +124,9 @@ class PolicyValueNet:
         self.leaf_source = None         # azk.LeafSource of the engine being stepped: the fused kernel reads the pending leaves itself
         self.fuse_ln_heads = True       # final LayerNorm + heads + finalize as one hand-written launch (needs hip_tail's packed weights)
         self.fused_embed_pool = False   # set by _prepare_folded when azk_nn_embed_pool covers this configuration
+        self.chain_tail = False         # set by _prepare_folded when azk_nn_tail_gemm covers this configuration
+        self.use_chain_tail = True
+        self._tail_ws = {}              # workspace of the tail chain, keyed by the row count
         self._compact = None            # azk.EmbedPoolTables when the compacting kernel covers this configuration (static softmax reference)
         self.use_compact = True
         self._scheds = {}               # work-queue words of the compacting kernel, one buffer per board source (= per stepping stream)
@@ -271,6 +274,18 @@ class PolicyValueNet:
             bhg[:Ap] = Wh @ bf_ + bh
             f["bhG_f"] = bhg
             self.hip_tail = D in (256, 512) and (H * D) % 256 == 0
+            # the chain of latency-shaped GEMMs (azk_nn_tail_gemm): the composed [H*D -> D] projection is applied in its factors -
+            # per-head value projection Wv'_h (dh x D, block diagonal over heads) then the output projection Wo - 4x fewer flops
+            # and weight bytes than Wcomb; both LayerNorm affines folded into the consuming weights and biases
+            self.chain_tail = D == 512 and dh == 64
+            if self.chain_tail:
+                g2, b2 = m[b + "norm2.weight"].to(dev), m[b + "norm2.bias"].to(dev)
+                W0, b0_ = m[b + "mlp.0.weight"].to(dev), m[b + "mlp.0.bias"].to(dev)
+                f["WvHP"] = torch.cat([azk.pack_linear_weight(Wvn[h]).reshape(-1) for h in range(H)])       # H blocks of [dh=64][D]
+                f["WoP"] = azk.pack_linear_weight(Wo)
+                f["W0GP"] = azk.pack_linear_weight(W0 * g2[None, :])
+                f["b0G_f"] = (W0 @ b2 + b0_).float().contiguous()
+                f["b3_f"] = m[b + "mlp.3.bias"].to(dev, torch.float32).contiguous()
             for k_, src in (("ln2_w", b + "norm2.weight"), ("ln2_b", b + "norm2.bias"), ("lnf_w", "norm.weight"),
                             ("lnf_b", "norm.bias"), ("b3", b + "mlp.3.bias")):
                 f[k_] = m[src].to(dev, torch.float32).contiguous()
@@ -348,8 +363,40 @@ class PolicyValueNet:
         azk.nn_heads_finalize_sum(P4, f["bh_f"], A, lb, vb, count=cnt)
         return lb, (vb if self.out_buffers is not None else vb[:, None])
 
+    def tail_chain(self, z):
+        """The cls-row tail as five hand-written launches (csrc/azk_nn.hip k_tail_gemm), every one honouring the device-side live
+        count:  u = blockdiag_h(Wv'_h) z_h  ->  x1 = u Wo^T + bias1 (+ row statistics)  ->  hh = GELU(LN2(x1) W0'^T + b0')  ->
+        x2 = x1 + b3 + hh W3^T (+ row statistics)  ->  logits, tanh(value) = heads(LNf(x2))       (nn.py:54-60, 78-83)."""
+        import azk
+        cfg, f = self.cfg, self._fold
+        n, A, D, H = z.shape[0], cfg.action_dim, cfg.embed_dim, cfg.num_heads
+        dev, cnt = z.device, self.live_count
+        key = (n, id(self.leaf_source) if self.leaf_source is not None else None)     # one workspace per stepped engine (= per stream)
+        ws = self._tail_ws.get(key)
+        if ws is None:
+            bf = dict(dtype=torch.bfloat16, device=dev)
+            ws = dict(u=torch.empty((n, D), **bf), x1=torch.empty((n, D), **bf), hh=torch.empty((n, 4 * D), **bf), x2=torch.empty((n, D), **bf),
+                      st1=torch.empty((n, D // 64, 2), dtype=torch.float32, device=dev), st2=torch.empty((n, D // 64, 2), dtype=torch.float32, device=dev))
+            if len(self._tail_ws) > 8:
+                self._tail_ws.clear()
+            self._tail_ws[key] = ws
+        azk.nn_tail_gemm(z.view(n, H * D), f["WvHP"], D // H, D, azk.TAIL_BF16, nbatch=H, a_batch_stride=D, out=ws["u"], count=cnt)
+        azk.nn_tail_gemm(ws["u"], f["WoP"], D, D, azk.TAIL_BF16, bias=f["bias1_f"], out=ws["x1"], stats_out=ws["st1"], count=cnt)
+        azk.nn_tail_gemm(ws["x1"], f["W0GP"], 4 * D, D, azk.TAIL_GELU, bias=f["b0G_f"], out=ws["hh"], a_stats=ws["st1"], count=cnt)
+        azk.nn_tail_gemm(ws["hh"], f["W3P"], D, 4 * D, azk.TAIL_RESID, bias=f["b3_f"], resid=ws["x1"], out=ws["x2"], stats_out=ws["st2"], count=cnt)
+        if self.out_buffers is not None:
+            lb, vb = self.out_buffers
+        else:
+            lb = torch.empty((n, A), dtype=torch.float32, device=dev)
+            vb = torch.empty(n, dtype=torch.float32, device=dev)
+        azk.nn_tail_gemm(ws["x2"], f["WhGP"], f["bhG_f"].numel(), D, azk.TAIL_HEADS, bias=f["bhG_f"], a_stats=ws["st2"], logits=lb, values=vb,
+                         action_dim=A, count=cnt)
+        return lb, (vb if self.out_buffers is not None else vb[:, None])
+
     def tail_fast(self, z):
         """depth-1 cls row after the pooled tokens zn [n, H, D]: composed projection, MLP, final norm, merged heads."""
+        if getattr(self, "chain_tail", False) and self.use_chain_tail:
+            return self.tail_chain(z)
         if self.hip_tail and self.use_hip_tail:
             return self.tail_hip(z)
         w, cfg, f = self.w, self.cfg, self._fold

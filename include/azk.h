@@ -334,6 +334,35 @@ int32_t azk_nn_embed_pool_compact_leaves(const azk_leaf_source *src, const azk_e
 int32_t azk_nn_gemm_rows(const void *a_bf16_dev, int32_t lda, const void *w_packed_dev, int32_t m, int32_t n_out, int32_t k,
                          int32_t ksplit, float *partials_out_dev, const float *bias_dev, void *gelu_out_bf16_dev,
                          const int32_t *n_valid_dev, void *stream);
+/* azk_nn_tail_gemm - one link of the cls-row tail as a latency-shaped small GEMM (every load of a K chunk in flight before
+ * the first MFMA, no LDS):  C[m][nbatch * n_out] = op(A) W^T (+ bias) through one of four epilogues.
+ *   a_bf16 [m][lda] row-major; batch b reads A columns [b * a_batch_stride, b * a_batch_stride + k), multiplies them with
+ *   weight block b and writes output columns [b * n_out, (b + 1) * n_out) - nbatch = 1 is a plain GEMM, nbatch = heads is the
+ *   block-diagonal per-head value projection.  w_packed: nbatch consecutive nn.Linear weights [n_out][k] in
+ *   azk_nn_gemm_rows' fragment packing.  k = 512 or 2048; n_out a multiple of 64.
+ *   layernorm_a (k = 512): A = LayerNorm(rows) without affine (fold it into weight / bias: W diag(gamma), W beta + b); the row
+ *            statistics are read from a_stats [m][a_stats_groups][2] = per 64-column group (sum, sum of squares) of the row, as
+ *            left by the GEMM that produced A (its stats_out).
+ *   stats_out (optional, epilogues 0-2): float32 [m][nbatch * n_out / 64][2], the same partials of the rows written here.
+ *   epilogue 0: out_bf16 = acc + bias;  1: GELU(acc + bias) (exact erf);  2: acc + bias + resid_bf16;
+ *            3: merged heads - logits_out float32 [m][action_dim], values_out[m] = tanh(column action_dim)   (nn.py:82-83).
+ *   n_valid (optional, device): rows at or beyond it are neither read nor written. */
+typedef struct azk_tail_gemm {
+    const void *a_bf16; int32_t lda, a_batch_stride;
+    const void *w_packed;
+    int32_t m, n_out, k, nbatch;
+    const int32_t *n_valid;
+    const float *bias;
+    int32_t layernorm_a, epilogue;
+    float ln_eps;
+    const float *a_stats; int32_t a_stats_groups;
+    float *stats_out;
+    void *out_bf16; int32_t ldo;
+    const void *resid_bf16; int32_t ldr;
+    float *logits_out, *values_out; int32_t action_dim;
+} azk_tail_gemm;
+int32_t azk_nn_tail_gemm(const azk_tail_gemm *desc, void *stream);
+
 /* azk_nn_ln_heads: final LayerNorm + merged policy/value head + finalize in one launch (nn.py:78-83 for the cls row):
  *   logits[n][A] = LN(x) Wh^T + bh (float32), values[n] = tanh(column A).  w_packed_dev: the merged head weight
  *   [n_out_padded][embed_dim] in azk_nn_gemm_rows' packing; each wave reads whole rows and takes their statistics itself.

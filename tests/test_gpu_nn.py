@@ -404,3 +404,50 @@ def test_compact_embed_pool_from_engine_leaves_equals_gathered_batch():
     assert int(eng.n_leaf.item()) == n and sched.tolist() == [0, 0]
     assert torch.equal(z_new[:n], z_ref)
     eng.close()
+
+
+def test_tail_chain_vs_torch_fp32_and_library_tail():
+    """The five-launch tail chain (azk_nn_tail_gemm: per-head value projection, output projection + LN statistics, LN2 + MLP up +
+    GELU, MLP down + residual + LN statistics, final LN + merged heads) against the same cls-row computation in plain fp32 PyTorch
+    from the same pooled tokens z, and against the library-GEMM tail.  bf16 activations between the links (as in the library
+    tail): logits within 3e-2 absolute, value within 1e-2; a device-side live count leaves the rows below it bit-identical."""
+    import azk
+    cfg = NetConfig(15, 15, 2, 225, 5, 512, 8, 1)
+    net = PolicyValueNet(cfg, seed=2, device="cuda", dtype=torch.bfloat16, path="clsfold")
+    assert net.chain_tail
+    f, m = net._fold, {k: v.cuda() for k, v in net.master.items()}
+    n, live, D, H = 333, 200, 512, 8
+    x = random_boards(n, 2, 15, 15, 5).cuda().to(torch.bfloat16).contiguous()
+    z = azk.nn_embed_pool(x, f["wt_ext"], f["cpos_frag"], f["score_frag"], f["score_msum"], f["score_ref"], 15, 15, 5, 512, 8)     # [n, H, D]
+    # fp32 reference of the tail from the same z (z = softmax-weighted sum of the normalised tokens, before LN1's affine)
+    g1, b1 = m["blocks.0.norm1.weight"], m["blocks.0.norm1.bias"]
+    Wi, bi = m["blocks.0.attn.in_proj_weight"], m["blocks.0.attn.in_proj_bias"]
+    zz = z.float() * g1 + b1                                                                          # sum_t a_t xhat_t (the weights sum to 1)
+    Wv, bv = Wi[2 * D:].view(H, D // H, D), bi[2 * D:].view(H, D // H)
+    a = (torch.einsum("nhd,hed->nhe", zz, Wv) + bv).reshape(n, D)
+    x0 = m["embedding.cls_token"][0, 0] + m["embedding.pos_embedding"][0, 0]
+    x1 = x0 + a @ m["blocks.0.attn.out_proj.weight"].t() + m["blocks.0.attn.out_proj.bias"]
+    h = F.layer_norm(x1, (D,), m["blocks.0.norm2.weight"], m["blocks.0.norm2.bias"], 1e-5)
+    x2 = x1 + F.gelu(h @ m["blocks.0.mlp.0.weight"].t() + m["blocks.0.mlp.0.bias"]) @ m["blocks.0.mlp.3.weight"].t() + m["blocks.0.mlp.3.bias"]
+    y = F.layer_norm(x2, (D,), m["norm.weight"], m["norm.bias"], 1e-5)
+    ref_l = y @ m["policy_head.weight"].t() + m["policy_head.bias"]
+    ref_v = torch.tanh(y @ m["value_head.weight"].t() + m["value_head.bias"])
+    net.use_chain_tail = True
+    lc, vc = net.tail_fast(z)
+    net.use_chain_tail = False
+    ll, vl = net.tail_fast(z)
+    assert (lc - ref_l).abs().max().item() < 3e-2 and (vc - ref_v).abs().max().item() < 1e-2, ((lc - ref_l).abs().max().item(), (vc - ref_v).abs().max().item())
+    assert (ll - ref_l).abs().max().item() < 3e-2                                                    # the library tail meets the same bound
+    assert (lc - ll).abs().max().item() < 3e-2
+    # live count: rows below it identical, rows above untouched
+    net.use_chain_tail = True
+    lb, vb = torch.full((n, 225), 7.0, device="cuda"), torch.full((n,), 7.0, device="cuda")
+    net.out_buffers, net.live_count = (lb, vb), torch.tensor([live], dtype=torch.int32, device="cuda")
+    net.tail_fast(z)
+    torch.cuda.synchronize()
+    assert torch.equal(lb[:live], lc[:live]) and torch.equal(vb[:live], vc[:live, 0])
+    assert bool((lb[live:] == 7.0).all()) and bool((vb[live:] == 7.0).all())
+    # deterministic: the LayerNorm statistics are summed in a fixed order (no atomics)
+    net.out_buffers, net.live_count = None, None
+    l2, v2 = net.tail_fast(z)
+    assert torch.equal(l2, lc) and torch.equal(v2, vc)
