@@ -180,7 +180,13 @@ def main():
     ap.add_argument("--games", type=int, default=2048, help="concurrent games per GPU")
     ap.add_argument("--sims", type=int, default=800)
     ap.add_argument("--size", type=int, default=15)
-    ap.add_argument("--nn-path", default="clsfold", choices=["clsfold", "cls", "full"])
+    ap.add_argument("--nn-path", default=None, choices=["clsfold", "cls", "full"], help="default: clsfold (bf16) / cls (fp32)")
+    ap.add_argument("--nn-dtype", default="bf16", choices=["bf16", "fp32"],
+                    help="fp32: the reference's own arithmetic (torch fp32 GEMMs) - the evaluator whose visit-count policies equal the "
+                         "reference's to the last visit; bf16 (default, north_star's MFMA bf16): the hand-written kernels")
+    ap.add_argument("--tail", default="library", choices=["chain", "library"],
+                    help="cls-row tail: hipBLASLt GEMMs + hand-written LN / heads kernels (default: 2-3 %% faster inside the step, where the "
+                         "tail's weights arrive cold), or the all-hand-written GEMM chain (azk_nn_tail_gemm)")
     ap.add_argument("--no-graph", action="store_true", help="eager stepping with a host sync per simulation (n_leaf-sized batches)")
     ap.add_argument("--split", type=int, default=1, help="independent game groups stepped on separate streams inside the step graph")
     ap.add_argument("--cache-entries", type=int, default=32768, help="per-game eval-cache entries (MCTS.cache; 64 GB of HBM at 2048 games x 32768); 0 = off")
@@ -190,6 +196,8 @@ def main():
                     help="BASELINE.json configs[4]: one train.py step (batch 512 per GPU, Adam lr 2.5e-4, one fused gradient bucket "
                          "all-reduced over RCCL) after every move, fed from the device-resident replay ring")
     args = ap.parse_args()
+    if args.nn_path is None:
+        args.nn_path = "clsfold" if args.nn_dtype == "bf16" else "cls"
 
     if args.cpu_worker > 0:              # child of cpu_baseline's all-cores leg: CPU only, prints one JSON line
         sims, evals, hits, moves, dt = cpu_port_sample(args.sims, args.cpu_worker, 1)
@@ -236,7 +244,9 @@ def main():
         torch.cuda.set_device(local_rank)
         from pvnet import PolicyValueNet
         from selfplay import KernelTimer, SelfPlayRunner
-        net = PolicyValueNet(cfg, seed=0, device=f"cuda:{local_rank}", dtype=torch.bfloat16, path=args.nn_path)
+        nn_torch_dtype = torch.bfloat16 if args.nn_dtype == "bf16" else torch.float32
+        net = PolicyValueNet(cfg, seed=0, device=f"cuda:{local_rank}", dtype=nn_torch_dtype, path=args.nn_path)
+        net.use_chain_tail = args.tail == "chain"
         kt = KernelTimer(stride=16)
         if args.train_step:
             from azk import DeviceReplay
@@ -244,7 +254,8 @@ def main():
             replay = DeviceReplay(400000, cfg.channels, cfg.rows, cfg.cols, cfg.action_dim, device=torch.device("cuda", local_rank))
             trainer = Trainer(cfg, net.state_dict(), device=f"cuda:{local_rank}", dropout=0.1)      # main.py:134 trains with dropout 0.1
         runner = SelfPlayRunner("gomoku", net, args.games, args.sims, size=args.size, seed=args.seed,
-                                first_global_game=shard_range(args.games, rank)[0], device=local_rank, leaf_dtype="bfloat16",
+                                first_global_game=shard_range(args.games, rank)[0], device=local_rank,
+                                leaf_dtype="bfloat16" if args.nn_dtype == "bf16" else "float32",
                                 recycle=True, kernel_timer=kt, use_graph=not args.no_graph, n_split=args.split, cache_entries=args.cache_entries,
                                 replay=replay)
 
@@ -384,10 +395,11 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt_max / args.steps * 1e3,
             "preroll": {"cheap_moves": args.preroll_cheap, "cheap_sims": args.preroll_sims, "full_moves": args.preroll_full,
                         "note": "untimed, independent of --warmup: de-phases the slots so the completion count is window-independent"},
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.nn_dtype == "bf16" else "f32", "data": "synthetic",
             "config": {"workload": f"Gomoku {args.size}x{args.size}, {args.sims} sims/move, {args.games} concurrent self-play games per GPU "
                                    f"(BASELINE.json configs[2]), continuous self-play", "games_per_gpu": args.games,
-                       "sims_per_move": args.sims, "net": f"ViT patch5 embed512 heads8 depth1 (ai/nn.py), random init seed 0, path={args.nn_path}",
+                       "sims_per_move": args.sims, "net": f"ViT patch5 embed512 heads8 depth1 (ai/nn.py), random init seed 0, path={args.nn_path}, "
+                                                           f"{args.nn_dtype}" + (f", tail={args.tail}" if args.nn_path == "clsfold" else ""),
                        "parallelism": f"games sharded over {world} GPU(s), no collectives on the generation path"},
             "sims_per_sec": sims_all / dt_max, "leaf_evals_per_sec": leaves_all / dt_max,
             "eval_cache": {"entries_per_game": args.cache_entries, "hits_rank0": c.get("cache_hits", 0),
@@ -398,6 +410,19 @@ def main():
             "mean_plies_per_game": mean_plies, "game_length_source": src, "games_finished_in_window": fin_window,
             "plies_in_window": plies_all, "counters_rank0": c, "roofline": dominant, "roofline_puct": roof, "kernel_rooflines": kernels,
         }
+        try:        # what this evaluator does to the search results, measured on the reference's recorded positions (tools/measure_nn_parity.py)
+            par = json.load(open(os.path.join(ROOT, "profiles", "r02_nn_parity.json")))
+            if args.nn_dtype == "bf16":
+                out["parity"] = {"tree_and_rules": "bit-exact vs the oracle / the reference's golden vectors (tests/test_gpu_engine.py)",
+                                 "evaluator_vs_reference_fp32": par["kat_vs_reference_seed0"].get(f"bf16_{args.nn_path}"),
+                                 "visit_policy_vs_fp32_evaluator": par["search_vs_fp32_full"]["bf16_clsfold"],
+                                 "note": "north_star's 1e-5 bar on visit-count policies holds for the fp32 evaluator (delta = 0, --nn-dtype fp32 line); "
+                                         "the bf16 evaluator changes a few visits in a few positions (numbers above; tests/test_gpu_parity_nn.py)",
+                                 "source": "profiles/r02_nn_parity.json"}
+            else:
+                out["parity"] = {"visit_policy_vs_fp32_full": par["search_vs_fp32_full"]["fp32_cls"], "source": "profiles/r02_nn_parity.json"}
+        except Exception:
+            pass
         if args.train_step:
             out["config"]["workload"] += " + one train step (batch 512 per GPU, fp32 autograd, fused gradient bucket all-reduce) after every move (BASELINE.json configs[4])"
             out["train_step"] = {"steps": len(train_ms), "ms_per_train_step": (sum(x.elapsed_time(y) for x, y in train_ms) / len(train_ms)) if train_ms else None,

@@ -48,18 +48,20 @@ def test_patch_embed_kernel_vs_torch_fp32(R, Cc, C, k, D, heads):
 
 def test_evaluator_paths_agree_and_match_reference_kat():
     """bf16 evaluator (hand-written embed + torch GEMMs) vs the reference's fp32 outputs for the seed-0 training
-    config (tests/golden/nn_small.npz 'full_*'): logits within 3e-2 absolute (bf16 ~ 2e-2)."""
+    config (tests/golden/nn_small.npz 'full_*'): logits within 2e-2 absolute ("bf16 ~2e-2"), every path incl. the
+    benched 'clsfold'.  The error budget and the end-to-end effect on pi: tests/test_gpu_parity_nn.py."""
     z = load_golden("nn_small.npz")
     cfg = NetConfig(15, 15, 2, 225, 5, 512, 8, 1)
     x = torch.from_numpy(z["full_x"]).cuda()
     outs = {}
-    for path in ("full", "cls"):
+    for path in ("full", "cls", "clsfold"):                      # clsfold = the path bench.py runs
         net = PolicyValueNet(cfg, seed=0, device="cuda", dtype=torch.bfloat16, path=path)
         logits, v = net(x.to(torch.bfloat16))
         outs[path] = logits
-        np.testing.assert_allclose(logits.cpu().numpy(), z["full_logits"], rtol=0, atol=4e-2)
-        np.testing.assert_allclose(v.cpu().numpy(), z["full_value"], rtol=0, atol=2e-2)
-    torch.testing.assert_close(outs["full"], outs["cls"], rtol=0, atol=3e-2)
+        np.testing.assert_allclose(logits.cpu().numpy(), z["full_logits"], rtol=0, atol=2e-2)      # measured 6.5e-3 .. 8.9e-3
+        np.testing.assert_allclose(v.cpu().numpy().reshape(-1), z["full_value"].reshape(-1), rtol=0, atol=2e-3)
+    torch.testing.assert_close(outs["full"], outs["cls"], rtol=0, atol=2e-2)
+    torch.testing.assert_close(outs["full"], outs["clsfold"], rtol=0, atol=2e-2)
     net32 = PolicyValueNet(cfg, seed=0, device="cuda", dtype=torch.float32, path="cls")
     l32, v32 = net32(x)
     np.testing.assert_allclose(l32.cpu().numpy(), z["full_logits"], rtol=0, atol=1e-4)
