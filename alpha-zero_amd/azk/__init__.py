@@ -40,14 +40,14 @@ class AzkError(RuntimeError):
 class Config(C.Structure):
     _fields_ = [("game", C.c_int32), ("rows", C.c_int32), ("cols", C.c_int32), ("n_games", C.c_int32),
                 ("max_sims", C.c_int32), ("leaf_dtype", C.c_int32), ("device", C.c_int32),
-                ("arena_nodes", C.c_int32), ("cache_entries", C.c_int32), ("reserved", C.c_int32 * 7)]
+                ("arena_nodes", C.c_int32), ("cache_entries", C.c_int32), ("cache_shared", C.c_int32), ("reserved", C.c_int32 * 6)]
 
 
 class LeafSource(C.Structure):
     """azk_leaf_source (include/azk.h): where azk_nn_embed_pool_leaves finds the pending leaves of an engine."""
     _fields_ = [("leaf_flag", C.c_void_p), ("leaf_cells", C.c_void_p), ("to_move", C.c_void_p), ("leaf_depth", C.c_void_p),
                 ("leaf_slot", C.c_void_p), ("n_leaf", C.c_void_p), ("n_games", C.c_int32), ("rows", C.c_int32), ("cols", C.c_int32),
-                ("rc", C.c_int32), ("rc_pad", C.c_int32), ("planes", C.c_int32), ("flag_bytes", C.c_int32)]
+                ("rc", C.c_int32), ("rc_pad", C.c_int32), ("planes", C.c_int32), ("flag_bytes", C.c_int32), ("cache_stamp", C.c_void_p)]
 
 
 class EmbedPoolConsts(C.Structure):
@@ -191,7 +191,8 @@ def _np(a):
 class Engine:
     """G concurrent games + their search trees resident on one GPU (one engine per process / GPU)."""
 
-    def __init__(self, game, n_games, max_sims, size=None, device=0, leaf_dtype="float32", arena_nodes=0, cache_entries=0):
+    def __init__(self, game, n_games, max_sims, size=None, device=0, leaf_dtype="float32", arena_nodes=0, cache_entries=0,
+                 cache_shared=False):
         torch = _torch()
         self.torch = torch
         self.L = lib()
@@ -201,6 +202,8 @@ class Engine:
         cfg.rows = cfg.cols = int(size or 0)
         cfg.n_games, cfg.max_sims, cfg.device, cfg.arena_nodes = int(n_games), int(max_sims), int(device), int(arena_nodes)
         cfg.cache_entries = int(cache_entries)
+        cfg.cache_shared = 1 if (cache_shared and cache_entries) else 0      # one table for all games (the reference's process-global MCTS.cache)
+        self.cache_shared = bool(cfg.cache_shared)
         cfg.leaf_dtype = LEAF_BF16 if leaf_dtype in ("bfloat16", "bf16", torch.bfloat16) else LEAF_F32
         self.device = torch.device("cuda", device)
         torch.cuda.set_device(self.device)

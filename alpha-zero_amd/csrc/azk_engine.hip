@@ -48,6 +48,16 @@ struct Dev {               // device view of the engine, passed to kernels by va
     float *cache_logits;                   // [G][E][A] the evaluator's logits row
     float *cache_value;                    // [G][E]
     int *leaf_cache;                       // [G] >= 0: pending leaf was a cache hit (entry index); < 0: miss, insert at -(x)-1
+    // shared mode (one table for every game of the engine, like the reference's process-global MCTS.cache): entries are written
+    // at EXPANSION by whichever game wins the entry's claim word for the current launch stamp, and read at selection only when
+    // their claim stamp is older than the current launch (the kernel boundary is the only cross-CU ordering relied on); a hit is
+    // copied into the game's own buffers at once, because another game may overwrite the entry before this game expands
+    int cache_shared;
+    unsigned long long cache_mask;         // shared: entries - 1 (entries = the largest power of two <= G * cache_entries)
+    unsigned *cache_claim;                 // shared: [entries] launch stamp of the entry's last write, 0 = never written
+    unsigned *cache_stamp;                 // shared: [1] stamp of the current launch (bumped by the leaf hand-off kernels)
+    unsigned long long *leaf_key;          // shared: [G][key_words] key of the pending (missed) leaf
+    float *hit_logits, *hit_value;         // shared: [G][A], [G] private copy of a hit
     int16_t *traj_action;  // [G][state_dim] cell played at each ply of the current game (square boards only, else null)
     double *traj_pi;       // [G][state_dim][A] visit distribution recorded at each ply
     long long *emit_base;  // [G] first tuple index (64-bit: the stream never wraps) of a game being emitted, -1 = not emitting
@@ -162,6 +172,10 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev dd, const float *__restri
     const int e_node = EXPAND ? d.leaf_node[g] : -1, e_slot = EXPAND ? d.leaf_slot[g] : 0, e_depth = EXPAND ? d.leaf_depth[g] : 0;
     const int e_nv = EXPAND ? d.leaf_nmoves[g] : 0, e_top = EXPAND ? d.arena_top[g] : 0;
     const int e_centry = (EXPAND && d.cache_entries) ? d.leaf_cache[g] : -1;
+    const bool shared = d.cache_entries && d.cache_shared;
+    const unsigned cstamp = shared ? d.cache_stamp[0] : 0u;
+    unsigned long long e_key = 0ull;
+    if (EXPAND && shared && lane < d.key_words) e_key = d.leaf_key[(size_t)g * d.key_words + lane];
     const int e_path = (EXPAND && lane < d.path_cap) ? d.path[(size_t)g * d.path_cap + lane] : 0;     // trace nodes 0..63 (deeper ones: below)
     constexpr int KSL = 7;                                  // cells per lane: rc <= 448 (make_game allows 400)
     int e_mv[KSL] = {0, 0, 0, 0, 0, 0, 0};
@@ -190,8 +204,10 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev dd, const float *__restri
             const int nv = uniform_i32(e_nv);
             const int centry = d.cache_entries ? uniform_i32(e_centry) : -1;
             const bool hit = d.cache_entries && centry >= 0;
-            const size_t crow = ((size_t)g * d.cache_entries + (hit ? centry : -(centry + 1)));
-            const float *lg = hit ? d.cache_logits + crow * A : logits + (size_t)slot * A;
+            const size_t crow = shared ? (size_t)(hit ? centry : -(centry + 1)) : ((size_t)g * d.cache_entries + (hit ? centry : -(centry + 1)));
+            const float *lg = hit ? (shared ? d.hit_logits + (size_t)g * A : d.cache_logits + crow * A) : logits + (size_t)slot * A;
+            unsigned claim_now = 0u;
+            if (shared && !hit) claim_now = __hip_atomic_load(d.cache_claim + crow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             // Node.backup operands (trace nodes 0..depth, one per lane) are fetched now, next to the logits: second round trip
             const bool shortpath = depth < AZK_WAVE;
             int bN = 0;
@@ -201,7 +217,7 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev dd, const float *__restri
             float lgv[KSL];
 #pragma unroll
             for (int k4 = 0; k4 < KSL; k4++) { const int i = lane + AZK_WAVE * k4; lgv[k4] = lg[i < A ? i : A - 1]; }
-            const float vraw = hit ? d.cache_value[crow] : values[slot];
+            const float vraw = hit ? (shared ? d.hit_value[g] : d.cache_value[crow]) : values[slot];
             const uint32_t node_meta = d.meta[base + node];
             const bool mix = depth == 0 && d.noise != nullptr;        // mcts.py:42-43,52-53
             double nzv[KSL] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
@@ -212,7 +228,17 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev dd, const float *__restri
                     nzv[k4] = d.noise[(size_t)g * A + azk_action_idx(gd, i < nv ? e_mv[k4] : 0)];   // (a lane's e_mv beyond nv is stale memory)
                 }
             }
-            if (d.cache_entries && !hit) {                            // MCTS.cache[board_key] = (...)  (mcts.py:51)
+            bool cache_write = d.cache_entries && !hit;               // MCTS.cache[board_key] = (...)  (mcts.py:51)
+            if (shared && !hit) {
+                // one writer per entry and launch: the claim word moves to this launch's stamp by compare-and-swap; an entry
+                // already claimed in this launch (by any game) is left alone.  The round trip hides under the softmax below.
+                const unsigned cur = (unsigned)uniform_i32((int)claim_now);
+                unsigned got = cur;
+                if (cur != cstamp && lane == 0) got = atomicCAS(d.cache_claim + crow, cur, cstamp);
+                cache_write = cur != cstamp && (unsigned)uniform_i32((int)got) == cur;
+                if (cache_write && lane < d.key_words) d.cache_key[crow * d.key_words + lane] = e_key;
+            }
+            if (cache_write) {
 #pragma unroll
                 for (int k4 = 0; k4 < KSL; k4++) { const int i = lane + AZK_WAVE * k4; if (i < A) d.cache_logits[crow * A + i] = lgv[k4]; }
                 if (lane == 0) d.cache_value[crow] = vraw;
@@ -473,11 +499,36 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev dd, const float *__restri
                 h = (h ^ own) * 0xFF51AFD7ED558CCDull; h ^= h >> 29;
                 h = (h ^ opp) * 0xC4CEB9FE1A85EC53ull; h ^= h >> 32;
             }
-            const int entry = (int)(h & (unsigned long long)(d.cache_entries - 1));
-            unsigned long long *kp = d.cache_key + ((size_t)g * d.cache_entries + entry) * KW;
-            const bool same = lane < KW ? kp[lane] == mykey : true;
-            cached = __ballot(!same) == 0ull;
-            if (!cached && lane < KW) kp[lane] = mykey;                // claim the slot now; logits/value land at expansion
+            int entry;
+            if (shared) {
+                entry = (int)(h & d.cache_mask);
+                const unsigned c1 = (unsigned)uniform_i32((int)__hip_atomic_load(d.cache_claim + entry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                if (c1 != 0u && c1 < cstamp) {                        // written in an earlier launch: complete and visible
+                    const unsigned long long *kp = d.cache_key + (size_t)entry * KW;
+                    const bool same = lane < KW ? kp[lane] == mykey : true;
+                    if (__ballot(!same) == 0ull) {
+                        float row[KSL];
+#pragma unroll
+                        for (int k4 = 0; k4 < KSL; k4++) { const int i = lane + AZK_WAVE * k4; row[k4] = d.cache_logits[(size_t)entry * A + (i < A ? i : A - 1)]; }
+                        const float vv = d.cache_value[entry];
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the copy is in registers before the claim word is read again
+                        const unsigned c2 = (unsigned)uniform_i32((int)__hip_atomic_load(d.cache_claim + entry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                        if (c2 == c1) {                               // nobody started rewriting the entry meanwhile: the copy is whole
+                            cached = true;
+#pragma unroll
+                            for (int k4 = 0; k4 < KSL; k4++) { const int i = lane + AZK_WAVE * k4; if (i < A) d.hit_logits[(size_t)g * A + i] = row[k4]; }
+                            if (lane == 0) d.hit_value[g] = vv;
+                        }
+                    }
+                }
+                if (!cached && lane < KW) d.leaf_key[(size_t)g * KW + lane] = mykey;      // written into the table at expansion
+            } else {
+                entry = (int)(h & (unsigned long long)(d.cache_entries - 1));
+                unsigned long long *kp = d.cache_key + ((size_t)g * d.cache_entries + entry) * KW;
+                const bool same = lane < KW ? kp[lane] == mykey : true;
+                cached = __ballot(!same) == 0ull;
+                if (!cached && lane < KW) kp[lane] = mykey;            // claim the slot now; logits/value land at expansion
+            }
             if (lane == 0) d.leaf_cache[g] = cached ? entry : -(entry + 1);
         }
         if (lane == 0) {
@@ -517,7 +568,10 @@ __global__ __launch_bounds__(AZK_WAVE) void k_gather(Dev d, void *__restrict__ l
     before = wave_sum_i32(before);
     if (last) {
         total = wave_sum_i32(total);
-        if (lane == 0) *n_leaf_out = total;
+        if (lane == 0) {
+            *n_leaf_out = total;
+            if (d.cache_entries && d.cache_shared) d.cache_stamp[0] += 1u;   // the next tree launch may read what the last one cached
+        }
     }
     if (!d.leaf_flag[g]) return;
     const int slot = before;
@@ -710,7 +764,7 @@ __global__ __launch_bounds__(AZK_WAVE) void k_vanilla(Dev d, int n_sims, uint32_
 // A leaf that missed the eval cache claims its entry's key at selection and fills logits/value at expansion; if the search
 // is abandoned in between (new search, reset, recycle) the half-written entry must not survive.
 __device__ __forceinline__ void drop_pending_cache_claim(const Dev &d, int g) {
-    if (d.cache_entries && d.leaf_node[g] >= 0 && d.leaf_cache[g] < 0) {
+    if (d.cache_entries && !d.cache_shared && d.leaf_node[g] >= 0 && d.leaf_cache[g] < 0) {      // (shared mode claims nothing at selection)
         unsigned long long *kp = d.cache_key + ((size_t)g * d.cache_entries + (size_t)(-(d.leaf_cache[g] + 1))) * d.key_words;
         for (int w = 0; w < d.key_words; w++) kp[w] = ~0ull;
     }
@@ -720,6 +774,7 @@ __device__ __forceinline__ void drop_pending_cache_claim(const Dev &d, int g) {
 __global__ void k_begin_search(Dev d) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= d.G) return;
+    if (g == 0 && d.cache_entries && d.cache_shared) d.cache_stamp[0] += 1u;
     drop_pending_cache_claim(d, g);
     const size_t base = (size_t)g * d.cap;
     d.N[base] = 0; d.W[base] = 0.0; d.P[base] = 0.f; d.meta[base] = meta_pack(0xffff, 0);
@@ -1193,9 +1248,21 @@ int32_t azk_create(const azk_config *cfg, azk_engine **out) {
     DA(d.counters, (size_t)CNT_N * G); DA(d.err, 1); DA(d.dbg, G * 8); DA(d.emit_base, G);
     d.cache_entries = cfg->cache_entries;
     d.key_words = 2 * ((g.rc + 64) / 64);                         // one spare bit (63 of the last own-plane word) for the side to move
+    d.cache_shared = (d.cache_entries && cfg->cache_shared) ? 1 : 0;
+    size_t cache_total = G * (size_t)d.cache_entries;
+    if (d.cache_shared) {
+        size_t p2 = 1;
+        while (p2 * 2 <= cache_total && p2 * 2 <= (size_t)1 << 30) p2 *= 2;       // entry indices travel as int32
+        cache_total = p2;
+        d.cache_mask = (unsigned long long)cache_total - 1ull;
+    }
     if (d.cache_entries) {
-        DA(d.cache_key, G * (size_t)d.cache_entries * d.key_words); DA(d.cache_logits, G * (size_t)d.cache_entries * g.action_dim);
-        DA(d.cache_value, G * (size_t)d.cache_entries); DA(d.leaf_cache, G);
+        DA(d.cache_key, cache_total * d.key_words); DA(d.cache_logits, cache_total * g.action_dim);
+        DA(d.cache_value, cache_total); DA(d.leaf_cache, G);
+        if (d.cache_shared) {
+            DA(d.cache_claim, cache_total); DA(d.cache_stamp, 1); DA(d.leaf_key, G * d.key_words);
+            DA(d.hit_logits, G * g.action_dim); DA(d.hit_value, G);
+        }
     }
     if (g.rows == g.cols && g.action_dim == g.rc) { DA(d.traj_action, G * g.state_dim); DA(d.traj_pi, G * g.state_dim * g.action_dim); } DA(e->counter_sums, CNT_N); DA(e->n_leaf_scratch, 1);
     if (s == hipSuccess) { uint8_t *ls = nullptr; s = dalloc(e, &ls, G * g.planes * g.rc * 4); e->leaf_scratch = ls; }
@@ -1204,7 +1271,12 @@ int32_t azk_create(const azk_config *cfg, azk_engine **out) {
     (void)hipMemset(d.leaf_flag, 0, ((G + 511) / 512) * 512 + 512);
     (void)hipMemset(d.counters, 0, sizeof(long long) * CNT_N * G);
     (void)hipMemset(d.err, 0, sizeof(int));
-    if (d.cache_entries) (void)hipMemset(d.cache_key, 0xff, sizeof(unsigned long long) * G * (size_t)d.cache_entries * d.key_words);   // all-ones = no position
+    if (d.cache_entries) (void)hipMemset(d.cache_key, 0xff, sizeof(unsigned long long) * cache_total * d.key_words);   // all-ones = no position
+    if (d.cache_shared) {
+        (void)hipMemset(d.cache_claim, 0, sizeof(unsigned) * cache_total);
+        const unsigned one = 1u;
+        (void)hipMemcpy(d.cache_stamp, &one, sizeof one, hipMemcpyHostToDevice);
+    }
     (void)hipMemset(d.dbg, 0, sizeof(long long) * G * 8);
     (void)hipMemset(d.leaf_node, 0xff, sizeof(int) * G);
     k_reset_games<<<(unsigned)((G * d.rc_pad + 255) / 256), 256>>>(d, 0, d.G);
@@ -1390,6 +1462,7 @@ int32_t azk_leaf_source_of(azk_engine *e, int32_t *n_leaf_dev, azk_leaf_source *
     out->leaf_slot = d.leaf_slot; out->n_leaf = n_leaf_dev;
     out->n_games = d.G; out->rows = d.g.rows; out->cols = d.g.cols; out->rc = d.g.rc; out->rc_pad = d.rc_pad; out->planes = d.g.planes;
     out->flag_bytes = ((d.G + 511) / 512) * 512 + 512;
+    out->cache_stamp = (d.cache_entries && d.cache_shared) ? d.cache_stamp : nullptr;
     return AZK_OK;
 }
 
@@ -1411,6 +1484,10 @@ int32_t azk_clear_cache(azk_engine *e, void *stream) {
     if (!e) return AZK_ERR_ARG;
     const Dev &d = e->d;
     if (!d.cache_entries) return AZK_OK;
+    if (d.cache_shared) {       // an entry whose claim word is 0 was never written: clearing the claims empties the table
+        HIPCHK(e, hipMemsetAsync(d.cache_claim, 0, sizeof(unsigned) * (size_t)(d.cache_mask + 1ull), (hipStream_t)stream));
+        return AZK_OK;
+    }
     HIPCHK(e, hipMemsetAsync(d.cache_key, 0xff, sizeof(unsigned long long) * (size_t)d.G * d.cache_entries * d.key_words, (hipStream_t)stream));
     return AZK_OK;
 }

@@ -847,7 +847,7 @@ __global__ __launch_bounds__(256, 2) void k_embed_pool(EmbedPoolArgs a) {
         for (int w = 0; w < wave; w++) before += scan[w];
         my_first = before + incl - my_count;
         nvalid = scan[0] + scan[1] + scan[2] + scan[3];
-        if (blockIdx.x == 0 && tid == 0) *a.src.n_leaf = nvalid;
+        if (blockIdx.x == 0 && tid == 0) { *a.src.n_leaf = nvalid; if (a.src.cache_stamp) *a.src.cache_stamp += 1u; }
         __syncthreads();
     } else {
         nvalid = a.count ? min(a.n, *a.count) : a.n;
@@ -1210,7 +1210,7 @@ __global__ __launch_bounds__(256, 2) void k_embed_pool_c(EmbedPoolCArgs a) {
         for (int w = 0; w < wave; w++) before += scan[w];
         my_first = before + incl - my_count;
         nvalid = scan[0] + scan[1] + scan[2] + scan[3];
-        if (blockIdx.x == 0 && tid == 0) *a.src.n_leaf = nvalid;
+        if (blockIdx.x == 0 && tid == 0) { *a.src.n_leaf = nvalid; if (a.src.cache_stamp) *a.src.cache_stamp += 1u; }
     } else {
         nvalid = a.count ? min(a.n, *a.count) : a.n;
     }

@@ -41,7 +41,7 @@ class SelfPlayResult:
 
 def self_play_batch(game, evaluator, n_games, n_sims, size=None, seed=0, first_global_game=0, dirichlet=True,
                     alpha=0.03, noise_fn=None, uniform_fn=None, device=0, leaf_dtype="float32", engine=None,
-                    max_moves=None, sample_until=None, stats=None, replay=None, cache_entries=0, vanilla_rng=None):
+                    max_moves=None, sample_until=None, stats=None, replay=None, cache_entries=0, vanilla_rng=None, cache_shared=False):
     """Play n_games games to the end in one batch.
 
     evaluator(boards[n,F,R,C] CUDA) -> (logits [n,A], values [n] | [n,1]).
@@ -56,7 +56,8 @@ def self_play_batch(game, evaluator, n_games, n_sims, size=None, seed=0, first_g
     """
     import torch
     max_sims = max(n_sims) if isinstance(n_sims, (tuple, list)) else n_sims
-    eng = engine or Engine(game, n_games, max_sims, size=size, device=device, leaf_dtype=leaf_dtype, cache_entries=cache_entries)
+    eng = engine or Engine(game, n_games, max_sims, size=size, device=device, leaf_dtype=leaf_dtype, cache_entries=cache_entries,
+                           cache_shared=cache_shared)
     assert eng.G == n_games
     G, A = eng.G, eng.action_dim
     eng.reset_games()
@@ -155,7 +156,7 @@ class SelfPlayRunner:
 
     def __init__(self, game, evaluator, n_games, n_sims, size=None, seed=0, first_global_game=0, dirichlet=True,
                  alpha=0.03, device=0, leaf_dtype="float32", recycle=True, on_records=None, kernel_timer=None,
-                 use_graph=False, n_split=1, replay=None, cache_entries=0):
+                 use_graph=False, n_split=1, replay=None, cache_entries=0, cache_shared=False):
         import torch
         self.replay = replay
         self.torch = torch
@@ -165,7 +166,7 @@ class SelfPlayRunner:
         self.n_split = n_split if use_graph else 1
         per = n_games // self.n_split
         self.halves = [_Half(torch, Engine(game, per, n_sims, size=size, device=device, leaf_dtype=leaf_dtype,
-                                           cache_entries=cache_entries), dirichlet)
+                                           cache_entries=cache_entries, cache_shared=cache_shared), dirichlet)
                        for _ in range(self.n_split)]
         self.eng = self.halves[0].eng
         self.G = n_games

@@ -190,6 +190,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="eager stepping with a host sync per simulation (n_leaf-sized batches)")
     ap.add_argument("--split", type=int, default=1, help="independent game groups stepped on separate streams inside the step graph")
     ap.add_argument("--cache-entries", type=int, default=32768, help="per-game eval-cache entries (MCTS.cache; 64 GB of HBM at 2048 games x 32768); 0 = off")
+    ap.add_argument("--cache", default="shared", choices=["shared", "per-game"],
+                    help="eval cache: one table shared by every game of the GPU (the reference's MCTS.cache is process-global, mcts.py:7) or one "
+                         "table per game; same memory, same results, different hit rate")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="wall-clock budget of the CPU baseline leg (0 = skip)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--train-step", action="store_true",
@@ -257,7 +260,7 @@ def main():
                                 first_global_game=shard_range(args.games, rank)[0], device=local_rank,
                                 leaf_dtype="bfloat16" if args.nn_dtype == "bf16" else "float32",
                                 recycle=True, kernel_timer=kt, use_graph=not args.no_graph, n_split=args.split, cache_entries=args.cache_entries,
-                                replay=replay)
+                                cache_shared=args.cache == "shared", replay=replay)
 
     def train_one():
         """train.train with one iteration (train.py:85-123): fresh Adam, the reference's loss, gradient bucket all-reduce.
@@ -402,7 +405,7 @@ def main():
                                                            f"{args.nn_dtype}" + (f", tail={args.tail}" if args.nn_path == "clsfold" else ""),
                        "parallelism": f"games sharded over {world} GPU(s), no collectives on the generation path"},
             "sims_per_sec": sims_all / dt_max, "leaf_evals_per_sec": leaves_all / dt_max,
-            "eval_cache": {"entries_per_game": args.cache_entries, "hits_rank0": c.get("cache_hits", 0),
+            "eval_cache": {"entries_per_game": args.cache_entries, "mode": args.cache, "hits_rank0": c.get("cache_hits", 0),
                            "hit_rate_rank0": c.get("cache_hits", 0) / max(1, c.get("cache_hits", 0) + c["leaves_evaluated"])},
             "nn_tflops_executed": nn_flop_total / dt_max / 1e12, "nn_flops_per_board": flops, "nn_boards_evaluated": evals,
             "stepping": "eager+sync" if args.no_graph else f"hipGraph replay, {runner.n_split} game group(s) (per simulation: k_tree, the network kernels taking the pending leaves straight from the engine, no host sync)",

@@ -57,7 +57,13 @@ typedef struct {
     int32_t arena_nodes;   /* nodes per game; 0 = worst case 1 + max_sims * max_children */
     int32_t cache_entries; /* eval cache (MCTS.cache, ai/mcts.py:7,38-51): entries per game, power of two, 0 = off.  Exact keys
                             * (the whole canonical position), so a hit returns precisely what the evaluator returned. */
-    int32_t reserved[7];
+    int32_t cache_shared;  /* 0: one table per game (single writer; exact MCTS.matched bookkeeping of a one-game run).
+                            * 1: ONE table of n_games * cache_entries entries shared by every game of the engine - the reference's
+                            * MCTS.cache is process-global (mcts.py:7): positions reached by several games (openings) are evaluated
+                            * once.  Entries are written at expansion under a per-entry claim word and become readable at the next
+                            * tree launch; a hit is copied into the game's own buffers at once.  Results are identical in both
+                            * modes (the cache is transparent); only the hit COUNT of the shared mode depends on timing. */
+    int32_t reserved[6];
 } azk_config;
 
 /* device-side work counters; sums over all games since the last azk_reset_counters */
@@ -283,6 +289,7 @@ typedef struct azk_leaf_source {
     int32_t *leaf_slot;           /* [n_games] out: row of the evaluator outputs */
     int32_t *n_leaf;              /* [1] out */
     int32_t n_games, rows, cols, rc, rc_pad, planes, flag_bytes;
+    uint32_t *cache_stamp;        /* shared eval cache: launch stamp the hand-off kernel bumps (NULL otherwise) */
 } azk_leaf_source;
 int32_t azk_leaf_source_of(azk_engine *e, int32_t *n_leaf_dev, azk_leaf_source *out);
 int32_t azk_nn_embed_pool_leaves(const azk_leaf_source *src, const void *wt_ext_bf16_dev, const float *cpos_frag_dev,

@@ -411,6 +411,55 @@ def test_eval_cache_whole_games_identical(azk):
     assert s1["cache_hits"] / s0["leaves_evaluated"] > 0.15          # the reference sees 34-66 %
 
 
+@pytest.mark.parametrize("case", [3, 13, 22])
+def test_shared_eval_cache_is_transparent_on_trees(azk, case):
+    """cache_shared = one table for every game of the engine (the reference's MCTS.cache is process-global, mcts.py:7): entries
+    are written at expansion under a claim word and read from the next tree launch on.  Transparent: every tree equals the
+    oracle's; and a second search of the same positions is served (almost) entirely from the table."""
+    m = next(x for x in _SMETA if x["case"] == case)
+    k = f"c{m['case']}_"
+    from oracle import az_oracle as ao
+    game, tree, cells, player, cnt = oracle_tree(ao, m, k, ao.softmax_det)
+    G = 6
+    eng = azk.Engine(m["game"], G, m["n_sims"], size=m["size"] or None, cache_entries=4096, cache_shared=True)
+    eng.set_positions(np.tile(cells, (G, 1)), [player] * G, [len(_SZ[k + "actions"])] * G)
+    noise = torch.from_numpy(np.tile(_SZ[k + "noise"], (G, 1))).to(dev()) if m["dirichlet"] else None
+    want = digest(tree.export())
+    for rep in range(2):
+        eng.reset_counters()
+        eng.search(gpu_evaluator(game.action_dim, m["variant"]), m["n_sims"], noise)
+        eng.check_error()
+        for g in range(G):
+            assert digest(eng.export_tree(g)) == want
+        c = eng.counters()
+        assert c["leaves_evaluated"] + c["cache_hits"] == G * cnt.expansions
+        if rep == 1 and m["n_sims"] <= 400:
+            assert c["cache_hits"] > 0.8 * G * cnt.expansions
+    eng.clear_cache()
+    eng.reset_counters()
+    eng.search(gpu_evaluator(game.action_dim, m["variant"]), min(8, m["n_sims"]), noise)
+    assert eng.counters()["cache_hits"] <= eng.counters()["leaves_evaluated"]       # cleared: the first leaves miss again
+    eng.close()
+
+
+def test_shared_eval_cache_whole_games_identical_and_hits_more(azk):
+    """Whole self-play batches: no cache, per-game tables, one shared table - the same games, to the bit; the shared table also
+    serves positions another game evaluated first, so it hits at least as often (all games open on the same board)."""
+    from selfplay import self_play_batch
+    A, G = 49, 48
+    ev = gpu_evaluator(A, "hash")
+    s0, s1, s2 = {}, {}, {}
+    plain = self_play_batch("gomoku", ev, G, 64, size=7, seed=9, stats=s0)
+    per_game = self_play_batch("gomoku", ev, G, 64, size=7, seed=9, stats=s1, cache_entries=1024)
+    shared = self_play_batch("gomoku", ev, G, 64, size=7, seed=9, stats=s2, cache_entries=1024, cache_shared=True)
+    for a, b, c in zip(plain, per_game, shared):
+        assert a.cells == b.cells == c.cells and a.winner == b.winner == c.winner
+        assert np.stack(a.pis).tobytes() == np.stack(b.pis).tobytes() == np.stack(c.pis).tobytes() and a.qs == b.qs == c.qs
+    assert s2["leaves_evaluated"] + s2["cache_hits"] == s0["leaves_evaluated"]
+    assert s2["cache_hits"] >= s1["cache_hits"] > 0
+    print("hit rate per-game", s1["cache_hits"] / s0["leaves_evaluated"], "shared", s2["cache_hits"] / s0["leaves_evaluated"])
+
+
 @pytest.mark.parametrize("size,plies,n_sims", [(19, 0, 40), (19, 30, 120), (20, 90, 80), (11, 14, 150)])
 def test_large_and_odd_gomoku_boards_vs_oracle(azk, ao, size, plies, n_sims):
     """Boards beyond 256 cells (19x19, 20x20: seven cells per lane, the 2048-slot set tables) and an odd mid size: legal-move
