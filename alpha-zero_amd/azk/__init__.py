@@ -29,7 +29,7 @@ SYMBOLS = [
     "azk_vanilla_set_rng", "azk_vanilla_get_rng", "azk_vanilla_search", "azk_nn_embed_pool",
     "azk_nn_gemm_rows", "azk_nn_layernorm_sum", "azk_nn_heads_finalize_sum", "azk_nn_ln_heads",
     "azk_leaf_source_of", "azk_nn_embed_pool_leaves", "azk_nn_embed_pool_compact", "azk_nn_embed_pool_compact_leaves",
-    "azk_nn_tail_gemm",
+    "azk_nn_tail_gemm", "azk_begin_search_budget", "azk_search_unfinished",
 ]
 
 
@@ -150,6 +150,8 @@ def lib():
     L.azk_nn_embed_pool_leaves.argtypes = [C.POINTER(LeafSource), vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, C.c_float, vp]
     L.azk_nn_embed_pool_compact.argtypes = [vp, i32, C.POINTER(EmbedPoolConsts), vp, i32, i32, i32, i32, vp, vp, vp]
     L.azk_nn_embed_pool_compact_leaves.argtypes = [C.POINTER(LeafSource), C.POINTER(EmbedPoolConsts), vp, vp, vp]
+    L.azk_begin_search_budget.argtypes = [vp, vp, i32, i32, vp]
+    L.azk_search_unfinished.argtypes = [vp, vp, vp]
     L.azk_nn_tail_gemm.argtypes = [C.POINTER(TailGemm), vp]
     L.azk_nn_ln_heads.argtypes = [vp, vp, vp, C.c_float, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]
     L.azk_nn_gemm_rows.argtypes = [vp, i32, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]
@@ -274,6 +276,22 @@ class Engine:
         self._noise = noise     # keep alive for the whole search
         self._chk(self.L.azk_begin_search(self.h, _p(noise), _stream()))
 
+    def begin_search_budget(self, noise, n_sims, per_launch=8):
+        """begin_search + a simulation budget: afterwards every step lets a game run on inside the launch while its simulations
+        need no evaluator (terminal leaves, eval-cache hits); step until unfinished() == 0, then step_expand_backup once."""
+        if noise is not None:
+            assert noise.dtype == self.torch.float64 and noise.is_cuda and noise.is_contiguous()
+            assert tuple(noise.shape) == (self.G, self.action_dim)
+        assert n_sims <= self.max_sims
+        self._noise = noise
+        self._chk(self.L.azk_begin_search_budget(self.h, _p(noise), int(n_sims), int(per_launch), _stream()))
+
+    def unfinished(self):
+        """Games that still owe simulations of their budget or whose last leaf awaits the evaluator (host sync)."""
+        out = C.c_int32(0)
+        self._chk(self.L.azk_search_unfinished(self.h, C.byref(out), _stream()))
+        return int(out.value)
+
     def step(self, logits=None, values=None):
         """expand+backup the previous leaves (if logits given) and select the next; no host sync."""
         self._chk(self.L.azk_step(self.h, _p(logits), _p(values), _p(self.leaf_boards), _p(self.n_leaf), _stream()))
@@ -331,6 +349,32 @@ class Engine:
                 logits = values = None
         if logits is not None:
             self.step_expand_backup(logits, values)
+
+    def search_budget(self, evaluator, n_sims, noise=None, per_launch=8):
+        """The same search as `search` - bit-identical trees - with budget stepping: a game runs on inside a launch while its
+        simulations need no evaluator, so n_sims simulations take about (share of simulations that miss the cache) * n_sims
+        launches, each with a fuller evaluator batch.  Returns the number of launches."""
+        torch = self.torch
+        self.begin_search_budget(noise, n_sims, per_launch)
+        logits = values = None
+        launches = 0
+        while True:
+            self.step(logits, values)
+            launches += 1
+            n = int(self.n_leaf.item())
+            if n > 0:
+                logits, values = evaluator(self.leaf_boards[:n])
+                logits = logits.to(torch.float32).contiguous()
+                values = values.to(torch.float32).reshape(-1).contiguous()
+                assert logits.shape == (n, self.action_dim) and values.shape[0] == n
+            else:
+                logits, values = (self._no_logits, self._no_values) if self.cache_entries else (None, None)
+                if self.unfinished() == 0:
+                    break
+            assert launches <= 2 * n_sims + 8, "budget stepping does not terminate"
+        if self.cache_entries:
+            self.step_expand_backup(self._no_logits, self._no_values)       # leaves served by the cache in the last launch
+        return launches
 
     # ---- vanilla mode (model=None) ----------------------------------------------------------------
     def vanilla_set_rng(self, states, first=0):

@@ -61,6 +61,8 @@ struct Dev {               // device view of the engine, passed to kernels by va
     int16_t *traj_action;  // [G][state_dim] cell played at each ply of the current game (square boards only, else null)
     double *traj_pi;       // [G][state_dim][A] visit distribution recorded at each ply
     long long *emit_base;  // [G] first tuple index (64-bit: the stream never wraps) of a game being emitted, -1 = not emitting
+    int *sims_done;        // [G] simulations of the current search already run (budget stepping, azk_begin_search_budget)
+    int *budget;           // [2] simulations per search, most simulations per game and launch
     long long *counters;   // [CNT_N][G]
     int *err;              // sticky error word
     int ablate;            // debug only (AZK_TREE_ABLATE): timing experiments that break parity on purpose
@@ -154,7 +156,13 @@ __device__ __forceinline__ void backup_path(const Dev &d, size_t base, const int
 // ================================================================================================
 // DBG: the AZK_TREE_ABLATE experiments and cycle stamps exist only in the <.., true> instantiation; the product kernel
 // (DBG = false) carries none of their branches.
-template <bool EXPAND, bool SELECT, bool DBG>
+// MULTI: a game keeps simulating inside the launch for as long as its simulations need no evaluator - a terminal leaf is backed
+// up at once (mcts.py:25-32) and a leaf served by the eval cache is expanded from the cached row (mcts.py:38-44) - and stops at
+// the first leaf that misses the cache (one pending evaluation per game, as before), at its simulation budget, or after
+// budget[1] simulations.  The order of a game's simulations is untouched (they are sequential inside one wave), so every tree
+// is bit-identical to one-simulation-per-launch stepping; what changes is that ~55 % of the simulations no longer wait for a
+// kernel boundary and every launch hands the evaluator a (nearly) full batch.
+template <bool EXPAND, bool SELECT, bool DBG, bool MULTI = false>
 __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev dd, const float *__restrict__ logits, const float *__restrict__ values) {
     const Dev &d = dd;
     const int ablate = DBG ? dd.ablate : 0;
@@ -166,6 +174,10 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev dd, const float *__restri
     LdsView L = carve(gd, d.path_cap, d.table_size);
     const bool stamp = (ablate & 16) != 0;
     long long t0 = stamp ? clock64() : 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+    int done_sims = MULTI ? d.sims_done[g] : 0;
+    const int sim_target = MULTI ? d.budget[0] : 0, max_iter = MULTI ? d.budget[1] : 1;
+    for (int it = 0; it < max_iter; it++) {
+    if (MULTI && it > 0) __syncthreads();       // the previous simulation's LDS scratch is free and its tree / leaf writes are done
 
     // ---- every load whose address depends only on the game index is issued here, together: ONE memory round trip for
     //      the pending leaf's record, its path and move list, the game's state and board, and the root header ----
@@ -195,6 +207,10 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev dd, const float *__restri
 
     if (EXPAND) {
         const int node = uniform_i32(e_node);
+        if (MULTI && node >= 0 && !(d.cache_entries && uniform_i32(e_centry) >= 0) && (it > 0 || logits == nullptr)) {
+            if (lane == 0) atomicExch(d.err, AZK_ERR_STATE);          // a pending evaluation without its logits: caller error
+            break;
+        }
         if (node >= 0) {
             const bool xst = (ablate & 1024) != 0;              // debug only: cycle stamps of the expansion's sub-phases
             long long x0 = 0, x1 = 0, x2 = 0, x3 = 0, x4 = 0;
@@ -307,10 +323,11 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev dd, const float *__restri
 
     if (SELECT) {
         const bool active = uniform_i32(s_done) == 0;
-        if (!active) {
-            if (lane == 0) d.leaf_flag[g] = 0;
-            return;
+        if (!active || (MULTI && done_sims >= sim_target)) {          // finished game / simulation budget of this search used up
+            if (lane == 0 && (!MULTI || it == 0)) d.leaf_flag[g] = 0;
+            break;
         }
+        done_sims++;
         if (stamp) t1 = clock64();
 #pragma unroll
         for (int k4 = 0; k4 < KSL; k4++) { const int i = lane + AZK_WAVE * k4; if (i < rc) L.board[i] = s_cells[k4]; }
@@ -473,7 +490,8 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev dd, const float *__restri
                 count_add(d, CNT_TERMINAL, g, 1);
                 count_add(d, CNT_TRACE, g, depth + 1);
             }
-            return;
+            if (MULTI) continue;                                      // no evaluation needed: the next simulation starts at once
+            break;
         }
         if (stamp) t3 = clock64();
         int nv;
@@ -543,7 +561,11 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev dd, const float *__restri
                 if (!(ablate & 64) && tend - t0 > q[7]) q[7] = tend - t0;   // slowest simulation of this game
             }
         }
+        if (MULTI && cached) continue;                                // served by the cache: expand it and go on, in this launch
     }
+    break;
+    }
+    if (MULTI && lane == 0) d.sims_done[g] = done_sims;
 }
 
 // Leaf compaction: slot = number of leaf games with a lower index (deterministic order); writes the
@@ -780,6 +802,7 @@ __global__ void k_begin_search(Dev d) {
     d.N[base] = 0; d.W[base] = 0.0; d.P[base] = 0.f; d.meta[base] = meta_pack(0xffff, 0);
     d.first_child[base] = -1;
     d.arena_top[g] = 1; d.leaf_node[g] = -1; d.root_f64[g] = 0; d.leaf_flag[g] = 0;
+    d.sims_done[g] = 0;
 }
 
 __global__ void k_reset_games(Dev d, int first, int count) {
@@ -1182,6 +1205,8 @@ struct azk_engine {
     uint32_t *vanilla_rng = nullptr;     // [G][625] MT19937 key + position (vanilla mode), allocated on first use
     double *lntab = nullptr;             // [lntab_n] math.log(N), from the host libm (the reference's math.log)
     int lntab_n = 0;
+    bool multi = false;                  // budget stepping (azk_begin_search_budget): the MULTI instantiation of k_tree
+    int budget_host[2] = {0, 1};
 };
 
 #define HIPCHK(e, call)                                                                 \
@@ -1245,7 +1270,7 @@ int32_t azk_create(const azk_config *cfg, azk_engine **out) {
     DA(d.leaf_node, G); DA(d.leaf_depth, G); DA(d.leaf_nmoves, G); DA(d.leaf_slot, G);
     DA(d.path, G * d.path_cap); DA(d.leaf_cells, G * d.rc_pad); DA(d.leaf_moves, G * g.rc);
     DA(d.leaf_flag, ((G + 511) / 512) * 512 + 512);
-    DA(d.counters, (size_t)CNT_N * G); DA(d.err, 1); DA(d.dbg, G * 8); DA(d.emit_base, G);
+    DA(d.counters, (size_t)CNT_N * G); DA(d.err, 1); DA(d.dbg, G * 8); DA(d.emit_base, G); DA(d.sims_done, G); DA(d.budget, 2);
     d.cache_entries = cfg->cache_entries;
     d.key_words = 2 * ((g.rc + 64) / 64);                         // one spare bit (63 of the last own-plane word) for the side to move
     d.cache_shared = (d.cache_entries && cfg->cache_shared) ? 1 : 0;
@@ -1339,8 +1364,43 @@ int32_t azk_set_positions(azk_engine *e, int32_t first, int32_t count, const int
 int32_t azk_begin_search(azk_engine *e, const double *noise_dev, void *stream) {
     if (!e) return AZK_ERR_ARG;
     e->d.noise = noise_dev;
+    e->multi = false;
     k_begin_search<<<(unsigned)((e->d.G + 255) / 256), 256, 0, (hipStream_t)stream>>>(e->d);
     HIPCHK(e, hipGetLastError());
+    return AZK_OK;
+}
+
+int32_t azk_begin_search_budget(azk_engine *e, const double *noise_dev, int32_t n_sims, int32_t max_sims_per_launch, void *stream) {
+    if (!e || n_sims < 1 || n_sims > e->cfg.max_sims || max_sims_per_launch < 1) { if (e) e->err = "azk_begin_search_budget: bad argument"; return AZK_ERR_ARG; }
+    e->d.noise = noise_dev;
+    e->multi = true;
+    if (e->budget_host[0] != n_sims || e->budget_host[1] != max_sims_per_launch) {
+        // the budget lives in device memory so that a captured step graph keeps working when it changes
+        e->budget_host[0] = n_sims; e->budget_host[1] = max_sims_per_launch;
+        HIPCHK(e, hipMemcpyAsync(e->d.budget, e->budget_host, sizeof e->budget_host, hipMemcpyHostToDevice, (hipStream_t)stream));
+        HIPCHK(e, hipStreamSynchronize((hipStream_t)stream));
+    }
+    k_begin_search<<<(unsigned)((e->d.G + 255) / 256), 256, 0, (hipStream_t)stream>>>(e->d);
+    HIPCHK(e, hipGetLastError());
+    return AZK_OK;
+}
+
+namespace {
+__global__ void k_unfinished(Dev d, int *out) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool open = g < d.G && d.done[g] == 0 && (d.sims_done[g] < d.budget[0] || (d.leaf_node[g] >= 0 && d.leaf_flag[g]));
+    const unsigned long long m = __ballot(open);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(out, __popcll(m));
+}
+}  // namespace
+
+int32_t azk_search_unfinished(azk_engine *e, int32_t *count_host, void *stream) {
+    if (!e || !count_host) return AZK_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(e, hipMemsetAsync(e->n_leaf_scratch, 0, sizeof(int), st));
+    k_unfinished<<<(unsigned)((e->d.G + 255) / 256), 256, 0, st>>>(e->d, e->n_leaf_scratch);
+    HIPCHK(e, hipMemcpyAsync(count_host, e->n_leaf_scratch, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(e, hipStreamSynchronize(st));
     return AZK_OK;
 }
 
@@ -1353,6 +1413,10 @@ static int32_t launch_tree(azk_engine *e, bool expand, bool select, const float 
         if (expand && select) k_tree<true, true, true><<<d.G, AZK_WAVE, d.lds_bytes, st>>>(d, logits, values);
         else if (expand) k_tree<true, false, true><<<d.G, AZK_WAVE, d.lds_bytes, st>>>(d, logits, values);
         else k_tree<false, true, true><<<d.G, AZK_WAVE, d.lds_bytes, st>>>(d, logits, values);
+    } else if (e->multi && select) {
+        // budget stepping always carries the expansion code: a leaf served by the cache is expanded inside the launch (logits may
+        // be null when no game has a pending evaluation, e.g. in a search's first launch)
+        k_tree<true, true, false, true><<<d.G, AZK_WAVE, d.lds_bytes, st>>>(d, logits, values);
     } else if (expand && select) k_tree<true, true, false><<<d.G, AZK_WAVE, d.lds_bytes, st>>>(d, logits, values);
     else if (expand) k_tree<true, false, false><<<d.G, AZK_WAVE, d.lds_bytes, st>>>(d, logits, values);
     else k_tree<false, true, false><<<d.G, AZK_WAVE, d.lds_bytes, st>>>(d, logits, values);
@@ -1388,6 +1452,8 @@ int32_t azk_step_tree(azk_engine *e, const float *logits_dev, const float *value
     if (d.ablate) {
         if (logits_dev) k_tree<true, true, true><<<d.G, AZK_WAVE, d.lds_bytes, st>>>(d, logits_dev, values_dev);
         else k_tree<false, true, true><<<d.G, AZK_WAVE, d.lds_bytes, st>>>(d, nullptr, nullptr);
+    } else if (e->multi) {
+        k_tree<true, true, false, true><<<d.G, AZK_WAVE, d.lds_bytes, st>>>(d, logits_dev, values_dev);
     } else if (logits_dev) k_tree<true, true, false><<<d.G, AZK_WAVE, d.lds_bytes, st>>>(d, logits_dev, values_dev);
     else k_tree<false, true, false><<<d.G, AZK_WAVE, d.lds_bytes, st>>>(d, nullptr, nullptr);
     HIPCHK(e, hipGetLastError());

@@ -41,7 +41,8 @@ class SelfPlayResult:
 
 def self_play_batch(game, evaluator, n_games, n_sims, size=None, seed=0, first_global_game=0, dirichlet=True,
                     alpha=0.03, noise_fn=None, uniform_fn=None, device=0, leaf_dtype="float32", engine=None,
-                    max_moves=None, sample_until=None, stats=None, replay=None, cache_entries=0, vanilla_rng=None, cache_shared=False):
+                    max_moves=None, sample_until=None, stats=None, replay=None, cache_entries=0, vanilla_rng=None, cache_shared=False,
+                    budget_stepping=False):
     """Play n_games games to the end in one batch.
 
     evaluator(boards[n,F,R,C] CUDA) -> (logits [n,A], values [n] | [n,1]).
@@ -89,6 +90,8 @@ def self_play_batch(game, evaluator, n_games, n_sims, size=None, seed=0, first_g
         ns = n_sims[move & 1] if isinstance(n_sims, (tuple, list)) else n_sims
         if ev is None:
             eng.vanilla_search(ns, chunk=vanilla_chunk)
+        elif budget_stepping:
+            eng.search_budget(ev, ns, noise if dirichlet else None)
         else:
             eng.search(ev, ns, noise if dirichlet else None)
         pi, q, _ = eng.root_stats()
@@ -156,10 +159,12 @@ class SelfPlayRunner:
 
     def __init__(self, game, evaluator, n_games, n_sims, size=None, seed=0, first_global_game=0, dirichlet=True,
                  alpha=0.03, device=0, leaf_dtype="float32", recycle=True, on_records=None, kernel_timer=None,
-                 use_graph=False, n_split=1, replay=None, cache_entries=0, cache_shared=False):
+                 use_graph=False, n_split=1, replay=None, cache_entries=0, cache_shared=False, budget_stepping=False, per_launch=8):
         import torch
         self.replay = replay
         self.torch = torch
+        self.budget_stepping, self.per_launch = budget_stepping and use_graph, per_launch
+        self.launches = 0               # simulation-step launches issued (per game group) since construction
         self.use_graph = use_graph
         self._graph = None
         assert n_games % n_split == 0
@@ -293,11 +298,15 @@ class SelfPlayRunner:
             cur.wait_stream(st)
 
     def search_graph(self):
-        """n_sims replays of captured hipGraphs (per group: k_tree -> k_gather -> evaluator kernels).  Each group has its
-        own graph, replayed on its own stream, so the groups' kernels can overlap on the GPU."""
+        """Replays of captured hipGraphs (per group: k_tree -> evaluator kernels).  Each group has its own graph, replayed on its
+        own stream.  One-simulation stepping replays n_sims times; budget stepping (games run on inside a launch while their
+        simulations need no evaluator) replays until no game owes simulations - about 45 % of n_sims at the benchmark config."""
         torch = self.torch
         for h in self.halves:
-            h.eng.begin_search(h.noise_buf)
+            if self.budget_stepping:
+                h.eng.begin_search_budget(h.noise_buf, self.n_sims, self.per_launch)
+            else:
+                h.eng.begin_search(h.noise_buf)
         cur = torch.cuda.current_stream()
         if self._graph is None:
             # the first simulations run eagerly on a side stream (allocator warm-up), the capture records one more
@@ -315,14 +324,15 @@ class SelfPlayRunner:
                 with torch.cuda.graph(g):
                     self._step_body(h)
                 self._graph.append(g)
-            done = 4
+            done = 3                     # the three eager steps ran; the captured one was only recorded
         else:
             done = 0
         kt = self.kernel_timer
         streams = self.streams if self.n_split > 1 else [cur]
         for st in self.streams:
             st.wait_stream(cur)
-        for s in range(done, self.n_sims):
+
+        def replay(s):
             timed = kt is not None and kt.want(s)
             for h, g, st in zip(self.halves, self._graph, streams):
                 with torch.cuda.stream(st):
@@ -331,6 +341,26 @@ class SelfPlayRunner:
                         self._step_body(h, timer=kt)
                     else:
                         g.replay()
+        if not self.budget_stepping:
+            for s in range(done, self.n_sims):
+                replay(s)
+            self.launches += self.n_sims
+        else:
+            # no game can finish before its budget's worth of cache misses: a first stretch without looking, then a look (one
+            # 4-byte read-back) every few launches
+            s, first = done, max(done, int(0.36 * self.n_sims))
+            while True:
+                stop = first if s < first else s + 8
+                while s < stop:
+                    replay(s)
+                    s += 1
+                for st in self.streams:
+                    cur.wait_stream(st)
+                if all(h.eng.unfinished() == 0 for h in self.halves):
+                    break
+                if s > 2 * self.n_sims + 16:
+                    raise RuntimeError("budget stepping does not terminate")
+            self.launches += s
         for h, st in zip(self.halves, streams):
             with torch.cuda.stream(st):
                 h.eng.step_expand_backup(h.logits_buf, h.values_buf)

@@ -193,6 +193,11 @@ def main():
     ap.add_argument("--cache", default="shared", choices=["shared", "per-game"],
                     help="eval cache: one table shared by every game of the GPU (the reference's MCTS.cache is process-global, mcts.py:7) or one "
                          "table per game; same memory, same results, different hit rate")
+    ap.add_argument("--budget-stepping", type=int, default=0,
+                    help="1: a game keeps simulating inside a tree launch while its simulations need no evaluator (terminal leaves, eval-cache "
+                         "hits) - same trees.  Measured SLOWER under per-move lock-step (236 vs 126 ms/move): the launch count of a move is set "
+                         "by its slowest game (early-ply games miss the cache almost always) while every launch lasts as long as its busiest "
+                         "wave; it needs asynchronous moves to pay (DESIGN.md section 10).  0 (default): one simulation per game and launch")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="wall-clock budget of the CPU baseline leg (0 = skip)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--train-step", action="store_true",
@@ -260,7 +265,7 @@ def main():
                                 first_global_game=shard_range(args.games, rank)[0], device=local_rank,
                                 leaf_dtype="bfloat16" if args.nn_dtype == "bf16" else "float32",
                                 recycle=True, kernel_timer=kt, use_graph=not args.no_graph, n_split=args.split, cache_entries=args.cache_entries,
-                                cache_shared=args.cache == "shared", replay=replay)
+                                cache_shared=args.cache == "shared", replay=replay, budget_stepping=bool(args.budget_stepping))
 
     def train_one():
         """train.train with one iteration (train.py:85-123): fresh Adam, the reference's loss, gradient bucket all-reduce.

@@ -102,6 +102,14 @@ int32_t azk_set_positions(azk_engine *e, int32_t first, int32_t count, const int
  * dirichlet=False.  The pointer is read by later steps: keep it alive until the search ends. */
 int32_t azk_begin_search(azk_engine *e, const double *noise_dev, void *stream);
 
+/* Budget stepping: like azk_begin_search, plus a simulation budget per game.  After it, every azk_step / azk_step_tree lets a game
+ * run on inside the launch while its simulations need no evaluator (terminal leaves, leaves served by the eval cache) and stop at
+ * the first leaf that does, at n_sims simulations in all, or after max_sims_per_launch in one launch.  A game's simulations stay
+ * strictly sequential, so trees and games are bit-identical to one-simulation-per-call stepping; the caller steps until
+ * azk_search_unfinished reports 0 (games still owing simulations or an evaluation), then calls azk_step_expand_backup once. */
+int32_t azk_begin_search_budget(azk_engine *e, const double *noise_dev, int32_t n_sims, int32_t max_sims_per_launch, void *stream);
+int32_t azk_search_unfinished(azk_engine *e, int32_t *count_host, void *stream);
+
 /* One simulation per active game (ai/mcts.py:16-60), split around the evaluator:
  *   azk_step_select   - mcts.py:18-37: PUCT walk (node.py:42-47, utils.py:29-44), make_move along the
  *                       path, terminal test + immediate backup, get_valid_moves, canonical board.

@@ -460,6 +460,49 @@ def test_shared_eval_cache_whole_games_identical_and_hits_more(azk):
     print("hit rate per-game", s1["cache_hits"] / s0["leaves_evaluated"], "shared", s2["cache_hits"] / s0["leaves_evaluated"])
 
 
+@pytest.mark.parametrize("case", [3, 10, 13, 18, 22])
+@pytest.mark.parametrize("cache", ["off", "per-game", "shared"])
+def test_budget_stepping_builds_the_same_trees(azk, case, cache):
+    """azk_begin_search_budget: a game keeps simulating inside a launch while its simulations need no evaluator (terminal leaves,
+    eval-cache hits) - fewer launches, fuller evaluator batches, and the SAME trees to the last bit (a game's simulations stay
+    sequential).  Checked against the oracle's tree on golden positions (near-terminal ones included), with every cache mode."""
+    m = next(x for x in _SMETA if x["case"] == case)
+    k = f"c{m['case']}_"
+    from oracle import az_oracle as ao
+    game, tree, cells, player, cnt = oracle_tree(ao, m, k, ao.softmax_det)
+    G = 5
+    eng = azk.Engine(m["game"], G, m["n_sims"], size=m["size"] or None, cache_entries=0 if cache == "off" else 2048, cache_shared=cache == "shared")
+    eng.set_positions(np.tile(cells, (G, 1)), [player] * G, [len(_SZ[k + "actions"])] * G)
+    noise = torch.from_numpy(np.tile(_SZ[k + "noise"], (G, 1))).to(dev()) if m["dirichlet"] else None
+    want = digest(tree.export())
+    for rep in range(2):
+        eng.reset_counters()
+        launches = eng.search_budget(gpu_evaluator(game.action_dim, m["variant"]), m["n_sims"], noise, per_launch=6)
+        eng.check_error()
+        for g in range(G):
+            assert digest(eng.export_tree(g)) == want
+        c = eng.counters()
+        assert c["sims"] == G * m["n_sims"]
+        assert c["leaves_evaluated"] + c["cache_hits"] == G * cnt.expansions
+        assert launches <= m["n_sims"] + 2
+        if cnt.terminal_sims > 0.2 * m["n_sims"] or (rep == 1 and cache != "off"):
+            assert launches < 0.95 * m["n_sims"], (launches, m["n_sims"])   # simulations that needed no evaluator did not cost a launch
+    eng.close()
+
+
+def test_budget_stepping_whole_games_identical(azk):
+    from selfplay import self_play_batch
+    A, G = 49, 24
+    ev = gpu_evaluator(A, "hash")
+    s0, s1 = {}, {}
+    plain = self_play_batch("gomoku", ev, G, 64, size=7, seed=9, stats=s0, cache_entries=1024)
+    fast = self_play_batch("gomoku", ev, G, 64, size=7, seed=9, stats=s1, cache_entries=1024, budget_stepping=True)
+    for a, b in zip(plain, fast):
+        assert a.cells == b.cells and a.winner == b.winner
+        assert np.stack(a.pis).tobytes() == np.stack(b.pis).tobytes() and a.qs == b.qs
+    assert s0["sims"] == s1["sims"] and s0["leaves_evaluated"] == s1["leaves_evaluated"] and s0["cache_hits"] == s1["cache_hits"]
+
+
 @pytest.mark.parametrize("size,plies,n_sims", [(19, 0, 40), (19, 30, 120), (20, 90, 80), (11, 14, 150)])
 def test_large_and_odd_gomoku_boards_vs_oracle(azk, ao, size, plies, n_sims):
     """Boards beyond 256 cells (19x19, 20x20: seven cells per lane, the 2048-slot set tables) and an odd mid size: legal-move

@@ -453,3 +453,26 @@ def test_tail_chain_vs_torch_fp32_and_library_tail():
     net.out_buffers, net.live_count = None, None
     l2, v2 = net.tail_fast(z)
     assert torch.equal(l2, lc) and torch.equal(v2, vc)
+
+
+def test_runner_budget_stepping_plays_the_same_moves():
+    """SelfPlayRunner with budget stepping (graph replays until no game owes simulations) against one-simulation-per-replay
+    stepping, real network, continuous self-play with recycling: the same pi and the same moves, in fewer launches."""
+    from selfplay import SelfPlayRunner
+    cfg = NetConfig(15, 15, 2, 225, 5, 512, 8, 1)
+    net = PolicyValueNet(cfg, seed=6, device="cuda", dtype=torch.bfloat16, path="clsfold")
+
+    def play(budget):
+        rec = []
+        r = SelfPlayRunner("gomoku", net, 128, 96, size=15, seed=9, leaf_dtype="bfloat16", recycle=True, use_graph=True, cache_entries=256,
+                           cache_shared=True, budget_stepping=budget,
+                           on_records=lambda mv, base, pi, q, ch, w, d: rec.append((pi.numpy().copy(), ch.numpy().copy())))
+        for _ in range(4):
+            r.play_move()
+        r.check_error()
+        return rec, r.launches, r.counters()
+    (a, la, ca), (b, lb, cb) = play(False), play(True)
+    for (pa, cha), (pb, chb) in zip(a, b):
+        assert np.array_equal(cha, chb) and pa.tobytes() == pb.tobytes()
+    assert ca["sims"] == cb["sims"] == 4 * 128 * 96
+    assert lb <= la + 4, (la, lb)          # early-game searches hit few terminals / cache entries: about as many launches, never more
