@@ -40,7 +40,8 @@ class AzkError(RuntimeError):
 class Config(C.Structure):
     _fields_ = [("game", C.c_int32), ("rows", C.c_int32), ("cols", C.c_int32), ("n_games", C.c_int32),
                 ("max_sims", C.c_int32), ("leaf_dtype", C.c_int32), ("device", C.c_int32),
-                ("arena_nodes", C.c_int32), ("cache_entries", C.c_int32), ("cache_shared", C.c_int32), ("reserved", C.c_int32 * 6)]
+                ("arena_nodes", C.c_int32), ("cache_entries", C.c_int32), ("cache_shared", C.c_int32), ("leaves_per_step", C.c_int32),
+                ("reserved", C.c_int32 * 5)]
 
 
 class LeafSource(C.Structure):
@@ -194,7 +195,7 @@ class Engine:
     """G concurrent games + their search trees resident on one GPU (one engine per process / GPU)."""
 
     def __init__(self, game, n_games, max_sims, size=None, device=0, leaf_dtype="float32", arena_nodes=0, cache_entries=0,
-                 cache_shared=False):
+                 cache_shared=False, leaves_per_step=1):
         torch = _torch()
         self.torch = torch
         self.L = lib()
@@ -206,6 +207,9 @@ class Engine:
         cfg.cache_entries = int(cache_entries)
         cfg.cache_shared = 1 if (cache_shared and cache_entries) else 0      # one table for all games (the reference's process-global MCTS.cache)
         self.cache_shared = bool(cfg.cache_shared)
+        # OPT-IN virtual-loss expansion: K leaves in flight per game (changes search results; 1 = the reference's sequential search)
+        self.K = max(1, int(leaves_per_step))
+        cfg.leaves_per_step = self.K
         cfg.leaf_dtype = LEAF_BF16 if leaf_dtype in ("bfloat16", "bf16", torch.bfloat16) else LEAF_F32
         self.device = torch.device("cuda", device)
         torch.cuda.set_device(self.device)
@@ -220,7 +224,8 @@ class Engine:
         self.G, self.max_sims = int(n_games), int(max_sims)
         tdt = torch.bfloat16 if cfg.leaf_dtype == LEAF_BF16 else torch.float32
         dev = self.device
-        self.leaf_boards = torch.zeros((self.G, self.planes, self.rows, self.cols), dtype=tdt, device=dev)
+        self.slots = self.G * self.K                # pending-leaf slots = capacity of one evaluator batch
+        self.leaf_boards = torch.zeros((self.slots, self.planes, self.rows, self.cols), dtype=tdt, device=dev)
         self.n_leaf = torch.zeros(1, dtype=torch.int32, device=dev)
         self.pi = torch.zeros((self.G, self.action_dim), dtype=torch.float64, device=dev)
         self.q = torch.zeros(self.G, dtype=torch.float64, device=dev)
@@ -231,8 +236,9 @@ class Engine:
         self._noise = None
         self.cache_entries = int(cache_entries)
         # with the eval cache a step can have pending (cached) leaves to expand although no leaf went to the evaluator
-        self._no_logits = torch.zeros((1, self.action_dim), dtype=torch.float32, device=dev) if cache_entries else None
-        self._no_values = torch.zeros(1, dtype=torch.float32, device=dev) if cache_entries else None
+        need = cache_entries or self.K > 1
+        self._no_logits = torch.zeros((1, self.action_dim), dtype=torch.float32, device=dev) if need else None
+        self._no_values = torch.zeros(1, dtype=torch.float32, device=dev) if need else None
 
     def _chk(self, rc):
         if rc < 0:
@@ -368,11 +374,11 @@ class Engine:
                 values = values.to(torch.float32).reshape(-1).contiguous()
                 assert logits.shape == (n, self.action_dim) and values.shape[0] == n
             else:
-                logits, values = (self._no_logits, self._no_values) if self.cache_entries else (None, None)
+                logits, values = (self._no_logits, self._no_values) if self._no_logits is not None else (None, None)
                 if self.unfinished() == 0:
                     break
             assert launches <= 2 * n_sims + 8, "budget stepping does not terminate"
-        if self.cache_entries:
+        if self.cache_entries and self.K == 1:
             self.step_expand_backup(self._no_logits, self._no_values)       # leaves served by the cache in the last launch
         return launches
 

@@ -23,6 +23,8 @@ enum { CNT_SIMS = 0, CNT_SCANNED, CNT_TRACE, CNT_CREATED, CNT_LEAVES, CNT_TERMIN
 struct Dev {               // device view of the engine, passed to kernels by value
     GameDesc g;
     int G, cap, path_cap, rc_pad, leaf_dtype, table_size, lds_bytes;
+    int K;                 // leaves in flight per game (virtual-loss mode, opt-in; 1 = the reference's sequential search).  Every
+                           // pending-leaf array below is [G * K], slot v = g * K + k
     // game state
     uint8_t *cells;        // [G][rc_pad]  cell codes (1 = player 0, 2 = player 1)
     int *to_move, *move_count, *done, *winner;   // [G]
@@ -40,7 +42,8 @@ struct Dev {               // device view of the engine, passed to kernels by va
     int *path;             // [G][path_cap]
     uint8_t *leaf_cells;   // [G][rc_pad] board at the leaf
     int16_t *leaf_moves;   // [G][rc] valid moves at the leaf, reference list order
-    uint8_t *leaf_flag;    // [G] 1 = this game contributes a leaf to the evaluator batch this step
+    uint8_t *leaf_flag;    // [G * K] 1 = this slot contributes a leaf to the evaluator batch this step
+    int *to_move_v;        // [G * K] to_move of the slot's game (K > 1: what the leaf hand-off kernels index by slot)
     const double *noise;   // [G][A] or nullptr
     // eval cache (MCTS.cache, ai/mcts.py:7,38-51): per-game direct-mapped table keyed by the exact canonical position
     int cache_entries, key_words;          // entries per game (power of two, 0 = off); 64-bit words per key
@@ -140,10 +143,11 @@ __device__ __forceinline__ void count_add(const Dev &d, int which, int g, long l
 }
 
 // Node.backup (node.py:62-74): the node at trace index i gets value * (-1)^(depth - i); lanes take one node each.
-__device__ __forceinline__ void backup_path(const Dev &d, size_t base, const int *path, int depth, double value) {
+__device__ __forceinline__ void backup_path(const Dev &d, size_t base, const int *path, int depth, double value, bool undo_virtual_loss = false) {
     for (int i = azk_lane(); i <= depth; i += AZK_WAVE) {
         int nd = path[i];
         double sv = ((depth - i) & 1) ? -value : value;
+        if (undo_virtual_loss) { d.W[base + nd] += sv + 1.0; continue; }      // the visit was counted at selection
         d.N[base + nd] += 1;
         d.W[base + nd] += sv;
     }
@@ -178,22 +182,26 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev dd, const float *__restri
     const int sim_target = MULTI ? d.budget[0] : 0, max_iter = MULTI ? d.budget[1] : 1;
     for (int it = 0; it < max_iter; it++) {
     if (MULTI && it > 0) __syncthreads();       // the previous simulation's LDS scratch is free and its tree / leaf writes are done
+    // virtual-loss mode (K > 1, opt-in, changes search results): iteration k serves slot k - it expands the slot's pending leaf,
+    // then selects a new one with a virtual loss left on its path so that the other slots' selections move elsewhere
+    const bool vl = MULTI && d.K > 1;
+    const int vi = g * d.K + (vl ? it : 0);
 
     // ---- every load whose address depends only on the game index is issued here, together: ONE memory round trip for
     //      the pending leaf's record, its path and move list, the game's state and board, and the root header ----
-    const int e_node = EXPAND ? d.leaf_node[g] : -1, e_slot = EXPAND ? d.leaf_slot[g] : 0, e_depth = EXPAND ? d.leaf_depth[g] : 0;
-    const int e_nv = EXPAND ? d.leaf_nmoves[g] : 0, e_top = EXPAND ? d.arena_top[g] : 0;
-    const int e_centry = (EXPAND && d.cache_entries) ? d.leaf_cache[g] : -1;
+    const int e_node = EXPAND ? d.leaf_node[vi] : -1, e_slot = EXPAND ? d.leaf_slot[vi] : 0, e_depth = EXPAND ? d.leaf_depth[vi] : 0;
+    const int e_nv = EXPAND ? d.leaf_nmoves[vi] : 0, e_top = EXPAND ? d.arena_top[g] : 0;
+    const int e_centry = (EXPAND && d.cache_entries) ? d.leaf_cache[vi] : -1;
     const bool shared = d.cache_entries && d.cache_shared;
     const unsigned cstamp = shared ? d.cache_stamp[0] : 0u;
     unsigned long long e_key = 0ull;
-    if (EXPAND && shared && lane < d.key_words) e_key = d.leaf_key[(size_t)g * d.key_words + lane];
-    const int e_path = (EXPAND && lane < d.path_cap) ? d.path[(size_t)g * d.path_cap + lane] : 0;     // trace nodes 0..63 (deeper ones: below)
+    if (EXPAND && shared && lane < d.key_words) e_key = d.leaf_key[(size_t)vi * d.key_words + lane];
+    const int e_path = (EXPAND && lane < d.path_cap) ? d.path[(size_t)vi * d.path_cap + lane] : 0;     // trace nodes 0..63 (deeper ones: below)
     constexpr int KSL = 7;                                  // cells per lane: rc <= 448 (make_game allows 400)
     int e_mv[KSL] = {0, 0, 0, 0, 0, 0, 0};
     if (EXPAND) {
 #pragma unroll
-        for (int k4 = 0; k4 < KSL; k4++) { const int i = lane + AZK_WAVE * k4; if (i < rc) e_mv[k4] = d.leaf_moves[(size_t)g * rc + i]; }
+        for (int k4 = 0; k4 < KSL; k4++) { const int i = lane + AZK_WAVE * k4; if (i < rc) e_mv[k4] = d.leaf_moves[(size_t)vi * rc + i]; }
     }
     const int s_done = SELECT ? d.done[g] : 1, s_player = SELECT ? d.to_move[g] : 0, s_mc = SELECT ? d.move_count[g] : 0;
     int s_rootf64 = SELECT ? d.root_f64[g] : 0;
@@ -207,7 +215,7 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev dd, const float *__restri
 
     if (EXPAND) {
         const int node = uniform_i32(e_node);
-        if (MULTI && node >= 0 && !(d.cache_entries && uniform_i32(e_centry) >= 0) && (it > 0 || logits == nullptr)) {
+        if (MULTI && node >= 0 && !(d.cache_entries && uniform_i32(e_centry) >= 0) && ((!vl && it > 0) || logits == nullptr)) {
             if (lane == 0) atomicExch(d.err, AZK_ERR_STATE);          // a pending evaluation without its logits: caller error
             break;
         }
@@ -221,7 +229,7 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev dd, const float *__restri
             const int centry = d.cache_entries ? uniform_i32(e_centry) : -1;
             const bool hit = d.cache_entries && centry >= 0;
             const size_t crow = shared ? (size_t)(hit ? centry : -(centry + 1)) : ((size_t)g * d.cache_entries + (hit ? centry : -(centry + 1)));
-            const float *lg = hit ? (shared ? d.hit_logits + (size_t)g * A : d.cache_logits + crow * A) : logits + (size_t)slot * A;
+            const float *lg = hit ? (shared ? d.hit_logits + (size_t)vi * A : d.cache_logits + crow * A) : logits + (size_t)slot * A;
             unsigned claim_now = 0u;
             if (shared && !hit) claim_now = __hip_atomic_load(d.cache_claim + crow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             // Node.backup operands (trace nodes 0..depth, one per lane) are fetched now, next to the logits: second round trip
@@ -233,7 +241,7 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev dd, const float *__restri
             float lgv[KSL];
 #pragma unroll
             for (int k4 = 0; k4 < KSL; k4++) { const int i = lane + AZK_WAVE * k4; lgv[k4] = lg[i < A ? i : A - 1]; }
-            const float vraw = hit ? (shared ? d.hit_value[g] : d.cache_value[crow]) : values[slot];
+            const float vraw = hit ? (shared ? d.hit_value[vi] : d.cache_value[crow]) : values[slot];
             const uint32_t node_meta = d.meta[base + node];
             const bool mix = depth == 0 && d.noise != nullptr;        // mcts.py:42-43,52-53
             double nzv[KSL] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
@@ -301,20 +309,21 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev dd, const float *__restri
             const double v = -(double)vraw;                          // mcts.py:56
             if (shortpath) {                                          // Node.backup (node.py:62-74) on the operands fetched above
                 if (lane <= depth) {
-                    d.N[base + e_path] = bN + 1;
-                    d.W[base + e_path] = bW + (((depth - lane) & 1) ? -v : v);
+                    // virtual-loss mode: the visit was already counted at selection and the value carries the loss (-1) left there
+                    d.N[base + e_path] = vl ? bN : bN + 1;
+                    d.W[base + e_path] = bW + (((depth - lane) & 1) ? -v : v) + (vl ? 1.0 : 0.0);
                 }
             } else {
-                backup_path(d, base, d.path + (size_t)g * d.path_cap, depth, v);
+                backup_path(d, base, d.path + (size_t)vi * d.path_cap, depth, v, vl);
             }
-            r_N += 1;                                                 // the root is trace node 0 of every simulation
+            if (!vl) r_N += 1;                                        // the root is trace node 0 of every simulation
             if (xst && lane == 0) {
                 x4 = clock64();
                 long long *qq = d.dbg + (size_t)g * 8;
                 qq[0] += x0 - t0; qq[1] += x1 - x0; qq[2] += x2 - x1; qq[3] += x3 - x2; qq[4] += x4 - x3; qq[6] += 1;
             }
             if (lane == 0) {
-                d.leaf_node[g] = -1;
+                d.leaf_node[vi] = -1;
                 count_add(d, CNT_TRACE, g, depth + 1);
             }
         }
@@ -324,7 +333,8 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev dd, const float *__restri
     if (SELECT) {
         const bool active = uniform_i32(s_done) == 0;
         if (!active || (MULTI && done_sims >= sim_target)) {          // finished game / simulation budget of this search used up
-            if (lane == 0 && (!MULTI || it == 0)) d.leaf_flag[g] = 0;
+            if (lane == 0 && (!MULTI || it == 0 || vl)) d.leaf_flag[vi] = 0;
+            if (vl) continue;                                         // the other slots may still hold leaves to expand
             break;
         }
         done_sims++;
@@ -471,6 +481,11 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev dd, const float *__restri
         }
         __syncthreads();
         if (stamp) t2 = clock64();
+        if (vl && fc == -2) {                                         // the walk ended on a node another slot is already evaluating: no simulation
+            done_sims--;
+            if (lane == 0) d.leaf_flag[vi] = 0;
+            continue;
+        }
         const int node_player = (root_player + depth) & 1;
         const int node_mc = root_mc + depth;
         int term = -1;
@@ -486,7 +501,7 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev dd, const float *__restri
         if (term >= 0) {
             backup_path(d, base, L.path, depth, (double)term);
             if (lane == 0) {
-                d.leaf_flag[g] = 0;
+                d.leaf_flag[vi] = 0;
                 count_add(d, CNT_TERMINAL, g, 1);
                 count_add(d, CNT_TRACE, g, depth + 1);
             }
@@ -498,9 +513,13 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev dd, const float *__restri
         if (ablate & 4) { nv = 1; if (lane == 0) L.moves[0] = (int16_t)(gd.rc / 2); __syncthreads(); }
         else nv = azk_valid_moves(L.board, gd, L.moves, L.ms, (ablate & 8) != 0, (ablate & 32) ? d.dbg + (size_t)g * 8 : nullptr);  // mcts.py:34
         if (stamp) t4 = clock64();
-        for (int i = lane; i < nv; i += AZK_WAVE) d.leaf_moves[(size_t)g * rc + i] = L.moves[i];
-        for (int i = lane; i < rc; i += AZK_WAVE) d.leaf_cells[(size_t)g * d.rc_pad + i] = L.board[i];
-        for (int i = lane; i <= depth; i += AZK_WAVE) d.path[(size_t)g * d.path_cap + i] = L.path[i];
+        for (int i = lane; i < nv; i += AZK_WAVE) d.leaf_moves[(size_t)vi * rc + i] = L.moves[i];
+        for (int i = lane; i < rc; i += AZK_WAVE) d.leaf_cells[(size_t)vi * d.rc_pad + i] = L.board[i];
+        for (int i = lane; i <= depth; i += AZK_WAVE) d.path[(size_t)vi * d.path_cap + i] = L.path[i];
+        if (vl) {                                                     // virtual loss: the path counts a visit now and a lost game until its value arrives
+            for (int i = lane; i <= depth; i += AZK_WAVE) { const int nd = L.path[i]; d.N[base + nd] += 1; d.W[base + nd] -= 1.0; }
+            if (lane == 0) d.first_child[base + node] = -2;           // "expansion pending": a second slot arriving here gives up
+        }
         bool cached = false;
         if (d.cache_entries) {                                        // mcts.py:37-44: key = canonical board bytes
             // key = ballots of "own stone" / "opponent stone" over the cells (own = the side to move at the leaf)
@@ -534,12 +553,12 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev dd, const float *__restri
                         if (c2 == c1) {                               // nobody started rewriting the entry meanwhile: the copy is whole
                             cached = true;
 #pragma unroll
-                            for (int k4 = 0; k4 < KSL; k4++) { const int i = lane + AZK_WAVE * k4; if (i < A) d.hit_logits[(size_t)g * A + i] = row[k4]; }
-                            if (lane == 0) d.hit_value[g] = vv;
+                            for (int k4 = 0; k4 < KSL; k4++) { const int i = lane + AZK_WAVE * k4; if (i < A) d.hit_logits[(size_t)vi * A + i] = row[k4]; }
+                            if (lane == 0) d.hit_value[vi] = vv;
                         }
                     }
                 }
-                if (!cached && lane < KW) d.leaf_key[(size_t)g * KW + lane] = mykey;      // written into the table at expansion
+                if (!cached && lane < KW) d.leaf_key[(size_t)vi * KW + lane] = mykey;      // written into the table at expansion
             } else {
                 entry = (int)(h & (unsigned long long)(d.cache_entries - 1));
                 unsigned long long *kp = d.cache_key + ((size_t)g * d.cache_entries + entry) * KW;
@@ -547,11 +566,11 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev dd, const float *__restri
                 cached = __ballot(!same) == 0ull;
                 if (!cached && lane < KW) kp[lane] = mykey;            // claim the slot now; logits/value land at expansion
             }
-            if (lane == 0) d.leaf_cache[g] = cached ? entry : -(entry + 1);
+            if (lane == 0) d.leaf_cache[vi] = cached ? entry : -(entry + 1);
         }
         if (lane == 0) {
-            d.leaf_node[g] = node; d.leaf_depth[g] = depth; d.leaf_nmoves[g] = nv;
-            d.leaf_flag[g] = cached ? 0 : 1;
+            d.leaf_node[vi] = node; d.leaf_depth[vi] = depth; d.leaf_nmoves[vi] = nv;
+            d.leaf_flag[vi] = cached ? 0 : 1;
             if (cached) count_add(d, CNT_CACHE_HITS, g, 1);
             count_add(d, CNT_LEAVES, g, cached ? 0 : 1);
             if (stamp) {
@@ -561,8 +580,9 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev dd, const float *__restri
                 if (!(ablate & 64) && tend - t0 > q[7]) q[7] = tend - t0;   // slowest simulation of this game
             }
         }
-        if (MULTI && cached) continue;                                // served by the cache: expand it and go on, in this launch
+        if (MULTI && (cached || vl)) continue;                        // served by the cache: expand it and go on, in this launch (vl: next slot)
     }
+    if (vl) continue;
     break;
     }
     if (MULTI && lane == 0) d.sims_done[g] = done_sims;
@@ -571,12 +591,13 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev dd, const float *__restri
 // Leaf compaction: slot = number of leaf games with a lower index (deterministic order); writes the
 // canonical board (gomoku.py:34-40; 3-plane: mcts.py:126-137) of each leaf into the evaluator batch.
 __global__ __launch_bounds__(AZK_WAVE) void k_gather(Dev d, void *__restrict__ leaf_boards, int *__restrict__ n_leaf_out) {
-    const int g = blockIdx.x, lane = azk_lane();
+    const int g = blockIdx.x, lane = azk_lane();          // g = slot index over the G * K pending-leaf slots
+    const int NV = d.G * d.K;
     // prefix over byte flags, 8 flags per lane per load (leaf_flag is padded to a multiple of 512 bytes)
     int before = 0, total = 0;
     const unsigned long long *fw = (const unsigned long long *)d.leaf_flag;
-    const int nw = (d.G + 7) >> 3;
-    const bool last = g == d.G - 1;
+    const int nw = (NV + 7) >> 3;
+    const bool last = g == NV - 1;
     const int limit_words = last ? nw : ((g + 8) >> 3);
     for (int w0 = 0; w0 < limit_words; w0 += AZK_WAVE) {
         int w = w0 + lane;
@@ -599,7 +620,7 @@ __global__ __launch_bounds__(AZK_WAVE) void k_gather(Dev d, void *__restrict__ l
     const int slot = before;
     if (lane == 0) d.leaf_slot[g] = slot;
     const int rc = d.g.rc, F = d.g.planes;
-    const int player = (d.to_move[g] + d.leaf_depth[g]) & 1;          // node.currentPlayer
+    const int player = (d.to_move[g / d.K] + d.leaf_depth[g]) & 1;     // node.currentPlayer
     const uint8_t *b = d.leaf_cells + (size_t)g * d.rc_pad;
     const size_t o = (size_t)slot * F * rc;
     for (int i = lane; i < F * rc; i += AZK_WAVE) {
@@ -786,10 +807,18 @@ __global__ __launch_bounds__(AZK_WAVE) void k_vanilla(Dev d, int n_sims, uint32_
 // A leaf that missed the eval cache claims its entry's key at selection and fills logits/value at expansion; if the search
 // is abandoned in between (new search, reset, recycle) the half-written entry must not survive.
 __device__ __forceinline__ void drop_pending_cache_claim(const Dev &d, int g) {
-    if (d.cache_entries && !d.cache_shared && d.leaf_node[g] >= 0 && d.leaf_cache[g] < 0) {      // (shared mode claims nothing at selection)
-        unsigned long long *kp = d.cache_key + ((size_t)g * d.cache_entries + (size_t)(-(d.leaf_cache[g] + 1))) * d.key_words;
-        for (int w = 0; w < d.key_words; w++) kp[w] = ~0ull;
+    for (int k = 0; k < d.K; k++) {
+        const int v = g * d.K + k;
+        if (d.cache_entries && !d.cache_shared && d.leaf_node[v] >= 0 && d.leaf_cache[v] < 0) {      // (shared mode claims nothing at selection)
+            unsigned long long *kp = d.cache_key + ((size_t)g * d.cache_entries + (size_t)(-(d.leaf_cache[v] + 1))) * d.key_words;
+            for (int w = 0; w < d.key_words; w++) kp[w] = ~0ull;
+        }
     }
+}
+
+// every pending-leaf slot of game g back to "nothing pending"
+__device__ __forceinline__ void clear_leaf_slots(const Dev &d, int g) {
+    for (int k = 0; k < d.K; k++) { d.leaf_node[g * d.K + k] = -1; d.leaf_flag[g * d.K + k] = 0; d.to_move_v[g * d.K + k] = d.to_move[g]; }
 }
 
 // Node(None, None, current_player, move_count) for every game (gomoku.py:134)
@@ -801,7 +830,8 @@ __global__ void k_begin_search(Dev d) {
     const size_t base = (size_t)g * d.cap;
     d.N[base] = 0; d.W[base] = 0.0; d.P[base] = 0.f; d.meta[base] = meta_pack(0xffff, 0);
     d.first_child[base] = -1;
-    d.arena_top[g] = 1; d.leaf_node[g] = -1; d.root_f64[g] = 0; d.leaf_flag[g] = 0;
+    d.arena_top[g] = 1; d.root_f64[g] = 0;
+    clear_leaf_slots(d, g);
     d.sims_done[g] = 0;
 }
 
@@ -811,7 +841,7 @@ __global__ void k_reset_games(Dev d, int first, int count) {
     const int g = first + t / d.rc_pad, i = t % d.rc_pad;
     d.cells[(size_t)g * d.rc_pad + i] = 0;
     if (i == 0) drop_pending_cache_claim(d, g);
-    if (i == 0) { d.to_move[g] = 0; d.move_count[g] = 0; d.done[g] = 0; d.winner[g] = -2; d.leaf_node[g] = -1; d.leaf_flag[g] = 0; }
+    if (i == 0) { d.to_move[g] = 0; d.move_count[g] = 0; d.done[g] = 0; d.winner[g] = -2; clear_leaf_slots(d, g); }
 }
 
 // Continuous self-play: every finished game's slot restarts from Game() (empty board, player 0).
@@ -825,7 +855,8 @@ __global__ void k_recycle(Dev d, long long *stats) {
     atomicAdd((unsigned long long *)&stats[w == 0 ? 2 : (w == 1 ? 3 : 4)], 1ull);
     drop_pending_cache_claim(d, g);
     for (int i = 0; i < d.rc_pad; i++) d.cells[(size_t)g * d.rc_pad + i] = 0;
-    d.to_move[g] = 0; d.move_count[g] = 0; d.done[g] = 0; d.winner[g] = -2; d.leaf_node[g] = -1; d.leaf_flag[g] = 0;
+    d.to_move[g] = 0; d.move_count[g] = 0; d.done[g] = 0; d.winner[g] = -2;
+    clear_leaf_slots(d, g);
 }
 
 // utils.get_probablity_distribution_of_children (utils.py:46-55), root.value / root.visit (gomoku.py:140)
@@ -1246,6 +1277,7 @@ int32_t azk_create(const azk_config *cfg, azk_engine **out) {
     if (!make_game(cfg->game, cfg->rows, cfg->cols, &d.g, &gerr)) return fail(AZK_ERR_ARG, gerr);
     if (cfg->n_games < 1 || cfg->max_sims < 1) return fail(AZK_ERR_ARG, "n_games and max_sims must be >= 1");
     if (cfg->leaf_dtype != AZK_LEAF_F32 && cfg->leaf_dtype != AZK_LEAF_BF16) return fail(AZK_ERR_ARG, "bad leaf_dtype");
+    if (cfg->leaves_per_step < 0 || cfg->leaves_per_step > 64) return fail(AZK_ERR_ARG, "leaves_per_step must be 0..64");
     if (cfg->cache_entries < 0 || (cfg->cache_entries & (cfg->cache_entries - 1)) != 0) return fail(AZK_ERR_ARG, "cache_entries must be 0 or a power of two");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
@@ -1267,9 +1299,11 @@ int32_t azk_create(const azk_config *cfg, azk_engine **out) {
     DA(d.cells, G * d.rc_pad); DA(d.to_move, G); DA(d.move_count, G); DA(d.done, G); DA(d.winner, G);
     DA(d.N, nodes); DA(d.W, nodes); DA(d.P, nodes); DA(d.meta, nodes); DA(d.first_child, nodes);
     DA(d.rootP, G * g.rc); DA(d.root_f64, G); DA(d.arena_top, G);
-    DA(d.leaf_node, G); DA(d.leaf_depth, G); DA(d.leaf_nmoves, G); DA(d.leaf_slot, G);
-    DA(d.path, G * d.path_cap); DA(d.leaf_cells, G * d.rc_pad); DA(d.leaf_moves, G * g.rc);
-    DA(d.leaf_flag, ((G + 511) / 512) * 512 + 512);
+    d.K = cfg->leaves_per_step > 1 ? cfg->leaves_per_step : 1;
+    const size_t GV = G * (size_t)d.K;                            // pending-leaf slots
+    DA(d.leaf_node, GV); DA(d.leaf_depth, GV); DA(d.leaf_nmoves, GV); DA(d.leaf_slot, GV); DA(d.to_move_v, GV);
+    DA(d.path, GV * d.path_cap); DA(d.leaf_cells, GV * d.rc_pad); DA(d.leaf_moves, GV * g.rc);
+    DA(d.leaf_flag, ((GV + 511) / 512) * 512 + 512);
     DA(d.counters, (size_t)CNT_N * G); DA(d.err, 1); DA(d.dbg, G * 8); DA(d.emit_base, G); DA(d.sims_done, G); DA(d.budget, 2);
     d.cache_entries = cfg->cache_entries;
     d.key_words = 2 * ((g.rc + 64) / 64);                         // one spare bit (63 of the last own-plane word) for the side to move
@@ -1283,17 +1317,17 @@ int32_t azk_create(const azk_config *cfg, azk_engine **out) {
     }
     if (d.cache_entries) {
         DA(d.cache_key, cache_total * d.key_words); DA(d.cache_logits, cache_total * g.action_dim);
-        DA(d.cache_value, cache_total); DA(d.leaf_cache, G);
+        DA(d.cache_value, cache_total); DA(d.leaf_cache, GV);
         if (d.cache_shared) {
-            DA(d.cache_claim, cache_total); DA(d.cache_stamp, 1); DA(d.leaf_key, G * d.key_words);
-            DA(d.hit_logits, G * g.action_dim); DA(d.hit_value, G);
+            DA(d.cache_claim, cache_total); DA(d.cache_stamp, 1); DA(d.leaf_key, GV * d.key_words);
+            DA(d.hit_logits, GV * g.action_dim); DA(d.hit_value, GV);
         }
     }
     if (g.rows == g.cols && g.action_dim == g.rc) { DA(d.traj_action, G * g.state_dim); DA(d.traj_pi, G * g.state_dim * g.action_dim); } DA(e->counter_sums, CNT_N); DA(e->n_leaf_scratch, 1);
-    if (s == hipSuccess) { uint8_t *ls = nullptr; s = dalloc(e, &ls, G * g.planes * g.rc * 4); e->leaf_scratch = ls; }
+    if (s == hipSuccess) { uint8_t *ls = nullptr; s = dalloc(e, &ls, GV * g.planes * g.rc * 4); e->leaf_scratch = ls; }
 #undef DA
     if (s != hipSuccess) return fail(AZK_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(s));
-    (void)hipMemset(d.leaf_flag, 0, ((G + 511) / 512) * 512 + 512);
+    (void)hipMemset(d.leaf_flag, 0, ((GV + 511) / 512) * 512 + 512);
     (void)hipMemset(d.counters, 0, sizeof(long long) * CNT_N * G);
     (void)hipMemset(d.err, 0, sizeof(int));
     if (d.cache_entries) (void)hipMemset(d.cache_key, 0xff, sizeof(unsigned long long) * cache_total * d.key_words);   // all-ones = no position
@@ -1303,7 +1337,7 @@ int32_t azk_create(const azk_config *cfg, azk_engine **out) {
         (void)hipMemcpy(d.cache_stamp, &one, sizeof one, hipMemcpyHostToDevice);
     }
     (void)hipMemset(d.dbg, 0, sizeof(long long) * G * 8);
-    (void)hipMemset(d.leaf_node, 0xff, sizeof(int) * G);
+    (void)hipMemset(d.leaf_node, 0xff, sizeof(int) * GV);
     k_reset_games<<<(unsigned)((G * d.rc_pad + 255) / 256), 256>>>(d, 0, d.G);
     k_begin_search<<<(unsigned)((G + 255) / 256), 256>>>(d);
     s = hipDeviceSynchronize();
@@ -1374,9 +1408,10 @@ int32_t azk_begin_search_budget(azk_engine *e, const double *noise_dev, int32_t 
     if (!e || n_sims < 1 || n_sims > e->cfg.max_sims || max_sims_per_launch < 1) { if (e) e->err = "azk_begin_search_budget: bad argument"; return AZK_ERR_ARG; }
     e->d.noise = noise_dev;
     e->multi = true;
-    if (e->budget_host[0] != n_sims || e->budget_host[1] != max_sims_per_launch) {
+    if (e->budget_host[0] != n_sims || e->budget_host[1] != (e->d.K > 1 ? e->d.K : max_sims_per_launch)) {
         // the budget lives in device memory so that a captured step graph keeps working when it changes
         e->budget_host[0] = n_sims; e->budget_host[1] = max_sims_per_launch;
+        if (e->d.K > 1) e->budget_host[1] = e->d.K;               // virtual-loss mode: one iteration per slot
         HIPCHK(e, hipMemcpyAsync(e->d.budget, e->budget_host, sizeof e->budget_host, hipMemcpyHostToDevice, (hipStream_t)stream));
         HIPCHK(e, hipStreamSynchronize((hipStream_t)stream));
     }
@@ -1388,7 +1423,10 @@ int32_t azk_begin_search_budget(azk_engine *e, const double *noise_dev, int32_t 
 namespace {
 __global__ void k_unfinished(Dev d, int *out) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool open = g < d.G && d.done[g] == 0 && (d.sims_done[g] < d.budget[0] || (d.leaf_node[g] >= 0 && d.leaf_flag[g]));
+    bool open = g < d.G && d.done[g] == 0 && d.sims_done[g] < d.budget[0];
+    if (g < d.G && d.done[g] == 0)
+        for (int k = 0; k < d.K; k++)        // a leaf awaiting the evaluator; with K > 1 also one served by the cache (only a tree launch expands it)
+            open = open || (d.leaf_node[g * d.K + k] >= 0 && (d.leaf_flag[g * d.K + k] || d.K > 1));
     const unsigned long long m = __ballot(open);
     if ((threadIdx.x & 63) == 0 && m) atomicAdd(out, __popcll(m));
 }
@@ -1422,7 +1460,7 @@ static int32_t launch_tree(azk_engine *e, bool expand, bool select, const float 
     else k_tree<false, true, false><<<d.G, AZK_WAVE, d.lds_bytes, st>>>(d, logits, values);
     HIPCHK(e, hipGetLastError());
     if (select) {
-        k_gather<<<d.G, AZK_WAVE, 0, st>>>(d, leaf_boards, n_leaf);
+        k_gather<<<d.G * d.K, AZK_WAVE, 0, st>>>(d, leaf_boards, n_leaf);
         HIPCHK(e, hipGetLastError());
     }
     return AZK_OK;
@@ -1524,10 +1562,10 @@ int32_t azk_vanilla_search(azk_engine *e, int32_t n_sims, void *stream) {
 int32_t azk_leaf_source_of(azk_engine *e, int32_t *n_leaf_dev, azk_leaf_source *out) {
     if (!e || !n_leaf_dev || !out) return AZK_ERR_ARG;
     const Dev &d = e->d;
-    out->leaf_flag = d.leaf_flag; out->leaf_cells = d.leaf_cells; out->to_move = d.to_move; out->leaf_depth = d.leaf_depth;
+    out->leaf_flag = d.leaf_flag; out->leaf_cells = d.leaf_cells; out->to_move = d.K > 1 ? d.to_move_v : d.to_move; out->leaf_depth = d.leaf_depth;
     out->leaf_slot = d.leaf_slot; out->n_leaf = n_leaf_dev;
-    out->n_games = d.G; out->rows = d.g.rows; out->cols = d.g.cols; out->rc = d.g.rc; out->rc_pad = d.rc_pad; out->planes = d.g.planes;
-    out->flag_bytes = ((d.G + 511) / 512) * 512 + 512;
+    out->n_games = d.G * d.K; out->rows = d.g.rows; out->cols = d.g.cols; out->rc = d.g.rc; out->rc_pad = d.rc_pad; out->planes = d.g.planes;
+    out->flag_bytes = ((d.G * d.K + 511) / 512) * 512 + 512;
     out->cache_stamp = (d.cache_entries && d.cache_shared) ? d.cache_stamp : nullptr;
     return AZK_OK;
 }

@@ -42,7 +42,7 @@ class SelfPlayResult:
 def self_play_batch(game, evaluator, n_games, n_sims, size=None, seed=0, first_global_game=0, dirichlet=True,
                     alpha=0.03, noise_fn=None, uniform_fn=None, device=0, leaf_dtype="float32", engine=None,
                     max_moves=None, sample_until=None, stats=None, replay=None, cache_entries=0, vanilla_rng=None, cache_shared=False,
-                    budget_stepping=False):
+                    budget_stepping=False, leaves_per_step=1):
     """Play n_games games to the end in one batch.
 
     evaluator(boards[n,F,R,C] CUDA) -> (logits [n,A], values [n] | [n,1]).
@@ -58,7 +58,8 @@ def self_play_batch(game, evaluator, n_games, n_sims, size=None, seed=0, first_g
     import torch
     max_sims = max(n_sims) if isinstance(n_sims, (tuple, list)) else n_sims
     eng = engine or Engine(game, n_games, max_sims, size=size, device=device, leaf_dtype=leaf_dtype, cache_entries=cache_entries,
-                           cache_shared=cache_shared)
+                           cache_shared=cache_shared, leaves_per_step=leaves_per_step)
+    budget_stepping = budget_stepping or eng.K > 1          # virtual-loss engines are driven by the simulation budget
     assert eng.G == n_games
     G, A = eng.G, eng.action_dim
     eng.reset_games()
@@ -139,8 +140,8 @@ class _Half:
         self.h_stats = torch.zeros(8, dtype=torch.int64, **pin)
         # static buffers so a captured step graph always sees the same addresses
         self.noise_buf = torch.zeros((e.G, e.action_dim), dtype=torch.float64, device=e.device) if dirichlet else None
-        self.logits_buf = torch.zeros((e.G, e.action_dim), dtype=torch.float32, device=e.device)
-        self.values_buf = torch.zeros(e.G, dtype=torch.float32, device=e.device)
+        self.logits_buf = torch.zeros((e.slots, e.action_dim), dtype=torch.float32, device=e.device)
+        self.values_buf = torch.zeros(e.slots, dtype=torch.float32, device=e.device)
         self.uni = None
 
 
@@ -159,11 +160,16 @@ class SelfPlayRunner:
 
     def __init__(self, game, evaluator, n_games, n_sims, size=None, seed=0, first_global_game=0, dirichlet=True,
                  alpha=0.03, device=0, leaf_dtype="float32", recycle=True, on_records=None, kernel_timer=None,
-                 use_graph=False, n_split=1, replay=None, cache_entries=0, cache_shared=False, budget_stepping=False, per_launch=8):
+                 use_graph=False, n_split=1, replay=None, cache_entries=0, cache_shared=False, budget_stepping=False, per_launch=8,
+                 leaves_per_step=1):
         import torch
         self.replay = replay
         self.torch = torch
-        self.budget_stepping, self.per_launch = budget_stepping and use_graph, per_launch
+        # leaves_per_step > 1: OPT-IN virtual-loss expansion (K leaves in flight per game; changes search results); it is driven
+        # by the simulation budget, like budget stepping
+        self.leaves_per_step = max(1, int(leaves_per_step))
+        self.budget_stepping, self.per_launch = (budget_stepping or self.leaves_per_step > 1) and use_graph, per_launch
+        assert self.leaves_per_step == 1 or use_graph, "virtual-loss mode runs on the graph runner"
         self.launches = 0               # simulation-step launches issued (per game group) since construction
         self.use_graph = use_graph
         self._graph = None
@@ -171,7 +177,7 @@ class SelfPlayRunner:
         self.n_split = n_split if use_graph else 1
         per = n_games // self.n_split
         self.halves = [_Half(torch, Engine(game, per, n_sims, size=size, device=device, leaf_dtype=leaf_dtype,
-                                           cache_entries=cache_entries, cache_shared=cache_shared), dirichlet)
+                                           cache_entries=cache_entries, cache_shared=cache_shared, leaves_per_step=self.leaves_per_step), dirichlet)
                        for _ in range(self.n_split)]
         self.eng = self.halves[0].eng
         self.G = n_games
@@ -348,7 +354,7 @@ class SelfPlayRunner:
         else:
             # no game can finish before its budget's worth of cache misses: a first stretch without looking, then a look (one
             # 4-byte read-back) every few launches
-            s, first = done, max(done, int(0.36 * self.n_sims))
+            s, first = done, max(done, int(0.36 * self.n_sims / self.leaves_per_step))
             while True:
                 stop = first if s < first else s + 8
                 while s < stop:
@@ -361,9 +367,10 @@ class SelfPlayRunner:
                 if s > 2 * self.n_sims + 16:
                     raise RuntimeError("budget stepping does not terminate")
             self.launches += s
-        for h, st in zip(self.halves, streams):
-            with torch.cuda.stream(st):
-                h.eng.step_expand_backup(h.logits_buf, h.values_buf)
+        if self.leaves_per_step == 1:            # (K > 1: the loop above only ends once nothing is pending)
+            for h, st in zip(self.halves, streams):
+                with torch.cuda.stream(st):
+                    h.eng.step_expand_backup(h.logits_buf, h.values_buf)
         for st in self.streams:
             cur.wait_stream(st)
 

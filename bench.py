@@ -198,6 +198,9 @@ def main():
                          "hits) - same trees.  Measured SLOWER under per-move lock-step (236 vs 126 ms/move): the launch count of a move is set "
                          "by its slowest game (early-ply games miss the cache almost always) while every launch lasts as long as its busiest "
                          "wave; it needs asynchronous moves to pay (DESIGN.md section 10).  0 (default): one simulation per game and launch")
+    ap.add_argument("--virtual-loss", type=int, default=1, metavar="K",
+                    help="OPT-IN, NOT the headline: K > 1 leaves in flight per game with a virtual loss on their paths (north_star's 'virtual-loss "
+                         "expansion').  Changes search results (the reference's search is sequential), so the line is reported under its own metric key")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="wall-clock budget of the CPU baseline leg (0 = skip)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--train-step", action="store_true",
@@ -265,7 +268,8 @@ def main():
                                 first_global_game=shard_range(args.games, rank)[0], device=local_rank,
                                 leaf_dtype="bfloat16" if args.nn_dtype == "bf16" else "float32",
                                 recycle=True, kernel_timer=kt, use_graph=not args.no_graph, n_split=args.split, cache_entries=args.cache_entries,
-                                cache_shared=args.cache == "shared", replay=replay, budget_stepping=bool(args.budget_stepping))
+                                cache_shared=args.cache == "shared", replay=replay, budget_stepping=bool(args.budget_stepping),
+                                leaves_per_step=args.virtual_loss)
 
     def train_one():
         """train.train with one iteration (train.py:85-123): fresh Adam, the reference's loss, gradient bucket all-reduce.
@@ -303,6 +307,7 @@ def main():
     train_ms.clear()
     runner.reset_counters()
     plies0, fin0, finp0 = runner.plies_played, runner.games_finished, runner.finished_plies
+    launches0 = getattr(runner, "launches", 0)
     kt.enabled = True
     sync_all()
     t0 = time.perf_counter()
@@ -340,7 +345,7 @@ def main():
                 dist.destroy_process_group()
             return 0
         tree_ms = kt.mean_ms()
-        launches = args.steps * args.sims * runner.n_split      # k_tree launches (one per game group per simulation)
+        launches = max(1, (getattr(runner, "launches", 0) - launches0)) * runner.n_split      # k_tree launches in the window (one per game group and step)
         alg_bytes = algorithmic_bytes(c, A) / launches
         roof = None
         traffic, traffic_src, pmc = None, None, {}
@@ -399,7 +404,7 @@ def main():
             front = 2 * (cfg.tokens - 1) * cfg.embed_dim * kreal_ + 2 * 2 * cfg.tokens * cfg.embed_dim * cfg.num_heads
             nn_flop_total = leaves_all * front + sims_all * (flops - front)
         out = {
-            "metric": "selfplay_games_per_sec", "value": games_per_s, "unit": "games/s", "n_gpus": world,
+            "metric": "selfplay_games_per_sec" if args.virtual_loss <= 1 else "selfplay_games_per_sec_virtual_loss", "value": games_per_s, "unit": "games/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt_max / args.steps * 1e3,
             "preroll": {"cheap_moves": args.preroll_cheap, "cheap_sims": args.preroll_sims, "full_moves": args.preroll_full,
                         "note": "untimed, independent of --warmup: de-phases the slots so the completion count is window-independent"},
@@ -431,6 +436,11 @@ def main():
                 out["parity"] = {"visit_policy_vs_fp32_full": par["search_vs_fp32_full"]["fp32_cls"], "source": "profiles/r02_nn_parity.json"}
         except Exception:
             pass
+        out["tree_launches_per_move"] = launches / runner.n_split / args.steps
+        if args.virtual_loss > 1:
+            out["config"]["workload"] += f" - OPT-IN virtual-loss mode, {args.virtual_loss} leaves in flight per game (not the reference's sequential search)"
+            out["virtual_loss"] = {"leaves_per_step": args.virtual_loss, "note": "separate metric key: results differ from the reference's search by design; "
+                                   "the headline (no flag) is the parity mode"}
         if args.train_step:
             out["config"]["workload"] += " + one train step (batch 512 per GPU, fp32 autograd, fused gradient bucket all-reduce) after every move (BASELINE.json configs[4])"
             out["train_step"] = {"steps": len(train_ms), "ms_per_train_step": (sum(x.elapsed_time(y) for x, y in train_ms) / len(train_ms)) if train_ms else None,

@@ -63,7 +63,12 @@ typedef struct {
                             * once.  Entries are written at expansion under a per-entry claim word and become readable at the next
                             * tree launch; a hit is copied into the game's own buffers at once.  Results are identical in both
                             * modes (the cache is transparent); only the hit COUNT of the shared mode depends on timing. */
-    int32_t reserved[6];
+    int32_t leaves_per_step; /* 0 / 1: the reference's sequential search, one leaf in flight per game (parity mode, the default).
+                              * K > 1 (OPT-IN, changes search results): virtual-loss expansion - K leaves in flight per game; a
+                              * selection leaves a visit and a lost game on its path until the leaf's value is backed up, so the
+                              * next selections of the same game go elsewhere; the evaluator batch holds up to n_games * K boards.
+                              * Drive it with azk_begin_search_budget (n_sims completed simulations per game). */
+    int32_t reserved[5];
 } azk_config;
 
 /* device-side work counters; sums over all games since the last azk_reset_counters */
