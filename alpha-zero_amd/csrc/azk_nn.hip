@@ -1527,6 +1527,8 @@ __global__ __launch_bounds__(256, 2) void k_embed_pool_c(EmbedPoolCArgs a) {
 #undef AZK_STAMP
 #ifdef AZK_EP_STAMPS
     if (stamp) {
+        const long long wg_total = tacc[0] + tacc[1] + tacc[2] + tacc[3] + tacc[4];
+        atomicMax((unsigned long long *)a.dbg + 5, (unsigned long long)wg_total);       // the busiest workgroup of any launch
         for (int i = 0; i < 5; i++) atomicAdd((unsigned long long *)a.dbg + i, (unsigned long long)tacc[i]);
         atomicAdd((unsigned long long *)a.dbg + 6, (unsigned long long)nt_acc);
         atomicAdd((unsigned long long *)a.dbg + 7, (unsigned long long)nb_acc);
@@ -1578,6 +1580,7 @@ static int32_t embed_pool_c_impl(const void *boards_dev, int32_t boards_are_f32,
             if (atoi(ds) == 2) {          // print-and-reset request
                 long long h[8];
                 if (hipMemcpy(h, dbg_buf, 64, hipMemcpyDeviceToHost) != hipSuccess) return AZK_ERR_HIP;
+                fprintf(stderr, "[embed_pool_c stamps] busiest workgroup %lld cycles | ", h[5]);
                 fprintf(stderr, "[embed_pool_c stamps] boards %lld tiles %lld | cycles per board: prologue(total) %lld, load %.0f, patch+compact %.0f, tiles %.0f (%.0f per tile), epilogue %.0f\n",
                         h[7], h[6], h[0], (double)h[1] / (double)(h[7] ? h[7] : 1), (double)h[2] / (double)(h[7] ? h[7] : 1), (double)h[3] / (double)(h[7] ? h[7] : 1),
                         (double)h[3] / (double)(h[6] ? h[6] : 1), (double)h[4] / (double)(h[7] ? h[7] : 1));

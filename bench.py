@@ -350,9 +350,9 @@ def main():
         roof = None
         traffic, traffic_src, pmc = None, None, {}
         try:        # HBM bytes per k_tree launch from the PMC passes committed under profiles/ (FETCH_SIZE + WRITE_SIZE)
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            traffic = pmc["k_tree<true, true>"]["bytes_per_launch"]
-            traffic_src = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same workload)"
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
+            traffic = next(v["bytes_per_launch"] for k_, v in pmc.items() if k_.startswith("k_tree<true, true"))
+            traffic_src = "profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same workload)"
         except Exception:
             pass
         if tree_ms:
@@ -388,12 +388,21 @@ def main():
                 ep_traffic = next(v["bytes_per_launch"] for k_, v in pmc.items() if k_.startswith("k_embed_pool"))
             except Exception:
                 pass
-            kernels.append({"kernel": "k_embed_pool", "bound": "mfma", "achieved": fl / (ms * 1e-3) / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS,
-                            "unit": "TFLOP/s", "frac": fl / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, "avg_launch_us": ms * 1e3,
+            compact = getattr(net, "_compact", None) is not None and getattr(net, "use_compact", False)
+            executed_share = None
+            try:        # share of the 16-token tiles the compacting kernel really evaluates (measured on the same workload, tools/measure_leaves.py)
+                executed_share = json.load(open(os.path.join(ROOT, "profiles", "r02_leaf_stats.json")))["dirty_tokens_per_leaf"]["mean_tiles_of_16"] / ((T_tok + 15) // 16)
+            except Exception:
+                pass
+            kernels.append({"kernel": "k_embed_pool_c" if compact else "k_embed_pool", "bound": "mfma", "achieved": fl / (ms * 1e-3) / 1e12,
+                            "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fl / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, "avg_launch_us": ms * 1e3,
                             "algorithmic_flops_per_launch": fl, "traffic": ep_traffic,
                             "traffic_source": traffic_src if ep_traffic else None, "event_samples": len(ch.pairs),
-                            "note": f"{per_board} flop per live board (conv + score columns + weighted token sum) x {live:.0f} live boards per launch; "
-                                    "HBM traffic is 9 KB per board (board in, z out): the kernel is bound by VALU/MFMA issue and LDS, not HBM"})
+                            "executed_share_of_algorithmic_flops": executed_share if compact else 1.0,
+                            "note": f"{per_board} flop per live board (the function's conv + score columns + weighted token sum over all {T_tok} tokens) x "
+                                    f"{live:.0f} live boards per launch; the compacting kernel evaluates only the tokens a stone can reach and takes the "
+                                    "rest as precomputed constants (executed_share_of_algorithmic_flops: MFMA work actually issued); HBM traffic is "
+                                    "~9 KB per board (board in, z out): bound by VALU/MFMA issue and LDS, not HBM"})
         dominant = max(kernels, key=lambda k: k["avg_launch_us"]) if kernels else None
         flops = {"cls": cfg.flops_cls(), "full": cfg.flops_full(), "clsfold": flops_clsfold(cfg)}[args.nn_path]
         evals = leaves_all if args.no_graph else sims_all      # graph mode runs the cls-row tail over the full fixed-size leaf buffer every step
