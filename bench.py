@@ -184,9 +184,9 @@ def main():
     ap.add_argument("--nn-dtype", default="bf16", choices=["bf16", "fp32"],
                     help="fp32: the reference's own arithmetic (torch fp32 GEMMs) - the evaluator whose visit-count policies equal the "
                          "reference's to the last visit; bf16 (default, north_star's MFMA bf16): the hand-written kernels")
-    ap.add_argument("--tail", default="library", choices=["chain", "library"],
-                    help="cls-row tail: hipBLASLt GEMMs + hand-written LN / heads kernels (default: 2-3 %% faster inside the step, where the "
-                         "tail's weights arrive cold), or the all-hand-written GEMM chain (azk_nn_tail_gemm)")
+    ap.add_argument("--tail", default="chain", choices=["chain", "library"],
+                    help="cls-row tail: the all-hand-written GEMM chain (azk_nn_tail_gemm: honours the live leaf count; default) or "
+                         "hipBLASLt GEMMs + the hand-written LN / heads kernels (always runs the full 2048-row buffer)")
     ap.add_argument("--no-graph", action="store_true", help="eager stepping with a host sync per simulation (n_leaf-sized batches)")
     ap.add_argument("--split", type=int, default=1, help="independent game groups stepped on separate streams inside the step graph")
     ap.add_argument("--cache-entries", type=int, default=32768, help="per-game eval-cache entries (MCTS.cache; 64 GB of HBM at 2048 games x 32768); 0 = off")
