@@ -1,6 +1,7 @@
 """Multi-GPU path on CPU: world_size 2 over gloo.  Games shard by index with no data-path collective; a game's
 result depends only on its GLOBAL index (RNG key), so the union of the ranks' outputs equals the single-process
-run; the measurement reduction is MAX(time) / SUM(work).  The oracle stands in for the engine here (tests only)."""
+run; the measurement reduction is MAX(time) / SUM(work).  On the CPU the oracle stands in for the engine (tests only); the same
+body runs the real engine under `-m gpu` (two ranks = two engines on the one GPU, offset first_global_game)."""
 import os
 import sys
 
@@ -66,3 +67,26 @@ def test_two_ranks_equal_one_process():
     assert plies == sum(len(v[0]) for v in single.values())
     assert [shard_range(2048, r) for r in range(3)] == [(0, 2048), (2048, 4096), (4096, 6144)]
     assert [split_games(10, r, 4) for r in range(4)] == [(0, 3), (3, 6), (6, 8), (8, 10)]
+
+
+def _engine_rank(rank, games_per_rank, n_sims=40):
+    """What one rank of bench.py does for its shard, with the real engine: (cells, winner) per GLOBAL game index."""
+    from fixture_eval import fixture_logits_value
+    from selfplay import self_play_batch
+    from shard import shard_range
+    first, last = shard_range(games_per_rank, rank)
+    res = self_play_batch("gomoku", lambda x: fixture_logits_value(x, 49, "hash"), games_per_rank, n_sims, size=7, seed=11,
+                          first_global_game=first, cache_entries=256, cache_shared=True)
+    return {first + i: (r.cells, r.winner) for i, r in enumerate(res)}
+
+
+@pytest.mark.gpu
+def test_two_engine_shards_equal_one_engine():
+    """The sharding invariant with the engine itself: rank r plays global games [r G, (r+1) G) with RNG keyed by the global index,
+    so two shards (two engines, here on one GPU) produce exactly the games of one engine holding all of them."""
+    gpr = 12
+    merged = {}
+    for rank in range(2):
+        merged.update(_engine_rank(rank, gpr))
+    single = _engine_rank(0, 2 * gpr)
+    assert merged == single and len(single) == 2 * gpr
