@@ -570,7 +570,9 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev dd, const float *__restri
         }
         if (lane == 0) {
             d.leaf_node[vi] = node; d.leaf_depth[vi] = depth; d.leaf_nmoves[vi] = nv;
-            d.leaf_flag[vi] = cached ? 0 : 1;
+            // 1 + cost class: the evaluator's embedding kernel works through the boards of a launch from the stone-heavy ones down
+            // (a board's cost is the number of tokens a stone can reach: 0.93 correlated with its stone count)
+            d.leaf_flag[vi] = cached ? 0 : (uint8_t)(1 + min(7, node_mc / 6));
             if (cached) count_add(d, CNT_CACHE_HITS, g, 1);
             count_add(d, CNT_LEAVES, g, cached ? 0 : 1);
             if (stamp) {
@@ -602,6 +604,7 @@ __global__ __launch_bounds__(AZK_WAVE) void k_gather(Dev d, void *__restrict__ l
     for (int w0 = 0; w0 < limit_words; w0 += AZK_WAVE) {
         int w = w0 + lane;
         unsigned long long x = w < nw ? fw[w] : 0ull;
+        x = (((x & 0x7f7f7f7f7f7f7f7full) + 0x7f7f7f7f7f7f7f7full) | x) & 0x8080808080808080ull;   // one bit per non-zero flag byte (a flag carries its leaf's cost class)
         total += __popcll(x);
         // flags strictly before game g
         int lo = w * 8;

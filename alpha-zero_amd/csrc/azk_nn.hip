@@ -837,7 +837,10 @@ __global__ __launch_bounds__(256, 2) void k_embed_pool(EmbedPoolArgs a) {
         my_per = ((((a.src.n_games + 255) >> 8) + 7) >> 3) << 3;
         my_lo = tid * my_per;
         for (int w = 0; w < my_per; w += 8)
-            if (my_lo + w < a.src.flag_bytes) my_count += __popcll(*(const unsigned long long *)(a.src.leaf_flag + my_lo + w));
+            if (my_lo + w < a.src.flag_bytes) {
+                const unsigned long long f = *(const unsigned long long *)(a.src.leaf_flag + my_lo + w);
+                my_count += __popcll((((f & 0x7f7f7f7f7f7f7f7full) + 0x7f7f7f7f7f7f7f7full) | f) & 0x8080808080808080ull);   // non-zero flag bytes
+            }
         int incl = my_count;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(incl, off); if (lane >= off) incl += v; }
@@ -1182,34 +1185,75 @@ __global__ __launch_bounds__(256, 2) void k_embed_pool_c(EmbedPoolCArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint4 *alut = (uint4 *)smem;                                  // [256] A fragment of 8 patch bits
     float *part = (float *)(alut + 256);                          // [2 parities][16 rows][4 waves] partial sums of squares
-    uint4 *pbits = (uint4 *)(part + 128);                         // [256 + 16] patch bits of the compacted dirty tokens
-    int *dlist = (int *)(pbits + 272);                            // [256 + 16] their token indices (null token = T past the end)
-    int *scan = dlist + 272;                                      // [4] SRC wave totals, [4] dirty counts per wave, [8] next board, [9] game
-    uint4 *bimg = (uint4 *)(scan + 16);                           // [33 column tiles][KS][64 lanes] weight B fragments (the wave's 8 tiles + the extra one)
+    const int Tp16 = ((a.T + 15) >> 4) << 4;
+    uint4 *pbits = (uint4 *)(part + 128);                         // [Tp16] patch bits of the compacted dirty tokens
+    int *dlist = (int *)(pbits + Tp16);                           // [Tp16] their token indices (null token = T past the end)
+    int *scan = dlist + Tp16;                                     // [4] SRC wave totals, [4] dirty counts per wave, [8] next board, [9] game
+    uint4 *rankv = (uint4 *)(scan + 32);                          // SRC: [256 threads] ranks of the thread's first eight games, 16 bits each (scan[16..31]: class totals of the four waves)
+    uint4 *bimg = rankv + (SRC ? 256 : 0);                        // [33 column tiles][KS][64 lanes] weight B fragments                           // [33 column tiles][KS][64 lanes] weight B fragments (the wave's 8 tiles + the extra one)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
-    int nvalid, my_first = 0, my_count = 0, my_lo = 0, my_per = 0;
-    unsigned long long myflags = 0ull;
+    // SRC: a non-zero leaf flag is 1 + the leaf's cost class (0..7, by stone count).  Board j of the launch is the j-th flagged
+    // game in the order (class descending, game index ascending): the stone-heavy boards - the ones with the most tokens to
+    // evaluate - are handed out first, the light ones fill the gaps at the end (longest-processing-time-first; the queue is
+    // dynamic).  Every workgroup derives the same ranks: per-class counts of its threads' games (thread t owns games
+    // [t per, (t+1) per)), an exclusive scan over the 256 threads with the eight 16-bit counters packed in two 64-bit words.
+    int nvalid, my_lo = 0, my_per = 0;
+    unsigned long long cb_lo = 0ull, cb_hi = 0ull;                // rank of this thread's first game of each class, 16 bits each (classes 0-3 / 4-7)
     if (SRC) {
-        // exclusive prefix of the leaf flags over the workgroup's 256 threads (thread t owns games [t per, (t+1) per))
         my_per = ((((a.src.n_games + 255) >> 8) + 7) >> 3) << 3;
         my_lo = tid * my_per;
+        unsigned long long myflags = 0ull;
+        unsigned long long c_lo = 0ull, c_hi = 0ull;              // classes 0-3 / 4-7, 16 bits each
         for (int w = 0; w < my_per; w += 8)
             if (my_lo + w < a.src.flag_bytes) {
                 const unsigned long long f = *(const unsigned long long *)(a.src.leaf_flag + my_lo + w);
                 if (w == 0) myflags = f;
-                my_count += __popcll(f);
-            }
-        int incl = my_count;
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(incl, off); if (lane >= off) incl += v; }
-        if (lane == 63) scan[wave] = incl;
+                for (int q = 0; q < 8; q++) {
+                    const unsigned c = (unsigned)((f >> (8 * q)) & 0xffull);
+                    if (c) { if (c <= 4) c_lo += 1ull << (16 * (c - 1)); else c_hi += 1ull << (16 * (c - 5)); }
+                }
+            }
+        unsigned long long i_lo = c_lo, i_hi = c_hi;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned long long v_lo = __shfl_up(i_lo, off), v_hi = __shfl_up(i_hi, off);
+            if (lane >= off) { i_lo += v_lo; i_hi += v_hi; }
+        }
+        unsigned long long *wtot = (unsigned long long *)(scan + 16);           // [4 waves][2]
+        if (lane == 63) { wtot[2 * wave] = i_lo; wtot[2 * wave + 1] = i_hi; }
         __syncthreads();
-        int before = 0;
-        for (int w = 0; w < wave; w++) before += scan[w];
-        my_first = before + incl - my_count;
-        nvalid = scan[0] + scan[1] + scan[2] + scan[3];
+        unsigned long long b_lo = 0ull, b_hi = 0ull, t_lo = 0ull, t_hi = 0ull;
+        for (int w = 0; w < 4; w++) {
+            if (w < wave) { b_lo += wtot[2 * w]; b_hi += wtot[2 * w + 1]; }
+            t_lo += wtot[2 * w]; t_hi += wtot[2 * w + 1];
+        }
+        const unsigned long long e_lo = b_lo + i_lo - c_lo, e_hi = b_hi + i_hi - c_hi;   // exclusive prefix over lower threads, per class
+        unsigned start = 0;
+#pragma unroll
+        for (int c = 7; c >= 0; c--) {                            // class 7 (most stones) first
+            const unsigned tot = (unsigned)(((c < 4 ? t_lo : t_hi) >> (16 * (c & 3))) & 0xffffull);
+            const unsigned long long cb = (unsigned long long)(start + (unsigned)(((c < 4 ? e_lo : e_hi) >> (16 * (c & 3))) & 0xffffull)) << (16 * (c & 3));
+            if (c < 4) cb_lo |= cb; else cb_hi |= cb;
+            start += tot;
+        }
+        nvalid = (int)start;
+        unsigned run = 0;                                         // games of each class seen so far in this thread: 4 bits each
+        unsigned myrank[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};   // 0xffff: no game
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const unsigned c = (unsigned)((myflags >> (8 * q)) & 0xffull);
+            unsigned r = 0xffffu;
+            if (c) {
+                const unsigned bsel = (unsigned)(((c <= 4 ? cb_lo : cb_hi) >> (16 * ((c - 1) & 3))) & 0xffffull);
+                r = bsel + ((run >> (4 * (c - 1))) & 0xfu);
+                run += 1u << (4 * (c - 1));
+            }
+            myrank[q >> 1] = (q & 1) ? ((myrank[q >> 1] & 0x0000ffffu) | (r << 16)) : ((myrank[q >> 1] & 0xffff0000u) | r);
+        }
+        rankv[tid] = make_uint4(myrank[0], myrank[1], myrank[2], myrank[3]);      // read back by the same thread only
         if (blockIdx.x == 0 && tid == 0) { *a.src.n_leaf = nvalid; if (a.src.cache_stamp) *a.src.cache_stamp += 1u; }
     } else {
         nvalid = a.count ? min(a.n, *a.count) : a.n;
@@ -1264,17 +1308,24 @@ __global__ __launch_bounds__(256, 2) void k_embed_pool_c(EmbedPoolCArgs a) {
     while (board < nvalid) {
         int game = 0, player = 0;
         if (SRC) {
-            // the game behind leaf `board`: the thread whose flag range holds the board-th flagged game finds it (its first
-            // eight flags are in a register), records the slot the next expansion reads and posts the game index
-            if (board >= my_first && board < my_first + my_count) {
-                int kq = board - my_first, g = my_lo;
+            // the game behind board `board`: the thread that owns the game with that rank posts it and records the slot the next
+            // expansion reads (its first eight games' ranks sit in registers; engines with more than 2048 slots walk the rest)
+            int g = -1;
+            const uint4 rk = rankv[tid];
+            const unsigned myrank[4] = {rk.x, rk.y, rk.z, rk.w};
+#pragma unroll
+            for (int q = 0; q < 8; q++) if (((myrank[q >> 1] >> (16 * (q & 1))) & 0xffffu) == (unsigned)board) g = my_lo + q;
+            if (my_per > 8) {
+                unsigned long long run2 = 0ull;                    // games of each class seen so far: 8 bits each
                 for (int w = 0; w < my_per; w++) {
-                    const int f = w < 8 ? (int)((myflags >> (8 * w)) & 0xffull) : (int)a.src.leaf_flag[my_lo + w];
-                    if (f && kq-- == 0) { g = my_lo + w; break; }
+                    const unsigned c = my_lo + w < a.src.flag_bytes ? (unsigned)a.src.leaf_flag[my_lo + w] : 0u;
+                    if (!c) continue;
+                    const unsigned r = (unsigned)(((c <= 4 ? cb_lo : cb_hi) >> (16 * ((c - 1) & 3))) & 0xffffull) + (unsigned)((run2 >> (8 * (c - 1))) & 0xffull);
+                    run2 += 1ull << (8 * (c - 1));
+                    if (w >= 8 && r == (unsigned)board) g = my_lo + w;
                 }
-                scan[9] = g;
-                a.src.leaf_slot[g] = board;
             }
+            if (g >= 0) { scan[9] = g; a.src.leaf_slot[g] = board; }
             __syncthreads();
             game = scan[9];
         }
@@ -1540,7 +1591,8 @@ __global__ __launch_bounds__(256, 2) void k_embed_pool_c(EmbedPoolCArgs a) {
 template <int NC, int KSZ, int NH, bool SRC>
 int launch_embed_pool_c2(const EmbedPoolCArgs &a, hipStream_t st) {
     constexpr int KS = (NC * KSZ * KSZ + 31) / 32;
-    const int lds = 256 * 16 + 512 + 272 * 16 + 272 * 4 + 64 + 33 * KS * 64 * 16;      // 77 KB at KS = 2: two workgroups per CU
+    const int tp16 = ((a.T + 15) / 16) * 16;
+    const int lds = 256 * 16 + 512 + tp16 * 16 + tp16 * 4 + 128 + (SRC ? 256 * 16 : 0) + 33 * KS * 64 * 16;      // 77 KB at KS = 2: two workgroups per CU
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void *)k_embed_pool_c<NC, KSZ, NH, SRC>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return AZK_ERR_HIP;

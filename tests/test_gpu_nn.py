@@ -398,13 +398,30 @@ def test_compact_embed_pool_from_engine_leaves_equals_gathered_batch():
     n = int(eng.n_leaf.item())
     assert 0 < n <= G
     sched = azk.new_sched("cuda")
-    z_ref = azk.nn_embed_pool_compact(eng.leaf_boards[:n].contiguous(), net._compact, 15, 15, sched)
-    slots_ref = eng.leaf_slot.clone() if hasattr(eng, "leaf_slot") else None
+    z_ref = azk.nn_embed_pool_compact(eng.leaf_boards[:n].contiguous(), net._compact, 15, 15, sched)      # rows in game order (azk_step_gather)
+    import ctypes as C
+    src = eng.leaf_source()
+    hip = C.CDLL("libamdhip64.so")
+
+    def peek(ptr, count, dtype):                                    # engine-owned device arrays of the leaf source
+        buf = np.empty(count, dtype)
+        assert hip.hipMemcpy(buf.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), C.c_size_t(buf.nbytes), 2) == 0
+        return buf
+    torch.cuda.synchronize()
+    gather_slot = peek(src.leaf_slot, G, np.int32)                  # slot of each flagged game in the gathered batch
+    fl = peek(src.leaf_flag, G, np.uint8)
     eng.n_leaf.zero_()
-    z_new = azk.nn_embed_pool_compact_leaves(eng.leaf_source(), net._compact, sched)
+    z_new = azk.nn_embed_pool_compact_leaves(src, net._compact, sched)
     torch.cuda.synchronize()
     assert int(eng.n_leaf.item()) == n and sched.tolist() == [0, 0]
-    assert torch.equal(z_new[:n], z_ref)
+    new_slot = peek(src.leaf_slot, G, np.int32)
+    games = np.nonzero(fl)[0]
+    assert len(games) == n and sorted(new_slot[games].tolist()) == list(range(n))                  # a permutation of the rows
+    # the kernel hands the boards out from the stone-heavy cost classes down (flag = 1 + class), game order inside a class
+    order = sorted(games.tolist(), key=lambda g: (-int(fl[g]), g))
+    assert [int(new_slot[g]) for g in order] == list(range(n))
+    for g in games[:: max(1, n // 64)]:
+        assert torch.equal(z_new[int(new_slot[g])], z_ref[int(gather_slot[g])])                       # same board, same bits, other row
     eng.close()
 
 
