@@ -1295,17 +1295,23 @@ __global__ __launch_bounds__(256, 2) void k_embed_pool_c(EmbedPoolCArgs a) {
     const int RC = a.R * a.Cc, T = a.T, ncell = NC * RC;
     const float msum = a.msum[l15], sref = a.sref[l15];
     const int colofs = 128 * wave + 8 * l15;
-    // this thread's token (t = tid): where its patch rows sit in the board bit string - the same for every board
-    const int tj = tid - 1, tr = tj / a.Cc, tc = tj - tr * a.Cc;
-    const bool tlive = tid >= 1 && tid < T;
-    unsigned colmask = 0;
-#pragma unroll
-    for (int kx = 0; kx < ksz; kx++) { const int cc = tc + kx - pad; if (cc >= 0 && cc < a.Cc) colmask |= 1u << kx; }
     int par = 0, nxt = 0;
     __syncthreads();
     AZK_STAMP(0);                                                 // prologue: weights staged
 
     while (board < nvalid) {
+        // Everything below that depends only on the thread index (where the token's patch rows sit in the board bit string, the
+        // cell each lane fetches, the cross-lane read addresses) is recomputed per board from an opaque copy of the index: left
+        // to the compiler these ~60 values are hoisted out of the board loop, live through the tile loop, and the spills they
+        // cause are reloaded between the board's loads - one memory round trip per reload.
+        int tv = tid;
+        asm volatile("" : "+v"(tv));
+        const int lane_b = tv & 63;
+        const int tj = tv - 1, tr = tj / a.Cc, tc = tj - tr * a.Cc;
+        const bool tlive = tv >= 1 && tv < T;
+        unsigned colmask = 0;
+#pragma unroll
+        for (int kx = 0; kx < ksz; kx++) { const int cc = tc + kx - pad; if (cc >= 0 && cc < a.Cc) colmask |= 1u << kx; }
         int game = 0, player = 0;
         if (SRC) {
             // the game behind board `board`: the thread that owns the game with that rank posts it and records the slot the next
@@ -1347,33 +1353,36 @@ __global__ __launch_bounds__(256, 2) void k_embed_pool_c(EmbedPoolCArgs a) {
                 // canonical planes from the cell codes (gomoku.py:34-40; 3-plane: mcts.py:126-137); the code loads do not
                 // depend on the side to move, so they travel together with the two words that give it
                 int code[NQ], chq[NQ];
+                const auto *cells = a.src.leaf_cells + (size_t)game * a.src.rc_pad;       // uniform base + 32-bit lane offsets
 #pragma unroll
                 for (int q = 0; q < NQ; q++) {
-                    const int e = min(q * 64 + lane, ncell - 1);
+                    const int e = min(q * 64 + lane_b, ncell - 1);
                     chq[q] = (e >= RC) + (e >= 2 * RC);
-                    code[q] = a.src.leaf_cells[(size_t)game * a.src.rc_pad + (e - chq[q] * RC)];
+                    code[q] = cells[(unsigned)(e - chq[q] * RC)];
                 }
                 player = (a.src.to_move[game] + a.src.leaf_depth[game]) & 1;     // node.currentPlayer at the leaf
 #pragma unroll
                 for (int q = 0; q < NQ; q++)
-                    on[q] = q * 64 + lane < ncell && (chq[q] == 2 ? player != 0 : ((code[q] >> (chq[q] ^ player)) & 1) != 0);
+                    on[q] = q * 64 + lane_b < ncell && (chq[q] == 2 ? player != 0 : ((code[q] >> (chq[q] ^ player)) & 1) != 0);
             } else if (a.boards_f32) {
                 float raw[NQ];
+                const float *bp32 = (const float *)a.boards + (size_t)board * ncell;
 #pragma unroll
-                for (int q = 0; q < NQ; q++) raw[q] = ((const float *)a.boards)[(size_t)board * ncell + min(q * 64 + lane, ncell - 1)];
+                for (int q = 0; q < NQ; q++) raw[q] = bp32[(unsigned)min(q * 64 + lane_b, ncell - 1)];
 #pragma unroll
-                for (int q = 0; q < NQ; q++) on[q] = q * 64 + lane < ncell && raw[q] != 0.0f;
+                for (int q = 0; q < NQ; q++) on[q] = q * 64 + lane_b < ncell && raw[q] != 0.0f;
             } else {
                 unsigned short raw[NQ];
+                const unsigned short *bp16 = (const unsigned short *)a.boards + (size_t)board * ncell;
 #pragma unroll
-                for (int q = 0; q < NQ; q++) raw[q] = ((const unsigned short *)a.boards)[(size_t)board * ncell + min(q * 64 + lane, ncell - 1)];
+                for (int q = 0; q < NQ; q++) raw[q] = bp16[(unsigned)min(q * 64 + lane_b, ncell - 1)];
 #pragma unroll
-                for (int q = 0; q < NQ; q++) on[q] = q * 64 + lane < ncell && (raw[q] & 0x7fff) != 0;
+                for (int q = 0; q < NQ; q++) on[q] = q * 64 + lane_b < ncell && (raw[q] & 0x7fff) != 0;
             }
 #pragma unroll
             for (int q = 0; q < NQ; q++) {
                 const unsigned long long m = __ballot(on[q]);
-                if ((lane - 1) >> 1 == q && lane >= 1) wbits = ((lane - 1) & 1) ? (unsigned)(m >> 32) : (unsigned)m;
+                if ((lane_b - 1) >> 1 == q && lane_b >= 1) wbits = ((lane_b - 1) & 1) ? (unsigned)(m >> 32) : (unsigned)m;
             }
         } else {
             if (SRC) player = (a.src.to_move[game] + a.src.leaf_depth[game]) & 1;
@@ -1441,38 +1450,37 @@ __global__ __launch_bounds__(256, 2) void k_embed_pool_c(EmbedPoolCArgs a) {
         AZK_STAMP(2);                                             // patch bits + compaction
         if (stamp) nt_acc += ntile;
         float L = 0.f;                                    // per head (lane&15 < NH): this lane>>4 group's share of sum (w - wc)
-        for (int tile = 0; tile < ntile; tile++) {
-            // ---- gathers: the four tokens of this lane's accumulator rows ----
-            const int4 tk = *(const int4 *)(dlist + 16 * tile + 4 * l4);
+        // The per-token constants are GATHERED (by token index, L2) and every tile would wait a full round trip for them, so they
+        // run one phase ahead: the conv MFMAs start from zero and the constants are added behind them; the registers they leave
+        // are refilled with the NEXT tile's constants before the statistics / pooling phase, and the constant rows of the pooling
+        // (needed last) are refetched right behind their use.  Same registers, the round trip under the other phase's arithmetic.
+        f32x4 c0[4], c1[4], scn, wcn;
+        uint4 xr[4];
+        auto gather_a = [&](int t) {
+            const int4 tk = *(const int4 *)(dlist + 16 * t + 4 * l4);
             const int tks[4] = {tk.x, tk.y, tk.z, tk.w};
-            // 32-bit element offsets from the (uniform) table bases: one VGPR per token instead of a 64-bit address per table
-            unsigned orow[4], osc[4];
 #pragma unroll
-            for (int r = 0; r < 4; r++) { orow[r] = (unsigned)tks[r] * (unsigned)D + (unsigned)colofs; osc[r] = (unsigned)tks[r] * 16u + (unsigned)l15; }
-            f32x4 acc[8];
-            f32x4 acce, wc;
-            {
-                f32x4 c0[4], c1[4];
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    c0[r] = *(const f32x4 *)(a.cposT + orow[r]); c1[r] = *(const f32x4 *)(a.cposT + orow[r] + 4);
-                    acce[r] = a.scoreT[osc[r]];
-                    wc[r] = a.wcT[osc[r]];
-                }
-                if (tile == 0 && tid == 0) {              // next board: the round trip hides under this tile
-                    __builtin_amdgcn_sched_barrier(0);
-                    nxt = atomicAdd(a.sched, 1);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    acc[0][r] = c0[r][0]; acc[1][r] = c0[r][1]; acc[2][r] = c0[r][2]; acc[3][r] = c0[r][3];
-                    acc[4][r] = c1[r][0]; acc[5][r] = c1[r][1]; acc[6][r] = c1[r][2]; acc[7][r] = c1[r][3];
-                }
+            for (int r = 0; r < 4; r++) {
+                // 32-bit element offsets from the (uniform) table bases: one VGPR per token instead of a 64-bit address per table
+                const unsigned orow = (unsigned)tks[r] * (unsigned)D + (unsigned)colofs, osc = (unsigned)tks[r] * 16u + (unsigned)l15;
+                c0[r] = *(const f32x4 *)(a.cposT + orow); c1[r] = *(const f32x4 *)(a.cposT + orow + 4);
+                scn[r] = a.scoreT[osc];
+                wcn[r] = a.wcT[osc];
             }
-            uint4 xr[4];                                  // the constant rows are needed last: fetched into the registers c0 / c1 just left
+        };
+        auto gather_x = [&](int t) {
+            const int4 tk = *(const int4 *)(dlist + 16 * t + 4 * l4);
+            const int tks[4] = {tk.x, tk.y, tk.z, tk.w};
 #pragma unroll
-            for (int r = 0; r < 4; r++) xr[r] = *(const uint4 *)((const unsigned short *)a.xncT + orow[r]);
+            for (int r = 0; r < 4; r++) xr[r] = *(const uint4 *)((const unsigned short *)a.xncT + ((unsigned)tks[r] * (unsigned)D + (unsigned)colofs));
+        };
+        if (ntile > 0) { gather_a(0); gather_x(0); }
+        for (int tile = 0; tile < ntile; tile++) {
+            if (tile == 0 && tid == 0) {                  // next board: the round trip hides under this tile
+                __builtin_amdgcn_sched_barrier(0);
+                nxt = atomicAdd(a.sched, 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             // ---- A fragments: 8 patch bits of this lane's token (row lane&15) per k-step -> table ----
             const uint4 pb = pbits[tile * 16 + l15];
             const unsigned pw[4] = {pb.x, pb.y, pb.z, pb.w};
@@ -1483,14 +1491,30 @@ __global__ __launch_bounds__(256, 2) void k_embed_pool_c(EmbedPoolCArgs a) {
                 af.u = alut[(pw[s] >> (8 * l4)) & 0xffu];
                 afrag[s] = af.v;
             }
+            f32x4 acc[8];
+            f32x4 acce = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < 8; q++) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s = 0; s < KS; s++) { BF b; b.u = bev[s * 64]; acce = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[s], b.v, acce, 0, 0, 0); }
 #pragma unroll
             for (int q = 0; q < 8; q++) {
 #pragma unroll
                 for (int s = 0; s < KS; s++) { BF b; b.u = bwv[(q * KS + s) * 64]; acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[s], b.v, acc[q], 0, 0, 0); }
-                if ((q & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // B-fragment prefetch depth: 4 accumulators (VGPR budget)
+                if ((q & 1) == 1) __builtin_amdgcn_sched_barrier(0);   // B-fragment prefetch depth: 2 accumulators (VGPR budget)
             }
+            // ---- the gathered constants (bias + positional term, score constants), then the next tile's gathers into their registers ----
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                acc[0][r] += c0[r][0]; acc[1][r] += c0[r][1]; acc[2][r] += c0[r][2]; acc[3][r] += c0[r][3];
+                acc[4][r] += c1[r][0]; acc[5][r] += c1[r][1]; acc[6][r] += c1[r][2]; acc[7][r] += c1[r][3];
+            }
+            acce += scn;
+            const f32x4 wc = wcn;
+            __builtin_amdgcn_sched_barrier(0);
+            const int tnext = min(tile + 1, ntile - 1);          // (the last tile refetches itself: no branch around loads)
+            gather_a(tnext);
+            __builtin_amdgcn_sched_barrier(0);
             // ---- LayerNorm statistics of the full rows (mean = GEMM column 15 of the extra tile) ----
             float mean[4];
 #pragma unroll
@@ -1544,6 +1568,8 @@ __global__ __launch_bounds__(256, 2) void k_embed_pool_c(EmbedPoolCArgs a) {
                 xb.p.c23 = __builtin_amdgcn_perm(xw[3][q >> 1], xw[2][q >> 1], sel);
                 Z[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa.v, xb.v, Z[q], 0, 0, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
+            gather_x(tnext);
         }
         AZK_STAMP(3);                                             // tile loop
         if (ntile == 0 && tid == 0) nxt = atomicAdd(a.sched, 1);
@@ -2085,6 +2111,7 @@ struct TailArgs {
     const float *stats_in; int stats_groups;     // AMODE 1: [M][stats_groups][2] partial (sum, sum of squares) of every A row, written by the producer
     float *stats_out;                            // optional: this GEMM's own partials [M][nbatch * N / 64][2] of the bf16-rounded output rows
     float *logits, *values; int action_dim;
+    int wave_slots;                              // SIMDs of the device (set by launch_tail)
 };
 
 enum { TAIL_EPI_BF16 = 0, TAIL_EPI_GELU = 1, TAIL_EPI_RESID = 2, TAIL_EPI_HEADS = 3 };
@@ -2101,18 +2128,17 @@ __device__ __forceinline__ float gelu_erf(float x) {
 
 // NWK > 1: the K range is split over NWK waves of the workgroup (every load of the whole K in flight at once, one round trip),
 // their partial accumulators meet in LDS and wave 0 runs the epilogue.
-template <int RT, int KCH, int NCH, int AMODE, int EPI, int NWR, int NWC, int NWK>
-__global__ __launch_bounds__(64 * NWR * NWC * NWK, 1) void k_tail_gemm(TailArgs a) {
-    constexpr int K = 32 * KCH * NCH * NWK, KS = KCH * NCH * NWK;
+// A wave keeps every A fragment of its K range in flight at once; the weight fragments are all in flight too when RT <= 2, and
+// for the taller tiles the second half of them is fetched into the registers the matrix pipe has just consumed.
+template <int RT, int KCH, int AMODE, int EPI, int NWR, int NWC, int NWK>
+__device__ __forceinline__ void tail_items(const TailArgs &a, const int nvalid, f32x4 *kred) {
+    constexpr int K = 32 * KCH * NWK, KS = KCH * NWK;
+    constexpr int BH = RT > 3 ? KCH / 4 : RT > 2 ? KCH / 2 : KCH;  // weight k-steps in flight before the first MFMA
     static_assert(NWK == 1 || (NWR == 1 && NWC == 1), "split-K workgroups hold one wave tile");
-    __shared__ f32x4 kred[NWK > 1 ? (NWK - 1) * RT * 4 * 64 : 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, l4 = lane >> 4;
     const int wk = NWK > 1 ? wave : 0, wrc = NWK > 1 ? 0 : wave;
     const int wr = wrc / NWC, wc = wrc - wr * NWC;
     constexpr int WROWS = 16 * RT * NWR;
-    // the items cover the live rows only (measured: letting the dead half of the buffer issue its loads too costs 40-60 % - these
-    // GEMMs move ~100 KB per wave through L2 and are bound by that traffic, not by the count's extra round trip)
-    const int nvalid = a.count ? min(a.M, *a.count) : a.M;
     const int rtiles = (nvalid + WROWS - 1) / WROWS, ctiles = a.N / (64 * NWC);
     const int nitems = rtiles * ctiles * a.nbatch;
     union BF { uint4 u; bf16x8 v; };
@@ -2122,64 +2148,71 @@ __global__ __launch_bounds__(64 * NWR * NWC * NWK, 1) void k_tail_gemm(TailArgs 
         const int row0 = rt * WROWS + wr * 16 * RT, g = ct * NWC + wc;
         const unsigned short *ap[RT];
 #pragma unroll
-        for (int i = 0; i < RT; i++) ap[i] = a.A + (size_t)min(row0 + 16 * i + l15, a.M - 1) * a.lda + (size_t)b * a.a_batch + 8 * l4 + 32 * KCH * NCH * wk;
-        const uint4 *bp = a.Wp + (size_t)b * a.w_batch + ((size_t)g * KS + (size_t)KCH * NCH * wk) * 4 * 64 + lane;
+        for (int i = 0; i < RT; i++) ap[i] = a.A + (size_t)min(row0 + 16 * i + l15, a.M - 1) * a.lda + (size_t)b * a.a_batch + 8 * l4 + 32 * KCH * wk;
+        const uint4 *bp = a.Wp + (size_t)b * a.w_batch + ((size_t)g * KS + (size_t)KCH * wk) * 4 * 64 + lane;
         f32x4 acc[RT][4];
 #pragma unroll
         for (int i = 0; i < RT; i++)
 #pragma unroll
             for (int c = 0; c < 4; c++) acc[i][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-        BF af[2][RT][KCH], bf[2][KCH][4];
-        auto fetch = [&](int ch, int buf) {
-#pragma unroll
-            for (int s = 0; s < KCH; s++) {
-#pragma unroll
-                for (int i = 0; i < RT; i++) af[buf][i][s].u = *(const uint4 *)(ap[i] + 32 * (ch * KCH + s));
-#pragma unroll
-                for (int c = 0; c < 4; c++) bf[buf][s][c].u = bp[((ch * KCH + s) * 4 + c) * 64];
-            }
-        };
-        fetch(0, 0);
         // AMODE 1: the row statistics were left by the producing GEMM as per-column-group partial sums (of the bf16 values this
-        // wave now reads): summed here in a fixed order - deterministic, no atomics, no second pass over the rows
-        float rstd[RT], shift[RT];
+        // wave now reads), eight (sum, sum of squares) pairs per row: fetched FIRST, as four 16-byte loads per row, so that they
+        // are back before the fragments they normalise (a scalar loop over the groups here cost one round trip per group)
+        f32x4 st[AMODE == 1 ? RT : 1];                        // a lane fetches the quarter l4 of its row's 64 bytes
         if (AMODE == 1) {
 #pragma unroll
+            for (int i = 0; i < RT; i++) st[i] = *((const f32x4 *)(a.stats_in + (size_t)min(row0 + 16 * i + l15, a.M - 1) * 16) + l4);
+        }
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        const int col0 = b * a.N + 64 * g + 4 * l15;          // a lane's four accumulators of a row are four consecutive output columns
+        if (a.bias) bv = *(const f32x4 *)(a.bias + col0);
+        BF af[RT][KCH], bf[KCH][4];
+#pragma unroll
+        for (int s = 0; s < KCH; s++) {
+#pragma unroll
+            for (int i = 0; i < RT; i++) af[i][s].u = *(const uint4 *)(ap[i] + 32 * s);
+            if (s < BH) {
+#pragma unroll
+                for (int c = 0; c < 4; c++) bf[s][c].u = bp[(s * 4 + c) * 64];
+            }
+        }
+        float rstd[RT], shift[RT];
+        if (AMODE == 1) {                                     // the groups are added in a fixed order: deterministic, no atomics
+#pragma unroll
             for (int i = 0; i < RT; i++) {
-                const float *sp = a.stats_in + (size_t)min(row0 + 16 * i + l15, a.M - 1) * a.stats_groups * 2;
-                float s1 = 0.f, s2 = 0.f;
-                for (int q = 0; q < a.stats_groups; q++) { s1 += sp[2 * q]; s2 += sp[2 * q + 1]; }
+                float s1 = st[i][0] + st[i][2], s2 = st[i][1] + st[i][3];
+                s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+                s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
                 const float mean = s1 * (1.0f / K);
                 rstd[i] = rsqrtf(fmaxf(s2 * (1.0f / K) - mean * mean, 0.f) + a.ln_eps);
                 shift[i] = -mean * rstd[i];
             }
         }
+        __builtin_amdgcn_sched_barrier(0);                    // every load above is issued before the first MFMA
 #pragma unroll
-        for (int ch = 0; ch < NCH; ch++) {
-            const int cur = ch & 1;
-            if (ch + 1 < NCH) fetch(ch + 1, cur ^ 1);
-            __builtin_amdgcn_sched_barrier(0);            // the next chunk's loads are issued before this chunk's first MFMA
+        for (int s = 0; s < KCH; s++) {
             if (AMODE == 1) {
 #pragma unroll
-                for (int i = 0; i < RT; i++)
+                for (int i = 0; i < RT; i++) {
+                    const unsigned w4[4] = {af[i][s].u.x, af[i][s].u.y, af[i][s].u.z, af[i][s].u.w};
+                    float v[8];
 #pragma unroll
-                    for (int s = 0; s < KCH; s++) {
-                        const unsigned w4[4] = {af[cur][i][s].u.x, af[cur][i][s].u.y, af[cur][i][s].u.z, af[cur][i][s].u.w};
-                        float v[8];
-#pragma unroll
-                        for (int q = 0; q < 4; q++) {
-                            v[2 * q] = __uint_as_float(w4[q] << 16) * rstd[i] + shift[i];
-                            v[2 * q + 1] = __uint_as_float(w4[q] & 0xffff0000u) * rstd[i] + shift[i];
-                        }
-                        af[cur][i][s].u = pack8(v);
+                    for (int q = 0; q < 4; q++) {
+                        v[2 * q] = __uint_as_float(w4[q] << 16) * rstd[i] + shift[i];
+                        v[2 * q + 1] = __uint_as_float(w4[q] & 0xffff0000u) * rstd[i] + shift[i];
                     }
+                    af[i][s].u = pack8(v);
+                }
             }
 #pragma unroll
-            for (int s = 0; s < KCH; s++)
+            for (int i = 0; i < RT; i++)
 #pragma unroll
-                for (int i = 0; i < RT; i++)
+                for (int c = 0; c < 4; c++) acc[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][s].v, bf[s][c].v, acc[i][c], 0, 0, 0);
+            if (BH < KCH && s + BH < KCH) {
 #pragma unroll
-                    for (int c = 0; c < 4; c++) acc[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[cur][i][s].v, bf[cur][s][c].v, acc[i][c], 0, 0, 0);
+                for (int c = 0; c < 4; c++) bf[s + BH][c].u = bp[((s + BH) * 4 + c) * 64];
+                __builtin_amdgcn_sched_barrier(0);            // (the refill stays behind the MFMAs that free its registers)
+            }
         }
         if (row0 >= nvalid) continue;                          // (uniform per wave tile; with NWK > 1 per workgroup)
         if (NWK > 1) {
@@ -2198,71 +2231,112 @@ __global__ __launch_bounds__(64 * NWR * NWC * NWK, 1) void k_tail_gemm(TailArgs 
 #pragma unroll
                     for (int c = 0; c < 4; c++) acc[i][c] += kred[((w - 1) * RT * 4 + i * 4 + c) * 64 + lane];
         }
-        const int col0 = b * a.N + 64 * g + 4 * l15;          // a lane's four accumulators of a row are four consecutive output columns
-        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-        if (a.bias) bv = *(const f32x4 *)(a.bias + col0);
+        // epilogue: every load (residual rows) first, then straight-line arithmetic, then the stores under their row predicate with
+        // nothing to wait for in between (a load or a branch between two stores makes every store wait for the one before it)
+        uint2 rr[EPI == TAIL_EPI_RESID ? RT : 1][4];
+        if (EPI == TAIL_EPI_RESID) {
 #pragma unroll
-        for (int i = 0; i < RT; i++)
+            for (int i = 0; i < RT; i++)
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int row = row0 + 16 * i + 4 * l4 + j;
-                if (row >= nvalid) continue;
-                f32x4 v = {acc[i][0][j] + bv[0], acc[i][1][j] + bv[1], acc[i][2][j] + bv[2], acc[i][3][j] + bv[3]};
-                if (EPI == TAIL_EPI_HEADS) {                          // nn.py:82-83
+                for (int j = 0; j < 4; j++) rr[i][j] = *(const uint2 *)(a.resid + (size_t)min(row0 + 16 * i + 4 * l4 + j, a.M - 1) * a.ldr + col0);
+        }
+        if (EPI == TAIL_EPI_HEADS) {                          // nn.py:82-83
+            f32x4 hv[RT][4];
+#pragma unroll
+            for (int i = 0; i < RT; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    hv[i][j] = f32x4{acc[i][0][j] + bv[0], acc[i][1][j] + bv[1], acc[i][2][j] + bv[2], acc[i][3][j] + bv[3]};
+#pragma unroll
+                    for (int c = 0; c < 4; c++)
+                        if (col0 + c == a.action_dim) hv[i][j][c] = tanhf(hv[i][j][c]);
+                }
+#pragma unroll
+            for (int i = 0; i < RT; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int row = row0 + 16 * i + 4 * l4 + j;
 #pragma unroll
                     for (int c = 0; c < 4; c++) {
                         const int col = col0 + c;
-                        if (col < a.action_dim) a.logits[(size_t)row * a.action_dim + col] = v[c];
-                        else if (col == a.action_dim) a.values[row] = tanhf(v[c]);
+                        if (row < nvalid && col < a.action_dim) a.logits[(size_t)row * a.action_dim + col] = hv[i][j][c];
+                        if (row < nvalid && col == a.action_dim) a.values[row] = hv[i][j][c];
                     }
-                } else {
+                }
+        } else {
+            uint2 o[RT][4];
+            f32x2 ps[RT][4];
+#pragma unroll
+            for (int i = 0; i < RT; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    f32x4 v = {acc[i][0][j] + bv[0], acc[i][1][j] + bv[1], acc[i][2][j] + bv[2], acc[i][3][j] + bv[3]};
                     if (EPI == TAIL_EPI_GELU) {
 #pragma unroll
                         for (int c = 0; c < 4; c++) v[c] = gelu_erf(v[c]);                                      // nn.GELU (erf form)
                     }
                     if (EPI == TAIL_EPI_RESID) {
-                        const uint2 rr = *(const uint2 *)(a.resid + (size_t)row * a.ldr + col0);
-                        v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
-                        v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
+                        v[0] += __uint_as_float(rr[i][j].x << 16); v[1] += __uint_as_float(rr[i][j].x & 0xffff0000u);
+                        v[2] += __uint_as_float(rr[i][j].y << 16); v[3] += __uint_as_float(rr[i][j].y & 0xffff0000u);
                     }
-                    union { bf16x4 b4; uint2 u; } o;
-                    o.b4 = __builtin_convertvector(v, bf16x4);
-                    *(uint2 *)(a.out + (size_t)row * a.ldo + col0) = o.u;
+                    union { bf16x4 b4; uint2 u; } ob;
+                    ob.b4 = __builtin_convertvector(v, bf16x4);
+                    o[i][j] = ob.u;
+                    if (a.stats_out) {
+                        // partial LayerNorm statistics of the row, over this wave's 64 columns, from the ROUNDED values
+                        const f32x4 vr = __builtin_convertvector(ob.b4, f32x4);
+                        ps[i][j] = f32x2{row16_sum((vr[0] + vr[1]) + (vr[2] + vr[3])),
+                                         row16_sum((vr[0] * vr[0] + vr[1] * vr[1]) + (vr[2] * vr[2] + vr[3] * vr[3]))};
+                    }
                 }
-            }
-        if (EPI != TAIL_EPI_HEADS && a.stats_out) {
-            // partial LayerNorm statistics of the rows just written, over this wave's 64 columns, from the ROUNDED values
             const int ngr = a.nbatch * (a.N >> 6), gr = b * (a.N >> 6) + g;
 #pragma unroll
             for (int i = 0; i < RT; i++)
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const int row = row0 + 16 * i + 4 * l4 + j;
-                    f32x4 v = {acc[i][0][j] + bv[0], acc[i][1][j] + bv[1], acc[i][2][j] + bv[2], acc[i][3][j] + bv[3]};
-                    if (EPI == TAIL_EPI_GELU) {
-#pragma unroll
-                        for (int c = 0; c < 4; c++) v[c] = gelu_erf(v[c]);
-                    }
-                    if (EPI == TAIL_EPI_RESID && row < nvalid) {
-                        const uint2 rr = *(const uint2 *)(a.resid + (size_t)row * a.ldr + col0);
-                        v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
-                        v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
-                    }
-                    const bf16x4 rb = __builtin_convertvector(v, bf16x4);
-                    const f32x4 vr = __builtin_convertvector(rb, f32x4);
-                    const float p1 = row16_sum((vr[0] + vr[1]) + (vr[2] + vr[3]));
-                    const float p2 = row16_sum((vr[0] * vr[0] + vr[1] * vr[1]) + (vr[2] * vr[2] + vr[3] * vr[3]));
-                    if (l15 == 0 && row < nvalid) *(f32x2 *)(a.stats_out + ((size_t)row * ngr + gr) * 2) = f32x2{p1, p2};
+                    if (row < nvalid) *(uint2 *)(a.out + (size_t)row * a.ldo + col0) = o[i][j];
+                    if (a.stats_out && l15 == 0 && row < nvalid) *(f32x2 *)(a.stats_out + ((size_t)row * ngr + gr) * 2) = ps[i][j];
                 }
         }
     }
 }
 
-template <int RT, int KCH, int NCH, int AMODE, int EPI, int NWR, int NWC, int NWK = 1>
-int launch_tail(const TailArgs &a, hipStream_t st) {
-    const long long items = (long long)((a.M + 16 * RT * NWR - 1) / (16 * RT * NWR)) * (a.N / (64 * NWC)) * a.nbatch;
+// The wave tile is 16 RT rows tall, RT chosen per launch from the LIVE row count (RTLO..RTHI): the smallest tile that still puts
+// every wave of the launch on the chip at once.  These kernels hold their whole K range in registers (one wave per SIMD), so a
+// launch with more waves than SIMDs runs as two rounds of the same latency chain - measured: the five-launch tail took 54 us at
+// 1024 live rows and 79 us at 1056 with a fixed 32-row tile.
+template <int RTLO, int RTHI, int KCH, int AMODE, int EPI, int NWR, int NWC, int NWK>
+__global__ __launch_bounds__(64 * NWR * NWC * NWK, 1) void k_tail_gemm(TailArgs a) {
+    __shared__ f32x4 kred[NWK > 1 ? (NWK - 1) * RTHI * 4 * 64 : 1];
+    // the items cover the live rows only (measured: letting the dead half of the buffer issue its loads too costs 40-60 % - these
+    // GEMMs move ~100 KB per wave through L2 and are bound by that traffic, not by the count's extra round trip)
+    const int nvalid = a.count ? min(a.M, *a.count) : a.M;
+    const int strip_waves = (a.N >> 6) * a.nbatch * NWK;          // waves per strip of 16 RT rows
+    int rt = RTLO;
+    while (rt < RTHI && ((nvalid + 16 * rt * NWR - 1) / (16 * rt * NWR)) * NWR * strip_waves > a.wave_slots) rt++;
+    if (RTHI >= RTLO + 2 && rt == RTLO + 2) tail_items<(RTHI >= RTLO + 2 ? RTLO + 2 : RTLO), KCH, AMODE, EPI, NWR, NWC, NWK>(a, nvalid, kred);
+    else if (RTHI >= RTLO + 1 && rt == RTLO + 1) tail_items<(RTHI >= RTLO + 1 ? RTLO + 1 : RTLO), KCH, AMODE, EPI, NWR, NWC, NWK>(a, nvalid, kred);
+    else tail_items<RTLO, KCH, AMODE, EPI, NWR, NWC, NWK>(a, nvalid, kred);
+}
+
+int tail_wave_slots() {
+    static int slots = 0;
+    if (!slots) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        slots = 4 * cus;                                         // one wave per SIMD
+    }
+    return slots;
+}
+
+template <int RTLO, int RTHI, int KCH, int AMODE, int EPI, int NWR, int NWC, int NWK = 1>
+int launch_tail(TailArgs &a, hipStream_t st) {
+    static_assert(RTHI <= RTLO + 2, "three tile heights per kernel");
+    a.wave_slots = tail_wave_slots();
+    const long long items = (long long)((a.M + 16 * RTLO * NWR - 1) / (16 * RTLO * NWR)) * (a.N / (64 * NWC)) * a.nbatch;
     const unsigned blocks = (unsigned)(items < 8192 ? items : 8192);
-    k_tail_gemm<RT, KCH, NCH, AMODE, EPI, NWR, NWC, NWK><<<blocks, 64 * NWR * NWC * NWK, 0, st>>>(a);
+    k_tail_gemm<RTLO, RTHI, KCH, AMODE, EPI, NWR, NWC, NWK><<<blocks, 64 * NWR * NWC * NWK, 0, st>>>(a);
     return hipGetLastError() == hipSuccess ? AZK_OK : AZK_ERR_HIP;
 }
 }  // namespace
@@ -2270,7 +2344,7 @@ int launch_tail(const TailArgs &a, hipStream_t st) {
 extern "C" int32_t azk_nn_tail_gemm(const azk_tail_gemm *t, void *stream) {
     if (!t || !t->a_bf16 || !t->w_packed || t->m < 0 || t->n_out < 64 || (t->n_out & 63) || t->nbatch < 1) return AZK_ERR_ARG;
     if ((t->k != 512 && t->k != 2048) || t->lda < t->k || (t->lda & 7) || (t->a_batch_stride & 7)) return AZK_ERR_ARG;
-    if (t->epilogue < 0 || t->epilogue > 3 || (t->layernorm_a && (t->k != 512 || !t->a_stats || t->a_stats_groups < 1))) return AZK_ERR_ARG;
+    if (t->epilogue < 0 || t->epilogue > 3 || (t->layernorm_a && (t->k != 512 || !t->a_stats || t->a_stats_groups != 8))) return AZK_ERR_ARG;
     if (t->epilogue == TAIL_EPI_HEADS ? (!t->logits_out || !t->values_out || t->action_dim + 1 > t->n_out * t->nbatch) : (!t->out_bf16 || t->ldo < t->n_out * t->nbatch || (t->ldo & 3)))
         return AZK_ERR_ARG;
     if (t->epilogue == TAIL_EPI_RESID && (!t->resid_bf16 || (t->ldr & 3))) return AZK_ERR_ARG;
@@ -2285,18 +2359,18 @@ extern "C" int32_t azk_nn_tail_gemm(const azk_tail_gemm *t, void *stream) {
     const bool wide = t->n_out % 128 == 0 && t->n_out >= 1024;          // many column groups: 2 x 2 waves share A rows and weight fragments in L1
     if (t->k == 512) {
         if (t->layernorm_a) {
-            if (t->epilogue == TAIL_EPI_GELU) return wide ? launch_tail<2, 16, 1, 1, TAIL_EPI_GELU, 2, 2>(a, st) : launch_tail<2, 16, 1, 1, TAIL_EPI_GELU, 1, 1>(a, st);
-            if (t->epilogue == TAIL_EPI_HEADS) return launch_tail<1, 16, 1, 1, TAIL_EPI_HEADS, 1, 1>(a, st);
-            if (t->epilogue == TAIL_EPI_BF16) return launch_tail<2, 16, 1, 1, TAIL_EPI_BF16, 1, 1>(a, st);
+            if (t->epilogue == TAIL_EPI_GELU) return wide ? launch_tail<2, 4, 16, 1, TAIL_EPI_GELU, 2, 2>(a, st) : launch_tail<2, 2, 16, 1, TAIL_EPI_GELU, 1, 1>(a, st);
+            if (t->epilogue == TAIL_EPI_HEADS) return launch_tail<1, 1, 16, 1, TAIL_EPI_HEADS, 1, 1>(a, st);
+            if (t->epilogue == TAIL_EPI_BF16) return launch_tail<2, 2, 16, 1, TAIL_EPI_BF16, 1, 1>(a, st);
             return AZK_ERR_ARG;
         }
-        if (t->epilogue == TAIL_EPI_BF16) return launch_tail<2, 16, 1, 0, TAIL_EPI_BF16, 1, 1>(a, st);
-        if (t->epilogue == TAIL_EPI_GELU) return wide ? launch_tail<2, 16, 1, 0, TAIL_EPI_GELU, 2, 2>(a, st) : launch_tail<2, 16, 1, 0, TAIL_EPI_GELU, 1, 1>(a, st);
-        if (t->epilogue == TAIL_EPI_RESID) return launch_tail<2, 16, 1, 0, TAIL_EPI_RESID, 1, 1>(a, st);
-        return launch_tail<2, 16, 1, 0, TAIL_EPI_HEADS, 1, 1>(a, st);
+        if (t->epilogue == TAIL_EPI_BF16) return launch_tail<2, 2, 16, 0, TAIL_EPI_BF16, 1, 1>(a, st);
+        if (t->epilogue == TAIL_EPI_GELU) return wide ? launch_tail<2, 4, 16, 0, TAIL_EPI_GELU, 2, 2>(a, st) : launch_tail<2, 2, 16, 0, TAIL_EPI_GELU, 1, 1>(a, st);
+        if (t->epilogue == TAIL_EPI_RESID) return launch_tail<2, 2, 16, 0, TAIL_EPI_RESID, 1, 1>(a, st);
+        return launch_tail<2, 2, 16, 0, TAIL_EPI_HEADS, 1, 1>(a, st);
     }
     // k = 2048: four waves of a workgroup take 512 columns of K each
-    if (t->epilogue == TAIL_EPI_RESID) return launch_tail<2, 16, 1, 0, TAIL_EPI_RESID, 1, 1, 4>(a, st);
-    if (t->epilogue == TAIL_EPI_BF16) return launch_tail<2, 16, 1, 0, TAIL_EPI_BF16, 1, 1, 4>(a, st);
+    if (t->epilogue == TAIL_EPI_RESID) return launch_tail<2, 4, 16, 0, TAIL_EPI_RESID, 1, 1, 4>(a, st);
+    if (t->epilogue == TAIL_EPI_BF16) return launch_tail<2, 4, 16, 0, TAIL_EPI_BF16, 1, 1, 4>(a, st);
     return AZK_ERR_ARG;
 }

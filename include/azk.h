@@ -362,7 +362,7 @@ int32_t azk_nn_gemm_rows(const void *a_bf16_dev, int32_t lda, const void *w_pack
  *   azk_nn_gemm_rows' fragment packing.  k = 512 or 2048; n_out a multiple of 64.
  *   layernorm_a (k = 512): A = LayerNorm(rows) without affine (fold it into weight / bias: W diag(gamma), W beta + b); the row
  *            statistics are read from a_stats [m][a_stats_groups][2] = per 64-column group (sum, sum of squares) of the row, as
- *            left by the GEMM that produced A (its stats_out).
+ *            left by the GEMM that produced A (its stats_out); a_stats_groups must be 8 (= k / 64; 64-byte rows, 16-byte aligned).
  *   stats_out (optional, epilogues 0-2): float32 [m][nbatch * n_out / 64][2], the same partials of the rows written here.
  *   epilogue 0: out_bf16 = acc + bias;  1: GELU(acc + bias) (exact erf);  2: acc + bias + resid_bf16;
  *            3: merged heads - logits_out float32 [m][action_dim], values_out[m] = tanh(column action_dim)   (nn.py:82-83).

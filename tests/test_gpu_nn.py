@@ -472,6 +472,34 @@ def test_tail_chain_vs_torch_fp32_and_library_tail():
     assert torch.equal(l2, lc) and torch.equal(v2, vc)
 
 
+def test_tail_chain_rows_do_not_depend_on_the_live_count():
+    """azk_nn_tail_gemm picks its wave tile height (32 / 48 / 64 rows) from the live row count so that one launch is one round
+    of waves; a row's result must not depend on that choice: the first 900 rows are bit-identical whether 900, 1100 (48-row
+    tiles), 1700 (64-row tiles) rows or the whole buffer are live, and every live count matches the fp32-checked chain."""
+    import azk
+    cfg = NetConfig(15, 15, 2, 225, 5, 512, 8, 1)
+    net = PolicyValueNet(cfg, seed=3, device="cuda", dtype=torch.bfloat16, path="clsfold")
+    assert net.chain_tail
+    n = 2048
+    z = (torch.randn(n, 8, 512, device="cuda", generator=torch.Generator("cuda").manual_seed(5)) * 0.3).to(torch.bfloat16)
+    net.use_chain_tail = True
+    outs = {}
+    for live in (900, 1024, 1100, 1537, 1700, 2048):
+        lb, vb = torch.full((n, 225), 7.0, device="cuda"), torch.full((n,), 7.0, device="cuda")
+        net.out_buffers, net.live_count = (lb, vb), torch.tensor([live], dtype=torch.int32, device="cuda")
+        net.tail_fast(z)
+        torch.cuda.synchronize()
+        assert bool((lb[live:] == 7.0).all()) and bool((vb[live:] == 7.0).all())
+        assert bool(torch.isfinite(lb[:live]).all())
+        outs[live] = (lb, vb)
+    for live in (900, 1024, 1100, 1537, 1700):
+        assert torch.equal(outs[live][0][:live], outs[2048][0][:live]) and torch.equal(outs[live][1][:live], outs[2048][1][:live]), live
+    net.out_buffers, net.live_count = None, None
+    net.use_chain_tail = False
+    ll, vl = net.tail_fast(z)
+    assert (outs[2048][0] - ll).abs().max().item() < 5e-2 and (outs[2048][1] - vl[:, 0]).abs().max().item() < 2e-2
+
+
 def test_runner_budget_stepping_plays_the_same_moves():
     """SelfPlayRunner with budget stepping (graph replays until no game owes simulations) against one-simulation-per-replay
     stepping, real network, continuous self-play with recycling: the same pi and the same moves, in fewer launches."""
