@@ -1201,15 +1201,29 @@ __global__ __launch_bounds__(256, 2) void k_embed_pool_c(EmbedPoolCArgs a) {
     // [t per, (t+1) per)), an exclusive scan over the 256 threads with the eight 16-bit counters packed in two 64-bit words.
     int nvalid, my_lo = 0, my_per = 0;
     unsigned long long cb_lo = 0ull, cb_hi = 0ull;                // rank of this thread's first game of each class, 16 bits each (classes 0-3 / 4-7)
+    // The launch's fixed cost is a chain of round trips (leaf flags -> ranks -> weights -> first board): the flag words and the
+    // whole conv weight image (wt_frag, MFMA fragment order [33 column tiles][KS][64 lanes] x 16 bytes: fragment (tile, s) of lane l
+    // = wt[col(tile, l)][32 s + 8 (l>>4) .. +8], column tile 32 = the extra columns) are requested together, the flags first so
+    // that the rank arithmetic waits for them alone; the image goes to LDS once the ranks are done.
+    constexpr int NF = 33 * KS * 64, PER = (NF + 255) / 256;
+    unsigned long long myflags = 0ull;
     if (SRC) {
         my_per = ((((a.src.n_games + 255) >> 8) + 7) >> 3) << 3;
         my_lo = tid * my_per;
-        unsigned long long myflags = 0ull;
+        if (my_lo < a.src.flag_bytes) myflags = *(const unsigned long long *)(a.src.leaf_flag + my_lo);
+    }
+    // (LDS-DMA: a wave instruction moves 64 x 16 contiguous bytes, no registers; NF is a multiple of 64, whole wave pieces only)
+    static_assert(NF % 64 == 0, "the weight image is copied in whole 1 KiB wave pieces");
+#pragma unroll
+    for (int i = 0; i < PER; i++)
+        if (256 * i + 64 * wave < NF)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)((const uint4 *)a.wt_frag + tid + 256 * i),
+                                             (__attribute__((address_space(3))) void *)(bimg + 256 * i + 64 * wave), 16, 0, 0);
+    if (SRC) {
         unsigned long long c_lo = 0ull, c_hi = 0ull;              // classes 0-3 / 4-7, 16 bits each
         for (int w = 0; w < my_per; w += 8)
             if (my_lo + w < a.src.flag_bytes) {
-                const unsigned long long f = *(const unsigned long long *)(a.src.leaf_flag + my_lo + w);
-                if (w == 0) myflags = f;
+                const unsigned long long f = w == 0 ? myflags : *(const unsigned long long *)(a.src.leaf_flag + my_lo + w);
 #pragma unroll
                 for (int q = 0; q < 8; q++) {
                     const unsigned c = (unsigned)((f >> (8 * q)) & 0xffull);
@@ -1268,22 +1282,9 @@ __global__ __launch_bounds__(256, 2) void k_embed_pool_c(EmbedPoolCArgs a) {
     long long nt_acc = 0, nb_acc = 0;
 #define AZK_STAMP(i) do { } while (0)
 #endif
+    if (board >= nvalid) __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): no LDS-DMA may outlive the workgroup
     if (board < nvalid) {                                         // (workgroups without a board go straight to the sign-off below)
     union BF { uint4 u; bf16x8 v; };
-    // the conv weight arrives in MFMA fragment order (wt_frag [33 column tiles][KS][64 lanes] x 16 bytes: fragment (tile, s)
-    // of lane l = wt[col(tile, l)][32 s + 8 (l>>4) .. +8], column tile 32 = the extra columns): a straight copy into LDS,
-    // every load of a thread in flight before its first LDS store
-    {
-        constexpr int NF = 33 * KS * 64, PER = (NF + 255) / 256, CH = 9;
-#pragma unroll
-        for (int i0 = 0; i0 < PER; i0 += CH) {
-            uint4 wv[CH];
-#pragma unroll
-            for (int i = 0; i < CH; i++) wv[i] = ((const uint4 *)a.wt_frag)[min(tid + 256 * (i0 + i), NF - 1)];
-#pragma unroll
-            for (int i = 0; i < CH; i++) if (i0 + i < PER && tid + 256 * (i0 + i) < NF) bimg[tid + 256 * (i0 + i)] = wv[i];
-        }
-    }
     const uint4 *bwv = bimg + (size_t)wave * 8 * KS * 64 + lane, *bev = bimg + (size_t)32 * KS * 64 + lane;
     {
         unsigned r[4];
@@ -1495,13 +1496,13 @@ __global__ __launch_bounds__(256, 2) void k_embed_pool_c(EmbedPoolCArgs a) {
             f32x4 acce = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int q = 0; q < 8; q++) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            // k-step outermost: nine independent accumulator chains per step, the B fragments stream from LDS
 #pragma unroll
-            for (int s = 0; s < KS; s++) { BF b; b.u = bev[s * 64]; acce = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[s], b.v, acce, 0, 0, 0); }
+            for (int s = 0; s < KS; s++) {
+                { BF b; b.u = bev[s * 64]; acce = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[s], b.v, acce, 0, 0, 0); }
 #pragma unroll
-            for (int q = 0; q < 8; q++) {
-#pragma unroll
-                for (int s = 0; s < KS; s++) { BF b; b.u = bwv[(q * KS + s) * 64]; acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[s], b.v, acc[q], 0, 0, 0); }
-                if ((q & 1) == 1) __builtin_amdgcn_sched_barrier(0);   // B-fragment prefetch depth: 2 accumulators (VGPR budget)
+                for (int q = 0; q < 8; q++) { BF b; b.u = bwv[(q * KS + s) * 64]; acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[s], b.v, acc[q], 0, 0, 0); }
+                if (s + 1 < KS) __builtin_amdgcn_sched_barrier(0);    // one k-step's fragments in flight at a time (VGPR budget)
             }
             // ---- the gathered constants (bias + positional term, score constants), then the next tile's gathers into their registers ----
 #pragma unroll
