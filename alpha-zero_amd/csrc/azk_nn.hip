@@ -1462,18 +1462,18 @@ __global__ __launch_bounds__(256, 2) void k_embed_pool_c(EmbedPoolCArgs a) {
             const int tks[4] = {tk.x, tk.y, tk.z, tk.w};
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                // 32-bit element offsets from the (uniform) table bases: one VGPR per token instead of a 64-bit address per table
-                const unsigned orow = (unsigned)tks[r] * (unsigned)D + (unsigned)colofs, osc = (unsigned)tks[r] * 16u + (unsigned)l15;
-                c0[r] = *(const f32x4 *)(a.cposT + orow); c1[r] = *(const f32x4 *)(a.cposT + orow + 4);
-                scn[r] = a.scoreT[osc];
-                wcn[r] = a.wcT[osc];
+                // 32-bit BYTE offsets from the (uniform) table bases: the loads take the base from SGPRs, one VGPR per token and table
+                const unsigned orow = ((unsigned)tks[r] * (unsigned)D + (unsigned)colofs) * 4u, osc = ((unsigned)tks[r] * 16u + (unsigned)l15) * 4u;
+                c0[r] = *(const f32x4 *)((const char *)a.cposT + orow); c1[r] = *(const f32x4 *)((const char *)a.cposT + orow + 16);
+                scn[r] = *(const float *)((const char *)a.scoreT + osc);
+                wcn[r] = *(const float *)((const char *)a.wcT + osc);
             }
         };
         auto gather_x = [&](int t) {
             const int4 tk = *(const int4 *)(dlist + 16 * t + 4 * l4);
             const int tks[4] = {tk.x, tk.y, tk.z, tk.w};
 #pragma unroll
-            for (int r = 0; r < 4; r++) xr[r] = *(const uint4 *)((const unsigned short *)a.xncT + ((unsigned)tks[r] * (unsigned)D + (unsigned)colofs));
+            for (int r = 0; r < 4; r++) xr[r] = *(const uint4 *)((const char *)a.xncT + ((unsigned)tks[r] * (unsigned)D + (unsigned)colofs) * 2u);
         };
         if (ntile > 0) { gather_a(0); gather_x(0); }
         for (int tile = 0; tile < ntile; tile++) {
