@@ -2112,7 +2112,7 @@ struct TailArgs {
     const float *stats_in; int stats_groups;     // AMODE 1: [M][stats_groups][2] partial (sum, sum of squares) of every A row, written by the producer
     float *stats_out;                            // optional: this GEMM's own partials [M][nbatch * N / 64][2] of the bf16-rounded output rows
     float *logits, *values; int action_dim;
-    int wave_slots;                              // SIMDs of the device (set by launch_tail)
+    int wave_slots;                              // waves of the launched instantiation the device holds at once (set by launch_tail)
 };
 
 enum { TAIL_EPI_BF16 = 0, TAIL_EPI_GELU = 1, TAIL_EPI_RESID = 2, TAIL_EPI_HEADS = 3 };
@@ -2321,20 +2321,27 @@ __global__ __launch_bounds__(64 * NWR * NWC * NWK, 1) void k_tail_gemm(TailArgs 
     else tail_items<RTLO, KCH, AMODE, EPI, NWR, NWC, NWK>(a, nvalid, kred);
 }
 
-int tail_wave_slots() {
-    static int slots = 0;
-    if (!slots) {
-        int dev = 0, cus = 0;
+int tail_cu_count() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-        slots = 4 * cus;                                         // one wave per SIMD
     }
-    return slots;
+    return cus;
 }
 
 template <int RTLO, int RTHI, int KCH, int AMODE, int EPI, int NWR, int NWC, int NWK = 1>
 int launch_tail(TailArgs &a, hipStream_t st) {
     static_assert(RTHI <= RTLO + 2, "three tile heights per kernel");
-    a.wave_slots = tail_wave_slots();
+    // waves of this instantiation the chip holds at once (its register footprint decides: 1 per SIMD for the whole-K variants,
+    // 2-3 for the split-K ones)
+    static int slots = 0;
+    if (!slots) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_tail_gemm<RTLO, RTHI, KCH, AMODE, EPI, NWR, NWC, NWK>, 64 * NWR * NWC * NWK, 0) != hipSuccess || nb < 1) nb = 1;
+        slots = nb * NWR * NWC * NWK * tail_cu_count();
+    }
+    a.wave_slots = slots;
     const long long items = (long long)((a.M + 16 * RTLO * NWR - 1) / (16 * RTLO * NWR)) * (a.N / (64 * NWC)) * a.nbatch;
     const unsigned blocks = (unsigned)(items < 8192 ? items : 8192);
     k_tail_gemm<RTLO, RTHI, KCH, AMODE, EPI, NWR, NWC, NWK><<<blocks, 64 * NWR * NWC * NWK, 0, st>>>(a);
@@ -2361,11 +2368,11 @@ extern "C" int32_t azk_nn_tail_gemm(const azk_tail_gemm *t, void *stream) {
     if (t->k == 512) {
         if (t->layernorm_a) {
             if (t->epilogue == TAIL_EPI_GELU) return wide ? launch_tail<2, 4, 16, 1, TAIL_EPI_GELU, 2, 2>(a, st) : launch_tail<2, 2, 16, 1, TAIL_EPI_GELU, 1, 1>(a, st);
-            if (t->epilogue == TAIL_EPI_HEADS) return launch_tail<1, 1, 16, 1, TAIL_EPI_HEADS, 1, 1>(a, st);
+            if (t->epilogue == TAIL_EPI_HEADS) return launch_tail<1, 1, 4, 1, TAIL_EPI_HEADS, 1, 1, 4>(a, st);
             if (t->epilogue == TAIL_EPI_BF16) return launch_tail<2, 2, 16, 1, TAIL_EPI_BF16, 1, 1>(a, st);
             return AZK_ERR_ARG;
         }
-        if (t->epilogue == TAIL_EPI_BF16) return launch_tail<2, 2, 16, 0, TAIL_EPI_BF16, 1, 1>(a, st);
+        if (t->epilogue == TAIL_EPI_BF16) return launch_tail<2, 2, 4, 0, TAIL_EPI_BF16, 1, 1, 4>(a, st);       // (K split over four waves: a quarter of the loads and MFMAs on each wave's chain)
         if (t->epilogue == TAIL_EPI_GELU) return wide ? launch_tail<2, 4, 16, 0, TAIL_EPI_GELU, 2, 2>(a, st) : launch_tail<2, 2, 16, 0, TAIL_EPI_GELU, 1, 1>(a, st);
         if (t->epilogue == TAIL_EPI_RESID) return launch_tail<2, 2, 16, 0, TAIL_EPI_RESID, 1, 1>(a, st);
         return launch_tail<2, 2, 16, 0, TAIL_EPI_HEADS, 1, 1>(a, st);
