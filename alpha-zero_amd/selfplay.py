@@ -161,6 +161,7 @@ class SelfPlayRunner:
     def __init__(self, game, evaluator, n_games, n_sims, size=None, seed=0, first_global_game=0, dirichlet=True,
                  alpha=0.03, device=0, leaf_dtype="float32", recycle=True, on_records=None, kernel_timer=None,
                  use_graph=False, n_split=1, replay=None, cache_entries=0, cache_shared=False, budget_stepping=False, per_launch=8,
+                 steps_per_graph=8,
                  leaves_per_step=1):
         import torch
         self.replay = replay
@@ -173,6 +174,7 @@ class SelfPlayRunner:
         self.launches = 0               # simulation-step launches issued (per game group) since construction
         self.use_graph = use_graph
         self._graph = None
+        self.steps_per_graph = max(1, int(steps_per_graph))
         assert n_games % n_split == 0
         self.n_split = n_split if use_graph else 1
         per = n_games // self.n_split
@@ -324,13 +326,21 @@ class SelfPlayRunner:
                         self._step_body(h)
             cur.wait_stream(side)
             torch.cuda.synchronize()
-            self._graph = []
+            self._graph, self._graph_many = [], []
             for h in self.halves:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
                     self._step_body(h)
                 self._graph.append(g)
-            done = 3                     # the three eager steps ran; the captured one was only recorded
+                if self.steps_per_graph > 1:
+                    # the same step `steps_per_graph` times in one graph: consecutive graph launches leave the GPU idle for ~8 us
+                    # (rocprofv3 kernel trace: gap before k_tree), consecutive kernels of one graph do not
+                    gm = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gm):
+                        for _ in range(self.steps_per_graph):
+                            self._step_body(h)
+                    self._graph_many.append(gm)
+            done = 3                     # the three eager steps ran; the captured ones were only recorded
         else:
             done = 0
         kt = self.kernel_timer
@@ -338,18 +348,30 @@ class SelfPlayRunner:
         for st in self.streams:
             st.wait_stream(cur)
 
-        def replay(s):
-            timed = kt is not None and kt.want(s)
-            for h, g, st in zip(self.halves, self._graph, streams):
+        def replay(s, timed=None, many=False):
+            timed = (kt is not None and kt.want(s)) if timed is None else timed
+            for i, (h, g, st) in enumerate(zip(self.halves, self._graph, streams)):
                 with torch.cuda.stream(st):
                     if timed:
                         # sampled steps run the same kernels eagerly so HIP events can bracket k_tree on its stream
                         self._step_body(h, timer=kt)
+                    elif many:
+                        self._graph_many[i].replay()
                     else:
                         g.replay()
         if not self.budget_stepping:
-            for s in range(done, self.n_sims):
-                replay(s)
+            s, U, next_sample = done, self.steps_per_graph, done
+            while s < self.n_sims:
+                if kt is not None and kt.enabled and s >= next_sample and len(kt.pairs) < kt.max:
+                    replay(s, timed=True)
+                    next_sample = s + kt.stride
+                    s += 1
+                elif U > 1 and s + U <= self.n_sims:
+                    replay(s, timed=False, many=True)
+                    s += U
+                else:
+                    replay(s, timed=False)
+                    s += 1
             self.launches += self.n_sims
         else:
             # no game can finish before its budget's worth of cache misses: a first stretch without looking, then a look (one

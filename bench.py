@@ -193,6 +193,8 @@ def main():
     ap.add_argument("--cache", default="shared", choices=["shared", "per-game"],
                     help="eval cache: one table shared by every game of the GPU (the reference's MCTS.cache is process-global, mcts.py:7) or one "
                          "table per game; same memory, same results, different hit rate")
+    ap.add_argument("--steps-per-graph", type=int, default=8,
+                    help="simulation steps captured in one hipGraph (consecutive graph launches leave an ~8 us bubble; 1 = one step per launch)")
     ap.add_argument("--budget-stepping", type=int, default=0,
                     help="1: a game keeps simulating inside a tree launch while its simulations need no evaluator (terminal leaves, eval-cache "
                          "hits) - same trees.  Measured SLOWER under per-move lock-step (236 vs 126 ms/move): the launch count of a move is set "
@@ -268,7 +270,7 @@ def main():
                                 first_global_game=shard_range(args.games, rank)[0], device=local_rank,
                                 leaf_dtype="bfloat16" if args.nn_dtype == "bf16" else "float32",
                                 recycle=True, kernel_timer=kt, use_graph=not args.no_graph, n_split=args.split, cache_entries=args.cache_entries,
-                                cache_shared=args.cache == "shared", replay=replay, budget_stepping=bool(args.budget_stepping),
+                                cache_shared=args.cache == "shared", replay=replay, budget_stepping=bool(args.budget_stepping), steps_per_graph=args.steps_per_graph,
                                 leaves_per_step=args.virtual_loss)
 
     def train_one():
@@ -427,7 +429,7 @@ def main():
             "eval_cache": {"entries_per_game": args.cache_entries, "mode": args.cache, "hits_rank0": c.get("cache_hits", 0),
                            "hit_rate_rank0": c.get("cache_hits", 0) / max(1, c.get("cache_hits", 0) + c["leaves_evaluated"])},
             "nn_tflops_executed": nn_flop_total / dt_max / 1e12, "nn_flops_per_board": flops, "nn_boards_evaluated": evals,
-            "stepping": "eager+sync" if args.no_graph else f"hipGraph replay, {runner.n_split} game group(s) (per simulation: k_tree, the network kernels taking the pending leaves straight from the engine, no host sync)",
+            "stepping": "eager+sync" if args.no_graph else f"hipGraph replay, {runner.steps_per_graph} simulation step(s) per graph, {runner.n_split} game group(s) (per simulation: k_tree, the network kernels taking the pending leaves straight from the engine, no host sync)",
             "value_definition": value_src, "games_per_sec_renewal_estimate": est_games_per_s,
             "mean_plies_per_game": mean_plies, "game_length_source": src, "games_finished_in_window": fin_window,
             "plies_in_window": plies_all, "counters_rank0": c, "roofline": dominant, "roofline_puct": roof, "kernel_rooflines": kernels,
