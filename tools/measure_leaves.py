@@ -3,7 +3,8 @@
     dedupe opportunity of VERDICT r01 item 6 (ai/mcts.py:38-51: the reference's cache is process-global);
   * "dirty" tokens per leaf (tokens whose 5x5 patch holds a stone) - the constant-token skipping opportunity of item 1(c);
   * with AZK_TREE_ABLATE=16/32/64/1024 in the environment: k_tree's per-phase cycle stamps on the same de-phased state.
-usage: measure_leaves.py [games] [sims] [measured_moves] [cheap_preroll_moves]     (writes one JSON line)"""
+usage: measure_leaves.py [games] [sims] [measured_moves] [cheap_preroll_moves]     (writes one JSON line)
+LEAF_CACHE=shared (default, the benchmark's cross-game cache) | game (one table per game, the round-1 engine)"""
 import json
 import os
 import sys
@@ -26,7 +27,7 @@ stride = int(os.environ.get("LEAF_STRIDE", 8))
 cfg = NetConfig(15, 15, 2, 225, 5, 512, 8, 1)
 net = PolicyValueNet(cfg, seed=0, device="cuda:0", dtype=torch.bfloat16, path="clsfold")
 runner = SelfPlayRunner("gomoku", net, G, sims, size=15, seed=0, device=0, leaf_dtype="bfloat16", recycle=True, use_graph=True,
-                        cache_entries=32768)
+                        cache_entries=32768, cache_shared=os.environ.get("LEAF_CACHE", "shared") == "shared")
 runner.n_sims = 16
 for _ in range(pre):
     runner.play_move()
