@@ -161,7 +161,7 @@ class SelfPlayRunner:
     def __init__(self, game, evaluator, n_games, n_sims, size=None, seed=0, first_global_game=0, dirichlet=True,
                  alpha=0.03, device=0, leaf_dtype="float32", recycle=True, on_records=None, kernel_timer=None,
                  use_graph=False, n_split=1, replay=None, cache_entries=0, cache_shared=False, budget_stepping=False, per_launch=8,
-                 steps_per_graph=8,
+                 steps_per_graph=32,
                  leaves_per_step=1):
         import torch
         self.replay = replay

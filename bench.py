@@ -193,7 +193,9 @@ def main():
     ap.add_argument("--cache", default="shared", choices=["shared", "per-game"],
                     help="eval cache: one table shared by every game of the GPU (the reference's MCTS.cache is process-global, mcts.py:7) or one "
                          "table per game; same memory, same results, different hit rate")
-    ap.add_argument("--steps-per-graph", type=int, default=8,
+    ap.add_argument("--timer-stride", type=int, default=64,
+                    help="every n-th simulation step runs eagerly with HIP events around k_tree and the embedding kernel (the roofline's live durations)")
+    ap.add_argument("--steps-per-graph", type=int, default=32,
                     help="simulation steps captured in one hipGraph (consecutive graph launches leave an ~8 us bubble; 1 = one step per launch)")
     ap.add_argument("--budget-stepping", type=int, default=0,
                     help="1: a game keeps simulating inside a tree launch while its simulations need no evaluator (terminal leaves, eval-cache "
@@ -260,7 +262,7 @@ def main():
         nn_torch_dtype = torch.bfloat16 if args.nn_dtype == "bf16" else torch.float32
         net = PolicyValueNet(cfg, seed=0, device=f"cuda:{local_rank}", dtype=nn_torch_dtype, path=args.nn_path)
         net.use_chain_tail = args.tail == "chain"
-        kt = KernelTimer(stride=16)
+        kt = KernelTimer(stride=args.timer_stride)
         if args.train_step:
             from azk import DeviceReplay
             from trainer import Trainer
