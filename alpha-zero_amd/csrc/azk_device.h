@@ -333,6 +333,11 @@ __device__ int azk_valid_moves(const uint8_t *b, const GameDesc &g, int16_t *mov
     //    has, otherwise an earlier key re-probing could have reached its slot first); the rest retry next round.
     unsigned stamp = 0x00ffffffu;     // claims carry a per-round stamp that only decreases: a newer round's atomicMin always beats
                                       // whatever an older round left in the slot, so claims never need to be reset
+    // occupancy bitmap of the CURRENT table (one bit per slot; the first-adder bitmap of steps 1-3 is free by now): a probe reads
+    // two words of it instead of sixteen table entries
+    uint32_t *occ = ms.bits;
+    for (int w = lane; w <= (ms.table_size >> 5); w += AZK_WAVE) occ[w] = 0u;
+    __syncthreads();
     auto insert_batch = [&](uint16_t *tb, unsigned msk, const int16_t *list, int count) {
         for (int c0 = 0; c0 < count; c0 += AZK_WAVE) {
             const int idx = c0 + lane;
@@ -349,20 +354,12 @@ __device__ int azk_valid_moves(const uint8_t *b, const GameDesc &g, int16_t *mov
                     unsigned i = (unsigned)h & msk;
                     for (;;) {
                         if (i + 9 <= msk) {
-                            // the ten-slot window in one round trip: four aligned 64-bit reads cover slots base .. base+15;
-                            // entries are < 0x8000, so (x + 0x7fff) sets bit 15 of a 16-bit lane exactly when it is non-zero
-                            const unsigned bs = i & ~3u, off = i - bs;
-                            const unsigned long long *p = (const unsigned long long *)(tb + bs);
-                            const unsigned long long w0 = p[0], w1 = p[1], w2 = p[2], w3 = p[3];
-                            const unsigned long long K = 0x7fff7fff7fff7fffull, T = 0x8000800080008000ull;
-                            auto z4 = [&](unsigned long long w) -> unsigned {       // bit q set <=> 16-bit lane q of w is zero
-                                const unsigned long long y = ~(w + K) & T;
-                                return (unsigned)(((y >> 15) * 0x0001000200040008ull) >> 48) & 0xfu;     // lane q -> bit q
-                            };
-                            unsigned z = z4(w0) | (z4(w1) << 4) | (z4(w2) << 8) | (z4(w3) << 12);
-                            z = (z >> off) & 0x3ffu;
+                            // the ten-slot window from the occupancy bitmap: two words cover bits i .. i+9
+                            const unsigned w = i >> 5, sh = i & 31u;
+                            const unsigned long long both = ((unsigned long long)occ[w + 1] << 32) | (unsigned long long)occ[w];
+                            const unsigned z = (unsigned)((~both) >> sh) & 0x3ffu;
                             if (z) { slot = i + (unsigned)__ffs((int)z) - 1u; break; }
-                        } else if (tb[i] == 0) { slot = i; break; }
+                        } else if (((occ[i >> 5] >> (i & 31u)) & 1u) == 0u) { slot = i; break; }
                         perturb >>= 5;
                         i = (unsigned)((unsigned long long)i * 5 + 1 + perturb) & msk;
                     }
@@ -372,7 +369,7 @@ __device__ int azk_valid_moves(const uint8_t *b, const GameDesc &g, int16_t *mov
                 const bool conflict = !placed && ms.claim[slot] != ((stamp << 6) | (unsigned)lane);
                 const unsigned long long cb = __ballot(conflict);
                 const int first_bad = cb ? __ffsll((long long)cb) - 1 : AZK_WAVE;
-                if (!placed && lane < first_bad) { tb[slot] = (uint16_t)keyv; placed = true; }
+                if (!placed && lane < first_bad) { tb[slot] = (uint16_t)keyv; atomicOr(&occ[slot >> 5], 1u << (slot & 31u)); placed = true; }
                 stamp--;
                 __syncthreads();
             }
@@ -407,6 +404,7 @@ __device__ int azk_valid_moves(const uint8_t *b, const GameDesc &g, int16_t *mov
             for (unsigned i = lane; i < newsize; i += AZK_WAVE) {       // the table the set grows into starts empty; new claim slots start free
                 other[i] = 0;
                 if (i > mask) ms.claim[i] = 0xffffffffu;
+                if (i <= (newsize >> 5)) occ[i] = 0u;
             }
             __syncthreads();
             uint16_t *tmp = tab; tab = other; other = tmp;

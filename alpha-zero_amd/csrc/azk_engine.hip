@@ -97,7 +97,7 @@ __host__ __device__ inline int lds_layout(const GameDesc &g, int path_cap, int t
     off[5] = o; o += up16(ea * 4);
     off[6] = o; o += up16(ea * 8);
     int nwords = (g.rc * 8 + 31) >> 5;
-    off[7] = o; o += up16(nwords * 4);
+    off[7] = o; o += up16((nwords > (table_size >> 5) + 2 ? nwords : (table_size >> 5) + 2) * 4);   // key bitmap, later the set table's occupancy bitmap
     off[8] = o; o += up16(nwords * 2);
     off[9] = o; o += up16(g.rc * 2);
     off[10] = o; o += up16(g.rc * 8);
