@@ -1294,7 +1294,7 @@ __global__ __launch_bounds__(256, 2) void k_embed_pool_c(EmbedPoolCArgs a) {
     }
     constexpr int ksz = KSZ, kk = KSZ * KSZ, pad = KSZ / 2;
     const int RC = a.R * a.Cc, T = a.T, ncell = NC * RC;
-    const float msum = a.msum[l15], sref = a.sref[l15];
+    const float msum = a.msum[l15], sref = a.sref[l15], lall = a.lall[l15];
     const int colofs = 128 * wave + 8 * l15;
     int par = 0, nxt = 0;
     __syncthreads();
@@ -1577,7 +1577,7 @@ __global__ __launch_bounds__(256, 2) void k_embed_pool_c(EmbedPoolCArgs a) {
         // ---- z[b][h][:] = (ZALL + Z)[h][:] / (LALL + L)[h] ----
         float Lt = L + __shfl_xor(L, 16);
         Lt += __shfl_xor(Lt, 32);
-        Lt += a.lall[l15];
+        Lt += lall;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int head = 4 * l4 + j;
