@@ -270,6 +270,7 @@ class SelfPlayRunner:
             e.step_tree(h.logits_buf, h.values_buf)          # the network kernel compacts the leaves itself
         else:
             e.step(h.logits_buf, h.values_buf)
+        had_fast = getattr(self.evaluator, "fast_outputs", False)
         if hasattr(self.evaluator, "live_count"):
             self.evaluator.live_count = e.n_leaf
             self.evaluator.fast_outputs = True
@@ -290,6 +291,11 @@ class SelfPlayRunner:
             self.evaluator.out_buffers = None
         if hasattr(self.evaluator, "leaf_source"):
             self.evaluator.leaf_source = None
+        if hasattr(self.evaluator, "live_count"):
+            # the step's row count belongs to THIS engine: an evaluator shared with another runner (or called directly afterwards)
+            # must not keep honouring it
+            self.evaluator.live_count = None
+            self.evaluator.fast_outputs = had_fast
 
     def _all_bodies(self):
         torch = self.torch

@@ -521,3 +521,31 @@ def test_runner_budget_stepping_plays_the_same_moves():
         assert np.array_equal(cha, chb) and pa.tobytes() == pb.tobytes()
     assert ca["sims"] == cb["sims"] == 4 * 128 * 96
     assert lb <= la + 4, (la, lb)          # early-game searches hit few terminals / cache entries: about as many launches, never more
+
+
+def test_runner_steps_per_graph_plays_the_same_moves():
+    """Several simulation steps captured in one hipGraph (the bench default: 32) against one step per graph and against eager
+    stepping: the same pi and the same moves, whatever the chunking (searches of 96 and of 50 simulations: whole chunks, a
+    remainder of single steps, a kernel-timer sample in between)."""
+    from selfplay import KernelTimer, SelfPlayRunner
+    cfg = NetConfig(15, 15, 2, 225, 5, 512, 8, 1)
+    net = PolicyValueNet(cfg, seed=6, device="cuda", dtype=torch.bfloat16, path="clsfold")
+
+    def play(per_graph, sims, use_graph=True, timer=None):
+        rec = []
+        r = SelfPlayRunner("gomoku", net, 128, sims, size=15, seed=9, leaf_dtype="bfloat16", recycle=True, use_graph=use_graph, cache_entries=256,
+                           cache_shared=True, steps_per_graph=per_graph, kernel_timer=timer,
+                           on_records=lambda mv, base, pi, q, ch, w, d: rec.append((pi.numpy().copy(), ch.numpy().copy())))
+        if timer is not None:
+            timer.enabled = True
+        for _ in range(3):
+            r.play_move()
+        r.check_error()
+        return rec, r.counters()["sims"]
+    for sims in (96, 50):
+        ref, n_ref = play(1, sims)
+        for per_graph, graph, timer in ((32, True, None), (8, True, KernelTimer(stride=20)), (1, False, None)):
+            got, n = play(per_graph, sims, graph, timer)
+            assert n == n_ref == 3 * 128 * sims
+            for (pa, cha), (pb, chb) in zip(ref, got):
+                assert np.array_equal(cha, chb) and pa.tobytes() == pb.tobytes(), (sims, per_graph, graph)
