@@ -195,22 +195,25 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev dd, const float *__restri
     const bool shared = d.cache_entries && d.cache_shared;
     const unsigned cstamp = shared ? d.cache_stamp[0] : 0u;
     unsigned long long e_key = 0ull;
-    if (EXPAND && shared && lane < d.key_words) e_key = d.leaf_key[(size_t)vi * d.key_words + lane];
-    const int e_path = (EXPAND && lane < d.path_cap) ? d.path[(size_t)vi * d.path_cap + lane] : 0;     // trace nodes 0..63 (deeper ones: below)
+    if (EXPAND && shared) e_key = d.leaf_key[(size_t)vi * d.key_words + min(lane, d.key_words - 1)];
+    // (every per-lane load below is UNCONDITIONAL with a clamped index: a load under a lane predicate - `lane < n ? p[lane] : 0` -
+    //  is compiled as a branch around the load plus a wait for its result right behind it, and the eighteen loads of this entry
+    //  sequence then cost one memory round trip EACH instead of one together)
+    const int e_path = EXPAND ? d.path[(size_t)vi * d.path_cap + min(lane, d.path_cap - 1)] : 0;     // trace nodes 0..63 (deeper ones: below)
     constexpr int KSL = 7;                                  // cells per lane: rc <= 448 (make_game allows 400)
     int e_mv[KSL] = {0, 0, 0, 0, 0, 0, 0};
     if (EXPAND) {
 #pragma unroll
-        for (int k4 = 0; k4 < KSL; k4++) { const int i = lane + AZK_WAVE * k4; if (i < rc) e_mv[k4] = d.leaf_moves[(size_t)vi * rc + i]; }
+        for (int k4 = 0; k4 < KSL; k4++) e_mv[k4] = d.leaf_moves[(size_t)vi * rc + min(lane + AZK_WAVE * k4, rc - 1)];
     }
     const int s_done = SELECT ? d.done[g] : 1, s_player = SELECT ? d.to_move[g] : 0, s_mc = SELECT ? d.move_count[g] : 0;
     int s_rootf64 = SELECT ? d.root_f64[g] : 0;
     int r_fc = SELECT ? d.first_child[base] : -1, r_N = SELECT ? d.N[base] : 0;
     uint32_t r_meta = SELECT ? d.meta[base] : 0u;
-    uint8_t s_cells[KSL] = {0, 0, 0, 0, 0, 0, 0};
+    int s_cells[KSL] = {0, 0, 0, 0, 0, 0, 0};               // (one register each: byte-sized destinations are packed, and every packed load waits for the one before)
     if (SELECT) {
 #pragma unroll
-        for (int k4 = 0; k4 < KSL; k4++) { const int i = lane + AZK_WAVE * k4; if (i < rc) s_cells[k4] = d.cells[(size_t)g * d.rc_pad + i]; }
+        for (int k4 = 0; k4 < KSL; k4++) s_cells[k4] = d.cells[(size_t)g * d.rc_pad + min(lane + AZK_WAVE * k4, rc - 1)];
     }
 
     if (EXPAND) {
