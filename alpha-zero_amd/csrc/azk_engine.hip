@@ -189,11 +189,41 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev dd, const float *__restri
 
     // ---- every load whose address depends only on the game index is issued here, together: ONE memory round trip for
     //      the pending leaf's record, its path and move list, the game's state and board, and the root header ----
-    const int e_node = EXPAND ? d.leaf_node[vi] : -1, e_slot = EXPAND ? d.leaf_slot[vi] : 0, e_depth = EXPAND ? d.leaf_depth[vi] : 0;
-    const int e_nv = EXPAND ? d.leaf_nmoves[vi] : 0, e_top = EXPAND ? d.arena_top[g] : 0;
-    const int e_centry = (EXPAND && d.cache_entries) ? d.leaf_cache[vi] : -1;
     const bool shared = d.cache_entries && d.cache_shared;
-    const unsigned cstamp = shared ? d.cache_stamp[0] : 0u;
+    int e_node, e_slot, e_depth, e_nv, e_top, e_centry, s_done, s_player, s_mc, s_rootf64, r_fc, r_N;
+    uint32_t r_meta;
+    unsigned cstamp;
+    constexpr bool ONE_LOAD = EXPAND && SELECT && !MULTI;
+    int uw = 0;
+    if (ONE_LOAD) {
+        // The fourteen per-game words below are uniform, and left to the compiler they become scalar loads issued in four
+        // dependent groups (SGPR pressure) - four round trips before the first branch.  Here lane k fetches word k: ONE vector
+        // load, first in the queue, and the words come back through v_readlane.
+        const int *up = d.leaf_node + vi;                                 // lane 0 (and every lane without a word of its own)
+        up = lane == 1 ? d.leaf_slot + vi : up;
+        up = lane == 2 ? d.leaf_depth + vi : up;
+        up = lane == 3 ? d.leaf_nmoves + vi : up;
+        up = lane == 4 ? d.arena_top + g : up;
+        up = (lane == 5 && d.cache_entries) ? d.leaf_cache + vi : up;
+        up = (lane == 6 && shared) ? (const int *)d.cache_stamp : up;
+        up = lane == 7 ? d.done + g : up;
+        up = lane == 8 ? d.to_move + g : up;
+        up = lane == 9 ? d.move_count + g : up;
+        up = lane == 10 ? d.root_f64 + g : up;
+        up = lane == 11 ? d.first_child + base : up;
+        up = lane == 12 ? d.N + base : up;
+        up = lane == 13 ? (const int *)(d.meta + base) : up;
+        uw = *up;
+    } else {
+        e_node = EXPAND ? d.leaf_node[vi] : -1; e_slot = EXPAND ? d.leaf_slot[vi] : 0; e_depth = EXPAND ? d.leaf_depth[vi] : 0;
+        e_nv = EXPAND ? d.leaf_nmoves[vi] : 0; e_top = EXPAND ? d.arena_top[g] : 0;
+        e_centry = (EXPAND && d.cache_entries) ? d.leaf_cache[vi] : -1;
+        cstamp = shared ? d.cache_stamp[0] : 0u;
+        s_done = SELECT ? d.done[g] : 1; s_player = SELECT ? d.to_move[g] : 0; s_mc = SELECT ? d.move_count[g] : 0;
+        s_rootf64 = SELECT ? d.root_f64[g] : 0;
+        r_fc = SELECT ? d.first_child[base] : -1; r_N = SELECT ? d.N[base] : 0;
+        r_meta = SELECT ? d.meta[base] : 0u;
+    }
     unsigned long long e_key = 0ull;
     if (EXPAND && shared) e_key = d.leaf_key[(size_t)vi * d.key_words + min(lane, d.key_words - 1)];
     // (every per-lane load below is UNCONDITIONAL with a clamped index: a load under a lane predicate - `lane < n ? p[lane] : 0` -
@@ -206,14 +236,19 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev dd, const float *__restri
 #pragma unroll
         for (int k4 = 0; k4 < KSL; k4++) e_mv[k4] = d.leaf_moves[(size_t)vi * rc + min(lane + AZK_WAVE * k4, rc - 1)];
     }
-    const int s_done = SELECT ? d.done[g] : 1, s_player = SELECT ? d.to_move[g] : 0, s_mc = SELECT ? d.move_count[g] : 0;
-    int s_rootf64 = SELECT ? d.root_f64[g] : 0;
-    int r_fc = SELECT ? d.first_child[base] : -1, r_N = SELECT ? d.N[base] : 0;
-    uint32_t r_meta = SELECT ? d.meta[base] : 0u;
     int s_cells[KSL] = {0, 0, 0, 0, 0, 0, 0};               // (one register each: byte-sized destinations are packed, and every packed load waits for the one before)
     if (SELECT) {
 #pragma unroll
         for (int k4 = 0; k4 < KSL; k4++) s_cells[k4] = d.cells[(size_t)g * d.rc_pad + min(lane + AZK_WAVE * k4, rc - 1)];
+    }
+    if (ONE_LOAD) {                                          // (behind the loads that do not depend on them)
+        e_node = __builtin_amdgcn_readlane(uw, 0); e_slot = __builtin_amdgcn_readlane(uw, 1); e_depth = __builtin_amdgcn_readlane(uw, 2);
+        e_nv = __builtin_amdgcn_readlane(uw, 3); e_top = __builtin_amdgcn_readlane(uw, 4);
+        e_centry = d.cache_entries ? __builtin_amdgcn_readlane(uw, 5) : -1;
+        cstamp = shared ? (unsigned)__builtin_amdgcn_readlane(uw, 6) : 0u;
+        s_done = __builtin_amdgcn_readlane(uw, 7); s_player = __builtin_amdgcn_readlane(uw, 8); s_mc = __builtin_amdgcn_readlane(uw, 9);
+        s_rootf64 = __builtin_amdgcn_readlane(uw, 10); r_fc = __builtin_amdgcn_readlane(uw, 11); r_N = __builtin_amdgcn_readlane(uw, 12);
+        r_meta = (uint32_t)__builtin_amdgcn_readlane(uw, 13);
     }
 
     if (EXPAND) {
