@@ -300,11 +300,6 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev dd, const float *__restri
                 cache_write = cur != cstamp && (unsigned)uniform_i32((int)got) == cur;
                 if (cache_write && lane < d.key_words) d.cache_key[crow * d.key_words + lane] = e_key;
             }
-            if (cache_write) {
-#pragma unroll
-                for (int k4 = 0; k4 < KSL; k4++) { const int i = lane + AZK_WAVE * k4; if (i < A) d.cache_logits[crow * A + i] = lgv[k4]; }
-                if (lane == 0) d.cache_value[crow] = vraw;
-            }
             if (xst) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); x1 = clock64(); }
             // float32 softmax, no max subtraction (mcts.py:48-49)
 #pragma unroll
@@ -315,6 +310,13 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev dd, const float *__restri
                 if (i < A) L.e[i] = ev;
             }
             __syncthreads();
+            if (cache_write) {
+                // (behind the exponentials: by now every logit is in its register, and the stores go out back to back - placed
+                //  right behind the loads, each store waited for the one before it, one write round trip per 64 actions)
+#pragma unroll
+                for (int k4 = 0; k4 < KSL; k4++) { const int i = lane + AZK_WAVE * k4; if (i < A) d.cache_logits[crow * A + i] = lgv[k4]; }
+                if (lane == 0) d.cache_value[crow] = vraw;
+            }
             if (xst) x2 = clock64();
             const float s = azk_pairwise_sum(L.e, A, L.racc);
             if (xst) x3 = clock64();
