@@ -272,9 +272,11 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev dd, const float *__restri
             if (shared && !hit) claim_now = __hip_atomic_load(d.cache_claim + crow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             // Node.backup operands (trace nodes 0..depth, one per lane) are fetched now, next to the logits: second round trip
             const bool shortpath = depth < AZK_WAVE;
-            int bN = 0;
-            double bW = 0.0;
-            if (shortpath && lane <= depth) { bN = d.N[base + e_path]; bW = d.W[base + e_path]; }
+            // (unconditional, the lanes beyond the path read the root: a load under a lane predicate is followed by a wait for it,
+            //  which put a whole round trip between these two loads and the logits below)
+            const int bnode = (shortpath && lane <= depth) ? e_path : 0;
+            const int bN = d.N[base + bnode];
+            const double bW = d.W[base + bnode];
             // second (and last) round trip of the expansion, all straight-line: logits, value, the node's header, root noise
             float lgv[KSL];
 #pragma unroll
@@ -579,23 +581,23 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev dd, const float *__restri
             int entry;
             if (shared) {
                 entry = (int)(h & d.cache_mask);
+                // one round trip for the claim word, the key and the entry's row (fetched on speculation: most probes miss, a row is
+                // 900 bytes), a second one for the claim word again; the reads of a hit used to be four dependent round trips
                 const unsigned c1 = (unsigned)uniform_i32((int)__hip_atomic_load(d.cache_claim + entry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                if (c1 != 0u && c1 < cstamp) {                        // written in an earlier launch: complete and visible
-                    const unsigned long long *kp = d.cache_key + (size_t)entry * KW;
-                    const bool same = lane < KW ? kp[lane] == mykey : true;
-                    if (__ballot(!same) == 0ull) {
-                        float row[KSL];
+                const unsigned long long kw = d.cache_key[(size_t)entry * KW + min(lane, KW - 1)];
+                float row[KSL];
 #pragma unroll
-                        for (int k4 = 0; k4 < KSL; k4++) { const int i = lane + AZK_WAVE * k4; row[k4] = d.cache_logits[(size_t)entry * A + (i < A ? i : A - 1)]; }
-                        const float vv = d.cache_value[entry];
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the copy is in registers before the claim word is read again
-                        const unsigned c2 = (unsigned)uniform_i32((int)__hip_atomic_load(d.cache_claim + entry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                        if (c2 == c1) {                               // nobody started rewriting the entry meanwhile: the copy is whole
-                            cached = true;
+                for (int k4 = 0; k4 < KSL; k4++) { const int i = lane + AZK_WAVE * k4; row[k4] = d.cache_logits[(size_t)entry * A + (i < A ? i : A - 1)]; }
+                const float vv = d.cache_value[entry];
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the copy is in registers before the claim word is read again
+                const bool same = lane < KW ? kw == mykey : true;
+                if (c1 != 0u && c1 < cstamp && __ballot(!same) == 0ull) {     // written in an earlier launch (complete and visible), same position
+                    const unsigned c2 = (unsigned)uniform_i32((int)__hip_atomic_load(d.cache_claim + entry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    if (c2 == c1) {                                       // nobody started rewriting the entry meanwhile: the copy is whole
+                        cached = true;
 #pragma unroll
-                            for (int k4 = 0; k4 < KSL; k4++) { const int i = lane + AZK_WAVE * k4; if (i < A) d.hit_logits[(size_t)vi * A + i] = row[k4]; }
-                            if (lane == 0) d.hit_value[vi] = vv;
-                        }
+                        for (int k4 = 0; k4 < KSL; k4++) { const int i = lane + AZK_WAVE * k4; if (i < A) d.hit_logits[(size_t)vi * A + i] = row[k4]; }
+                        if (lane == 0) d.hit_value[vi] = vv;
                     }
                 }
                 if (!cached && lane < KW) d.leaf_key[(size_t)vi * KW + lane] = mykey;      // written into the table at expansion
