@@ -434,6 +434,39 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev dd, const float *__restri
                 }
                 best = __ffsll((long long)winners) - 1;
                 bN = Nc; bmeta = mc; bfc = fcc;
+            } else if (nch <= 2 * AZK_WAVE && !(ablate & 2048)) {
+                // 65 .. 128 candidates (late plies: every node of the tree): two per lane, the same straight-line shape - ten loads,
+                // one round trip.  (The general loop below sinks its prior loads into per-slot branches: one more round trip per
+                // 64 candidates, on every level of a late-game walk.)  First maximum wins: indices below 64 before the others.
+                const bool va = true, vb = lane + AZK_WAVE < nch;
+                const size_t ca = base + fc + lane, cb = base + fc + (vb ? lane + AZK_WAVE : 0);
+                const int Na = d.N[ca], Nb = d.N[cb];
+                const double Wa = d.W[ca], Wb = d.W[cb];
+                const uint32_t ma = d.meta[ca], mb = d.meta[cb];
+                const int fa = d.first_child[ca], fb = d.first_child[cb];
+                const float Pa = d.P[ca], Pb = d.P[cb];
+                unsigned long long wa, wb;
+                if (f64) {
+                    const double Qa = d.rootP[(size_t)g * rc + lane], Qb = d.rootP[(size_t)g * rc + (vb ? lane + AZK_WAVE : 0)];
+                    const double s = sqrt((double)Np);
+                    const double u0a = Qa * s / (double)(Na + 1), u0b = Qb * s / (double)(Nb + 1);
+                    const double qa = Wa / (double)Na, qb = Wb / (double)Nb;
+                    const double ua = Na != 0 ? qa + u0a : u0a;
+                    const double ub = vb ? (Nb != 0 ? qb + u0b : u0b) : -__builtin_huge_val();
+                    const double um = wave_max_f64(fmax(ua, ub));
+                    wa = __ballot(va & (ua == um)); wb = __ballot(vb & (ub == um));
+                } else {
+                    const float s = (float)sqrt((double)Np);
+                    const float u0a = (Pa * s) / (float)(Na + 1), u0b = (Pb * s) / (float)(Nb + 1);
+                    const float qa = (float)(Wa / (double)Na), qb = (float)(Wb / (double)Nb);
+                    const float ua = Na != 0 ? qa + u0a : u0a;
+                    const float ub = vb ? (Nb != 0 ? qb + u0b : u0b) : -__builtin_huge_valf();
+                    const float um = wave_max_f32(fmaxf(ua, ub));
+                    wa = __ballot(va & (ua == um)); wb = __ballot(vb & (ub == um));
+                }
+                const bool first = wa != 0ull;
+                best = first ? __ffsll((long long)wa) - 1 : AZK_WAVE + __ffsll((long long)wb) - 1;
+                bN = first ? Na : Nb; bmeta = first ? ma : mb; bfc = first ? fa : fb;
             } else {
             // all of this level's loads are issued before any arithmetic: 4 candidates per lane per 256-child chunk
             for (int c0 = 0; c0 < nch; c0 += 4 * AZK_WAVE) {
