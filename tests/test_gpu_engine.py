@@ -548,3 +548,46 @@ def test_large_and_odd_gomoku_boards_vs_oracle(azk, ao, size, plies, n_sims):
     want = digest(tree.export())
     assert digest(eng.export_tree(0)) == want and digest(eng.export_tree(1)) == want
     eng.close()
+
+
+@pytest.mark.parametrize("plies,variant", [(22, "uniform"), (34, "uniform"), (34, "hash")])
+def test_level_scan_with_65_to_128_children_vs_oracle(azk, ao, plies, variant):
+    """Late-ply 15x15 positions have 65..128 candidate moves: k_tree scans such a node two candidates per lane.  With uniform
+    priors every unvisited child ties, so the tree is right only if "first maximum wins" (node.py:47) holds across the two
+    candidates of a lane and across lanes; also with the hashed logits, with Dirichlet noise at the root (float64 UCB)."""
+    size, n_sims = 15, 300
+    game = ao.OracleGame("gomoku", size)
+    rng = np.random.RandomState(4242 + plies)
+    while True:
+        b = game.new_board()
+        player, mc = 0, 0
+        # scattered stones (far apart) make many candidates out of few plies
+        while mc < plies:
+            cell = int(rng.randint(size * size))
+            r, c = game.rc(cell)
+            if b[0][r][c] or b[1][r][c]:
+                continue
+            b2 = b.copy()
+            nxt = game.make_move(b2, player, (r, c))
+            if game.check_winner(b2, player, (r, c)) == -1:
+                b, player, mc = b2, nxt, mc + 1
+        ncand = len(game.valid_cells(b))
+        if 70 <= ncand <= 120:
+            break
+    cells = (b[0] + 2 * b[1]).astype(np.int8).reshape(-1)
+    A = size * size
+    noise = rng.dirichlet([0.03] * A)
+
+    def evc(canon):
+        logits, v = fixture_logits_value(torch.from_numpy(np.ascontiguousarray(canon))[None], A, variant)
+        return ao.softmax_det(logits[0].numpy()), float(v[0])
+    tree = ao.OracleTree(game, cap=1 + n_sims * A)
+    tree.reset(player, mc)
+    ao.mcts(game, tree, b.copy(), n_sims, evc, noise, None, None, None)
+    eng = azk.Engine("gomoku", 2, n_sims, size=size)
+    eng.set_positions(np.tile(cells, (2, 1)), [player] * 2, [mc] * 2)
+    eng.search(gpu_evaluator(A, variant), n_sims, torch.from_numpy(np.tile(noise, (2, 1))).to(dev()))
+    eng.check_error()
+    want = digest(tree.export())
+    assert digest(eng.export_tree(0)) == want and digest(eng.export_tree(1)) == want
+    eng.close()
