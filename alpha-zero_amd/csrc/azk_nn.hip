@@ -2312,6 +2312,11 @@ __global__ __launch_bounds__(64 * NWR * NWC * NWK, 1) void k_tail_gemm(TailArgs 
     __shared__ f32x4 kred[NWK > 1 ? (NWK - 1) * RTHI * 4 * 64 : 1];
     // the items cover the live rows only (measured: letting the dead half of the buffer issue its loads too costs 40-60 % - these
     // GEMMs move ~100 KB per wave through L2 and are bound by that traffic, not by the count's extra round trip)
+    // (every kernel argument is wanted in SGPRs HERE: left alone, the compiler fetches the count pointer first, waits for the count,
+    //  and only then goes back to the argument segment for the rest - a third dependent scalar round trip before the first load)
+    asm volatile("" :: "s"(a.A), "s"(a.Wp), "s"(a.out), "s"(a.bias), "s"(a.resid), "s"(a.stats_in), "s"(a.stats_out), "s"(a.logits), "s"(a.values),
+                 "s"(a.lda), "s"(a.ldo), "s"(a.N), "s"(a.nbatch), "s"(a.wave_slots), "s"(a.M), "s"(a.a_batch), "s"(a.w_batch), "s"(a.ldr),
+                 "s"(a.ln_eps), "s"(a.action_dim));
     const int nvalid = a.count ? min(a.M, *a.count) : a.M;
     const int strip_waves = (a.N >> 6) * a.nbatch * NWK;          // waves per strip of 16 RT rows
     int rt = RTLO;
