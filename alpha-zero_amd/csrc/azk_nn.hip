@@ -2085,10 +2085,12 @@ extern "C" int32_t azk_nn_heads_finalize_sum(const float *partials_dev, int32_t 
 // =====================================================================================================
 // k_tail_gemm: the cls-row tail (nn.py:54-60, 78-83 for the one row the heads read) as a chain of latency-shaped small
 // GEMMs.  At ~1000 live rows every GEMM of the tail is a few MFLOP per CU: what costs time is the number of dependent
-// memory round trips, so a wave issues EVERY load of its K chunk (A rows and weight fragments) before its first MFMA -
-// one round trip per 256..512 columns of K - and a second chunk is already in flight while the first is multiplied.
-//   wave tile 16 RT rows x 64 columns, no LDS, no barriers; A fragments straight from the row-major activations, B
-//   fragments from weights packed in fragment order (pack_linear_weight: one 16-byte load per fragment);
+// memory round trips, so a wave issues EVERY load of its K range (A rows and weight fragments) before its first MFMA: one
+// round trip.  NWK > 1 splits K over the waves of a workgroup (partials meet in LDS): a quarter of the loads and MFMAs on
+// each wave's chain - what the three small GEMMs of the tail use.
+//   wave tile 16 RT rows x 64 columns (RT picked in the kernel from the live row count, see k_tail_gemm below), no LDS staging;
+//   A fragments straight from the row-major activations, B fragments from weights packed in fragment order
+//   (pack_linear_weight: one 16-byte load per fragment);
 //   AMODE 1: A = LayerNorm(rows) with the affine folded into weight and bias by the caller.  The row statistics come from the
 //            PRODUCING GEMM: its epilogue leaves, per row and 64-column group, the (sum, sum of squares) of the bf16 values it
 //            stored; the consumer adds the groups in a fixed order (deterministic, no atomics) and normalises its fragments on
