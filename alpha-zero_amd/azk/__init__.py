@@ -14,8 +14,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(os.path.dirname(_HERE), "csrc")
 LIB_PATH = os.path.join(_HERE, "libazk.so")
 
+ABI_VERSION = 2           # include/azk.h AZK_ABI_VERSION the structure layouts below were written for
 GAME_ID = {"tictactoe": 0, "connect4": 1, "gomoku": 2}
 LEAF_F32, LEAF_BF16 = 0, 1
+EMBED_POOL_COMPACT_MAX_SLOTS = 65279       # AZK_EMBED_POOL_COMPACT_MAX_SLOTS (include/azk.h)
 
 # every symbol include/azk.h declares (checked by tests/test_abi.py against the header text)
 SYMBOLS = [
@@ -56,7 +58,7 @@ class EmbedPoolConsts(C.Structure):
     _fields_ = [("wt_frag", C.c_void_p), ("cpos_tok", C.c_void_p), ("score_tok", C.c_void_p), ("wconst_tok", C.c_void_p),
                 ("xnconst_tok", C.c_void_p), ("z_all", C.c_void_p), ("l_all", C.c_void_p), ("score_msum", C.c_void_p),
                 ("score_ref", C.c_void_p), ("num_heads", C.c_int32), ("ksize", C.c_int32), ("kp", C.c_int32),
-                ("embed_dim", C.c_int32), ("ln_eps", C.c_float)]
+                ("embed_dim", C.c_int32), ("ln_eps", C.c_float), ("work_stats", C.c_void_p)]
 
 
 class TailGemm(C.Structure):
@@ -107,6 +109,9 @@ def lib():
     L = C.CDLL(LIB_PATH)
     vp, i32, i64, u64, f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_double
     L.azk_abi_version.restype = i32
+    if L.azk_abi_version() != ABI_VERSION:
+        raise AzkError(f"{LIB_PATH} speaks ABI version {L.azk_abi_version()}, this binding was written for {ABI_VERSION} "
+                       "(include/azk.h AZK_ABI_VERSION): rebuild with __graft_entry__.build()")
     L.azk_last_error.restype = C.c_char_p
     L.azk_last_error.argtypes = [vp]
     L.azk_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
@@ -670,7 +675,15 @@ class EmbedPoolTables:
         self.tokens, self.num_heads, self.embed_dim = T1 - 1, num_heads, embed_dim
         self.c = EmbedPoolConsts(*[self.t[k].data_ptr() for k in ("wt_frag", "cpos_tok", "score_tok", "wconst_tok", "xnconst_tok", "z_all",
                                                                  "l_all", "score_msum", "score_ref")],
-                                 num_heads, ksize, self.t["wt_ext"].shape[1], embed_dim, float(eps))
+                                 num_heads, ksize, self.t["wt_ext"].shape[1], embed_dim, float(eps), None)
+        self.work_stats = None
+
+    def enable_work_stats(self):
+        """Device counters [boards evaluated, 16-token tiles evaluated] (int64 [2]), bumped by every launch from now on."""
+        if self.work_stats is None:
+            self.work_stats = _torch().zeros(2, dtype=_torch().int64, device=self.t["cpos_tok"].device)
+            self.c.work_stats = self.work_stats.data_ptr()
+        return self.work_stats
 
 
 def new_sched(device):

@@ -1173,6 +1173,7 @@ struct EmbedPoolCArgs {
     const int *count;
     int *sched;                    // [1]: ticket counter of the board queue; zero between launches
     long long *dbg;                // debug only (AZK_EMBED_POOL_STAMPS): [8] cycle sums per phase, wave 0 of every workgroup
+    unsigned long long *wstats;    // optional [2]: boards evaluated, 16-token tiles evaluated (fire-and-forget atomics, one pair per board)
     int n, R, Cc, T;
     float eps;
     azk_leaf_source src;
@@ -1450,6 +1451,7 @@ __global__ __launch_bounds__(256, 2) void k_embed_pool_c(EmbedPoolCArgs a) {
 
         AZK_STAMP(2);                                             // patch bits + compaction
         if (stamp) nt_acc += ntile;
+        if (a.wstats != nullptr && tid == 0) { atomicAdd(a.wstats, 1ull); atomicAdd(a.wstats + 1, (unsigned long long)ntile); }
         float L = 0.f;                                    // per head (lane&15 < NH): this lane>>4 group's share of sum (w - wc)
         // The per-token constants are GATHERED (by token index, L2) and every tile would wait a full round trip for them, so they
         // run one phase ahead: the conv MFMAs start from zero and the constants are added behind them; the registers they leave
@@ -1648,6 +1650,7 @@ static int32_t embed_pool_c_impl(const void *boards_dev, int32_t boards_are_f32,
     a.boards = boards_dev; a.boards_f32 = boards_are_f32; a.wt_frag = k->wt_frag; a.cposT = k->cpos_tok;
     a.scoreT = k->score_tok; a.wcT = k->wconst_tok; a.xncT = (const __hip_bfloat16 *)k->xnconst_tok; a.zall = k->z_all; a.lall = k->l_all;
     a.msum = k->score_msum; a.sref = k->score_ref; a.z = (__hip_bfloat16 *)z_out_bf16_dev; a.count = n_valid_dev; a.sched = sched_dev;
+    a.wstats = (unsigned long long *)k->work_stats;
     a.n = n; a.R = rows; a.Cc = cols; a.T = rows * cols + 1; a.eps = k->ln_eps;
     if (src) a.src = *src;
     {
@@ -1688,6 +1691,9 @@ extern "C" int32_t azk_nn_embed_pool_compact_leaves(const azk_leaf_source *src, 
                                                     int32_t *sched_dev, void *stream) {
     if (!src || !src->leaf_flag || !src->leaf_cells || !src->to_move || !src->leaf_depth || !src->leaf_slot || !src->n_leaf) return AZK_ERR_ARG;
     if (src->n_games < 1 || src->rows * src->cols != src->rc || src->flag_bytes < src->n_games) return AZK_ERR_ARG;
+    // the leaf ranks travel as 16-bit per-class counters with 0xffff = "no game" (and 8-bit per-thread run counters): more pending-leaf
+    // slots than this would wrap them silently - refuse, the caller keeps azk_nn_embed_pool_leaves / azk_step_gather for such engines
+    if (src->n_games > AZK_EMBED_POOL_COMPACT_MAX_SLOTS) return AZK_ERR_ARG;
     return embed_pool_c_impl(nullptr, 0, src, consts, z_out_bf16_dev, src->n_games, src->planes, src->rows, src->cols, nullptr, sched_dev, stream);
 }
 

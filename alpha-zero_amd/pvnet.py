@@ -126,11 +126,12 @@ class PolicyValueNet:
         self.fused_embed_pool = False   # set by _prepare_folded when azk_nn_embed_pool covers this configuration
         self.chain_tail = False         # set by _prepare_folded when azk_nn_tail_gemm covers this configuration
         self.use_chain_tail = True
-        self._tail_ws = {}              # workspace of the tail chain, keyed by the row count
+        self._tail_ws = {}              # workspaces of the tail chain, one per board source, sized for the largest batch seen
+        self._tail_ws_retired = []      # outgrown workspaces, kept alive (captured graphs may hold their addresses)
         self._compact = None            # azk.EmbedPoolTables when the compacting kernel covers this configuration (static softmax reference)
         self.use_compact = True
         self._scheds = {}               # work-queue words of the compacting kernel, one buffer per board source (= per stepping stream)
-        self.kernel_timers = None   # optional (embed_timer, pool_timer) with start()/stop(): HIP-event timing of the two kernels
+        self.kernel_timers = None   # optional timers with start()/stop() (HIP events): (embed+pool, tail) on the fused path, (embed, pool, tail) otherwise
         self.live_count = None      # optional int32 CUDA tensor: number of valid rows at the head of the batch (graph stepping)
         self.to(device, dtype)
 
@@ -371,15 +372,21 @@ class PolicyValueNet:
         cfg, f = self.cfg, self._fold
         n, A, D, H = z.shape[0], cfg.action_dim, cfg.embed_dim, cfg.num_heads
         dev, cnt = z.device, self.live_count
-        key = (n, id(self.leaf_source) if self.leaf_source is not None else None)     # one workspace per stepped engine (= per stream)
+        # one workspace per stepped engine (= per stream), sized for the largest batch seen and sliced; a workspace is never freed:
+        # a captured step graph has its addresses baked in (freeing would let the caching allocator hand the memory to someone else
+        # while graph replays keep writing into it), so a larger batch retires the old buffers to a keep-alive list instead
+        key = id(self.leaf_source) if self.leaf_source is not None else None
         ws = self._tail_ws.get(key)
-        if ws is None:
+        if ws is None or ws["rows"] < n:
+            rows = n if ws is None else max(n, 2 * ws["rows"])
+            if ws is not None:
+                self._tail_ws_retired.append(ws)
             bf = dict(dtype=torch.bfloat16, device=dev)
-            ws = dict(u=torch.empty((n, D), **bf), x1=torch.empty((n, D), **bf), hh=torch.empty((n, 4 * D), **bf), x2=torch.empty((n, D), **bf),
-                      st1=torch.empty((n, D // 64, 2), dtype=torch.float32, device=dev), st2=torch.empty((n, D // 64, 2), dtype=torch.float32, device=dev))
-            if len(self._tail_ws) > 8:
-                self._tail_ws.clear()
+            ws = dict(rows=rows, u=torch.empty((rows, D), **bf), x1=torch.empty((rows, D), **bf), hh=torch.empty((rows, 4 * D), **bf),
+                      x2=torch.empty((rows, D), **bf), st1=torch.empty((rows, D // 64, 2), dtype=torch.float32, device=dev),
+                      st2=torch.empty((rows, D // 64, 2), dtype=torch.float32, device=dev))
             self._tail_ws[key] = ws
+        ws = {k_: (v[:n] if k_ != "rows" else v) for k_, v in ws.items()}
         azk.nn_tail_gemm(z.view(n, H * D), f["WvHP"], D // H, D, azk.TAIL_BF16, nbatch=H, a_batch_stride=D, out=ws["u"], count=cnt)
         azk.nn_tail_gemm(ws["u"], f["WoP"], D, D, azk.TAIL_BF16, bias=f["bias1_f"], out=ws["x1"], stats_out=ws["st1"], count=cnt)
         azk.nn_tail_gemm(ws["x1"], f["W0GP"], 4 * D, D, azk.TAIL_GELU, bias=f["b0G_f"], out=ws["hh"], a_stats=ws["st1"], count=cnt)
@@ -395,6 +402,16 @@ class PolicyValueNet:
 
     def tail_fast(self, z):
         """depth-1 cls row after the pooled tokens zn [n, H, D]: composed projection, MLP, final norm, merged heads."""
+        # kernel_timers = (k_embed_pool, k_tail) on the fused path, (k_embed, k_cls_pool, k_tail) on the two-kernel path
+        kt = self.kernel_timers[-1] if self.kernel_timers is not None and len(self.kernel_timers) >= (2 if self.fused_embed_pool else 3) else None
+        if kt is None:
+            return self._tail_fast(z)
+        kt.start()                                   # HIP events around the whole tail (its launches back to back on this stream)
+        out = self._tail_fast(z)
+        kt.stop()
+        return out
+
+    def _tail_fast(self, z):
         if getattr(self, "chain_tail", False) and self.use_chain_tail:
             return self.tail_chain(z)
         if self.hip_tail and self.use_hip_tail:
@@ -590,7 +607,8 @@ class PolicyValueNet:
                 if self.cfg.num_heads in (4, 8):
                     if x.dtype not in (torch.bfloat16, torch.float32):
                         x = x.float()
-                    if self.fused_embed_pool and self._compact is not None and self.use_compact:
+                    compact_ok = self.leaf_source is None or self.leaf_source.n_games <= azk.EMBED_POOL_COMPACT_MAX_SLOTS
+                    if self.fused_embed_pool and self._compact is not None and self.use_compact and compact_ok:
                         # only the tokens a stone can reach are evaluated (k_embed_pool_c); boards pulled from a device queue
                         if self.leaf_source is not None:
                             z = azk.nn_embed_pool_compact_leaves(self.leaf_source, self._compact, self._sched_for(self.leaf_source),

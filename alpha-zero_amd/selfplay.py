@@ -278,9 +278,9 @@ class SelfPlayRunner:
             if timer is None:
                 self.evaluator.kernel_timers = None
             elif getattr(self.evaluator, "fused_embed_pool", False):
-                self.evaluator.kernel_timers = (timer.child("k_embed_pool"),)
+                self.evaluator.kernel_timers = (timer.child("k_embed_pool"), timer.child("k_tail"))
             else:
-                self.evaluator.kernel_timers = (timer.child("k_embed"), timer.child("k_cls_pool"))
+                self.evaluator.kernel_timers = (timer.child("k_embed"), timer.child("k_cls_pool"), timer.child("k_tail"))
         if hasattr(self.evaluator, "out_buffers"):
             self.evaluator.out_buffers = (h.logits_buf, h.values_buf)
         logits, values = self.evaluator(e.leaf_boards)

@@ -263,6 +263,7 @@ def main():
         net = PolicyValueNet(cfg, seed=0, device=f"cuda:{local_rank}", dtype=nn_torch_dtype, path=args.nn_path)
         net.use_chain_tail = args.tail == "chain"
         kt = KernelTimer(stride=args.timer_stride)
+        ep_stats = net._compact.enable_work_stats() if getattr(net, "_compact", None) is not None else None   # boards / 16-token tiles evaluated
         if args.train_step:
             from azk import DeviceReplay
             from trainer import Trainer
@@ -310,6 +311,8 @@ def main():
             train_one()
     train_ms.clear()
     runner.reset_counters()
+    if not stub and ep_stats is not None:
+        ep_stats.zero_()
     plies0, fin0, finp0 = runner.plies_played, runner.games_finished, runner.finished_plies
     launches0 = getattr(runner, "launches", 0)
     kt.enabled = True
@@ -394,10 +397,10 @@ def main():
                 pass
             compact = getattr(net, "_compact", None) is not None and getattr(net, "use_compact", False)
             executed_share = None
-            try:        # share of the 16-token tiles the compacting kernel really evaluates (measured on the same workload, tools/measure_leaves.py)
-                executed_share = json.load(open(os.path.join(ROOT, "profiles", "r02_leaf_stats.json")))["dirty_tokens_per_leaf"]["mean_tiles_of_16"] / ((T_tok + 15) // 16)
-            except Exception:
-                pass
+            if compact and ep_stats is not None:
+                # share of the 16-token tiles the compacting kernel really evaluated IN THIS RUN (device counters of the kernel itself)
+                eb, et = (int(v) for v in ep_stats.tolist())
+                executed_share = et / max(1, eb) / ((T_tok + 15) // 16)
             kernels.append({"kernel": "k_embed_pool_c" if compact else "k_embed_pool", "bound": "mfma", "achieved": fl / (ms * 1e-3) / 1e12,
                             "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fl / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, "avg_launch_us": ms * 1e3,
                             "algorithmic_flops_per_launch": fl, "traffic": ep_traffic,
@@ -407,15 +410,36 @@ def main():
                                     f"{live:.0f} live boards per launch; the compacting kernel evaluates only the tokens a stone can reach and takes the "
                                     "rest as precomputed constants (executed_share_of_algorithmic_flops: MFMA work actually issued); HBM traffic is "
                                     "~9 KB per board (board in, z out): bound by VALU/MFMA issue and LDS, not HBM"})
-        dominant = max(kernels, key=lambda k: k["avg_launch_us"]) if kernels else None
+        ch = kt.children.get("k_tail")                  # the cls-row tail (five k_tail_gemm launches, or the library GEMMs): MFMA-bound
+        ms = ch.mean_ms() if ch else None
+        if ms and args.nn_path == "clsfold":
+            Hh, dh = cfg.num_heads, Dm // cfg.num_heads
+            # value projection per head + output projection + MLP up + MLP down + merged heads, per row
+            per_row = 2 * Hh * dh * Dm + 2 * Dm * Dm + 2 * 2 * Dm * 4 * Dm + 2 * Dm * (cfg.action_dim + 1)
+            rows = live if args.tail == "chain" else args.games * runner.leaves_per_step
+            fl = per_row * rows
+            kernels.append({"kernel": "k_tail_gemm x5 (cls-row tail)" if args.tail == "chain" else "library tail", "bound": "mfma",
+                            "achieved": fl / (ms * 1e-3) / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                            "frac": fl / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, "avg_launch_us": ms * 1e3,
+                            "algorithmic_flops_per_launch": fl, "traffic": None, "event_samples": len(ch.pairs),
+                            "note": f"{per_row} flop per row x {rows:.0f} rows per step; avg_launch_us = the whole tail (all of its launches, HIP events "
+                                    "around them); the per-launch split is in the rocprofv3 summary under profiles/"})
+        dominant = max((k for k in kernels if not k["kernel"].startswith(("k_tail_gemm x5", "library tail"))), key=lambda k: k["avg_launch_us"]) if kernels else None
         flops = {"cls": cfg.flops_cls(), "full": cfg.flops_full(), "clsfold": flops_clsfold(cfg)}[args.nn_path]
-        evals = leaves_all if args.no_graph else sims_all      # graph mode runs the cls-row tail over the full fixed-size leaf buffer every step
-        nn_flop_total = evals * flops
+        # Boards the network really processed: eager stepping and the hand-written tail chain honour the live leaf count; only the
+        # library tail (--tail library) runs the whole fixed-size leaf buffer every step.
+        chain = args.tail == "chain" and getattr(net, "chain_tail", False) and args.nn_path == "clsfold"
+        full_buffer_rows = sims_all * runner.leaves_per_step
+        evals = leaves_all if (args.no_graph or chain) else full_buffer_rows
+        nn_flop_alg = evals * flops                     # algorithmic flops of the function on the boards processed
+        nn_flop_issued = nn_flop_alg
         if not args.no_graph and getattr(net, "fused_embed_pool", False) and args.nn_path == "clsfold":
-            # ... but the embedding / pooling kernel honours the live leaf count: only the tail is paid for dead rows
             kreal_ = cfg.channels * cfg.patch_size ** 2
             front = 2 * (cfg.tokens - 1) * cfg.embed_dim * kreal_ + 2 * 2 * cfg.tokens * cfg.embed_dim * cfg.num_heads
-            nn_flop_total = leaves_all * front + sims_all * (flops - front)
+            # the embedding / pooling kernel always honours the live count; the compacting kernel issues only `share` of its tiles
+            share = next((k_["executed_share_of_algorithmic_flops"] for k_ in kernels if k_["kernel"].startswith("k_embed_pool")), None) or 1.0
+            nn_flop_alg = leaves_all * front + evals * (flops - front)
+            nn_flop_issued = leaves_all * front * share + evals * (flops - front)
         out = {
             "metric": "selfplay_games_per_sec" if args.virtual_loss <= 1 else "selfplay_games_per_sec_virtual_loss", "value": games_per_s, "unit": "games/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt_max / args.steps * 1e3,
@@ -430,7 +454,8 @@ def main():
             "sims_per_sec": sims_all / dt_max, "leaf_evals_per_sec": leaves_all / dt_max,
             "eval_cache": {"entries_per_game": args.cache_entries, "mode": args.cache, "hits_rank0": c.get("cache_hits", 0),
                            "hit_rate_rank0": c.get("cache_hits", 0) / max(1, c.get("cache_hits", 0) + c["leaves_evaluated"])},
-            "nn_tflops_executed": nn_flop_total / dt_max / 1e12, "nn_flops_per_board": flops, "nn_boards_evaluated": evals,
+            "nn_tflops_algorithmic": nn_flop_alg / dt_max / 1e12, "nn_tflops_issued": nn_flop_issued / dt_max / 1e12,
+            "nn_flops_per_board": flops, "nn_boards_evaluated": evals,
             "stepping": "eager+sync" if args.no_graph else f"hipGraph replay, {runner.steps_per_graph} simulation step(s) per graph, {runner.n_split} game group(s) (per simulation: k_tree, the network kernels taking the pending leaves straight from the engine, no host sync)",
             "value_definition": value_src, "games_per_sec_renewal_estimate": est_games_per_s,
             "mean_plies_per_game": mean_plies, "game_length_source": src, "games_finished_in_window": fin_window,

@@ -27,7 +27,9 @@
 extern "C" {
 #endif
 
-#define AZK_ABI_VERSION 1
+/* 2: azk_emit_finished's game_base_dev became int64*, azk_leaf_source gained cache_stamp, azk_config gained cache_shared /
+ * leaves_per_step (round 2); callers compare azk_abi_version() with the header they were built against */
+#define AZK_ABI_VERSION 2
 
 /* games (games/tictactoe.py, games/connect4.py, games/gomoku.py) */
 #define AZK_TICTACTOE 0
@@ -334,10 +336,14 @@ typedef struct azk_embed_pool_consts {
     const float *z_all, *l_all, *score_msum, *score_ref;
     int32_t num_heads, ksize, kp, embed_dim;
     float ln_eps;
+    uint64_t *work_stats;   /* optional device uint64 [2]: += boards evaluated, += 16-token tiles evaluated (bench accounting) */
 } azk_embed_pool_consts;
 int32_t azk_nn_embed_pool_compact(const void *boards_dev, int32_t boards_are_f32, const azk_embed_pool_consts *consts,
                                   void *z_out_bf16_dev, int32_t n, int32_t channels, int32_t rows, int32_t cols,
                                   const int32_t *n_valid_dev, int32_t *sched_dev, void *stream);
+/* azk_nn_embed_pool_compact_leaves ranks the pending leaves with 16-bit counters: engines with more pending-leaf slots
+ * (n_games * leaves_per_step) than this get AZK_ERR_ARG and keep azk_nn_embed_pool_leaves */
+#define AZK_EMBED_POOL_COMPACT_MAX_SLOTS 65279
 int32_t azk_nn_embed_pool_compact_leaves(const azk_leaf_source *src, const azk_embed_pool_consts *consts, void *z_out_bf16_dev,
                                          int32_t *sched_dev, void *stream);
 

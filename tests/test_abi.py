@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, name), f"{name} declared in include/azk.h but not exported"
     assert sorted(azk.SYMBOLS) == declared, "azk.SYMBOLS (python binding) and include/azk.h disagree"
     L.azk_abi_version.restype = ctypes.c_int32
-    assert L.azk_abi_version() == 1
+    assert L.azk_abi_version() == azk.ABI_VERSION == 2
 
 
 def test_no_torch_types_in_the_abi():
@@ -71,3 +71,16 @@ def test_facade_import_surface_matches_reference():
     assert MCTS.mcts_count >= 0 and isinstance(MCTS.cache, dict)
     for meth in ("display_board", "get_action_idx", "get_valid_moves", "make_move", "undo_move", "check_winner", "mcts"):
         assert hasattr(Gomoku, meth)
+
+
+def test_binding_refuses_a_library_of_another_abi_version(monkeypatch):
+    """azk.lib() compares azk_abi_version() with the version its structure layouts were written for (a stale libazk.so would
+    otherwise overrun buffers silently: e.g. azk_emit_finished's game_base went from int32* to int64* between versions 1 and 2)."""
+    import azk
+    monkeypatch.setattr(azk, "_LIB", None)
+    monkeypatch.setattr(azk, "ABI_VERSION", 999)
+    with pytest.raises(azk.AzkError, match="ABI version"):
+        azk.lib()
+    monkeypatch.setattr(azk, "ABI_VERSION", 2)
+    monkeypatch.setattr(azk, "_LIB", None)
+    assert azk.lib().azk_abi_version() == 2

@@ -549,3 +549,31 @@ def test_runner_steps_per_graph_plays_the_same_moves():
             assert n == n_ref == 3 * 128 * sims
             for (pa, cha), (pb, chb) in zip(ref, got):
                 assert np.array_equal(cha, chb) and pa.tobytes() == pb.tobytes(), (sims, per_graph, graph)
+
+
+def test_runner_real_network_eval_cache_is_transparent():
+    """The eval cache under the REAL bf16 network: 256 games, continuous self-play on the graph runner, the
+    cache off / one table per game / ONE table shared by every game (multi-writer: claim word, copy, re-read) must give the same
+    pi bytes and the same moves - a torn or stale row of the shared table would change a prior and show up here.  The shared
+    table is made small (64 entries per game) so that entries are overwritten while other games read them."""
+    from selfplay import SelfPlayRunner
+    cfg = NetConfig(15, 15, 2, 225, 5, 512, 8, 1)
+    net = PolicyValueNet(cfg, seed=6, device="cuda", dtype=torch.bfloat16, path="clsfold")
+
+    def play(entries, shared):
+        rec = []
+        r = SelfPlayRunner("gomoku", net, 256, 64, size=15, seed=11, leaf_dtype="bfloat16", recycle=True, use_graph=True, cache_entries=entries,
+                           cache_shared=shared, steps_per_graph=8,
+                           on_records=lambda mv, base, pi, q, ch, w, d: rec.append((pi.numpy().copy(), q.numpy().copy(), ch.numpy().copy())))
+        for _ in range(6):
+            r.play_move()
+        r.check_error()
+        return rec, r.counters()
+    off, c_off = play(0, False)
+    per, c_per = play(64, False)
+    sh, c_sh = play(64, True)
+    assert c_off["cache_hits"] == 0 and c_per["cache_hits"] > 0 and c_sh["cache_hits"] > c_per["cache_hits"] > 0
+    assert c_off["sims"] == c_per["sims"] == c_sh["sims"] == 6 * 256 * 64
+    for (pa, qa, ca), (pb, qb, cb), (pc, qc, cc) in zip(off, per, sh):
+        assert np.array_equal(ca, cb) and np.array_equal(ca, cc)
+        assert pa.tobytes() == pb.tobytes() == pc.tobytes() and qa.tobytes() == qb.tobytes() == qc.tobytes()
