@@ -32,6 +32,7 @@ SYMBOLS = [
     "azk_nn_gemm_rows", "azk_nn_layernorm_sum", "azk_nn_heads_finalize_sum", "azk_nn_ln_heads",
     "azk_leaf_source_of", "azk_nn_embed_pool_leaves", "azk_nn_embed_pool_compact", "azk_nn_embed_pool_compact_leaves",
     "azk_nn_tail_gemm", "azk_begin_search_budget", "azk_search_unfinished",
+    "azk_nnx_embed_pool", "azk_nnx_embed_pool_leaves", "azk_nnx_gemm",
 ]
 
 
@@ -69,6 +70,24 @@ class TailGemm(C.Structure):
                 ("a_stats", C.c_void_p), ("a_stats_groups", C.c_int32), ("stats_out", C.c_void_p),
                 ("out_bf16", C.c_void_p), ("ldo", C.c_int32), ("resid_bf16", C.c_void_p), ("ldr", C.c_int32),
                 ("logits_out", C.c_void_p), ("values_out", C.c_void_p), ("action_dim", C.c_int32)]
+
+
+class EmbedPoolXConsts(C.Structure):
+    """azk_embed_pool_x_consts (include/azk.h): tables of the fp32-accurate embedding + pooling kernel."""
+    _fields_ = [("wt_frag", C.c_void_p), ("cpos_tok", C.c_void_p), ("score_tok", C.c_void_p), ("wconst_tok", C.c_void_p),
+                ("xnconst_tok", C.c_void_p), ("z_all", C.c_void_p), ("l_all", C.c_void_p), ("score_msum", C.c_void_p),
+                ("score_ref", C.c_void_p), ("num_heads", C.c_int32), ("ksize", C.c_int32), ("kp", C.c_int32),
+                ("embed_dim", C.c_int32), ("ln_eps", C.c_float), ("wt_scale", C.c_float), ("work_stats", C.c_void_p)]
+
+
+class GemmX(C.Structure):
+    """azk_gemm_x (include/azk.h): one link of the cls-row tail in float32."""
+    _fields_ = [("a_f32", C.c_void_p), ("lda", C.c_int32), ("a_batch_stride", C.c_int32), ("w_packed", C.c_void_p),
+                ("m", C.c_int32), ("n_out", C.c_int32), ("k", C.c_int32), ("nbatch", C.c_int32), ("n_valid", C.c_void_p),
+                ("bias", C.c_void_p), ("layernorm_a", C.c_int32), ("epilogue", C.c_int32), ("ln_eps", C.c_float),
+                ("a_stats", C.c_void_p), ("stats_out", C.c_void_p), ("out_f32", C.c_void_p), ("ldo", C.c_int32),
+                ("resid_f32", C.c_void_p), ("ldr", C.c_int32), ("logits_out", C.c_void_p), ("values_out", C.c_void_p),
+                ("action_dim", C.c_int32)]
 
 
 class Counters(C.Structure):
@@ -159,6 +178,9 @@ def lib():
     L.azk_begin_search_budget.argtypes = [vp, vp, i32, i32, vp]
     L.azk_search_unfinished.argtypes = [vp, vp, vp]
     L.azk_nn_tail_gemm.argtypes = [C.POINTER(TailGemm), vp]
+    L.azk_nnx_embed_pool.argtypes = [vp, i32, C.POINTER(EmbedPoolXConsts), vp, i32, i32, i32, i32, vp, vp, vp]
+    L.azk_nnx_embed_pool_leaves.argtypes = [C.POINTER(LeafSource), C.POINTER(EmbedPoolXConsts), vp, vp, vp]
+    L.azk_nnx_gemm.argtypes = [C.POINTER(GemmX), vp]
     L.azk_nn_ln_heads.argtypes = [vp, vp, vp, C.c_float, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]
     L.azk_nn_gemm_rows.argtypes = [vp, i32, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]
     L.azk_nn_layernorm_sum.argtypes = [vp, i32, i32, vp, vp, vp, vp, C.c_float, vp, vp, vp, i32, i32, vp, vp]
@@ -931,3 +953,128 @@ def nn_ln_heads(x, ln_w, ln_b, w_packed, bias, action_dim, logits_out, values_ou
                                _p(logits_out), _p(values_out), _p(count), _stream())
     if rc != 0:
         raise AzkError(f"azk_nn_ln_heads failed ({rc})")
+
+
+# ---- fp32-accurate network path (csrc/azk_nnx.hip) ----------------------------------------------------------------------
+def split_fp16(x64, scale):
+    """float64 tensor -> (hi, lo) fp16 tensors with (hi + lo) / scale = x to 22 significant bits (two round-to-nearest steps)."""
+    torch = _torch()
+    xs = x64.double() * float(scale)
+    hi = xs.to(torch.float16)
+    lo = (xs - hi.double()).to(torch.float16)
+    return hi, lo
+
+
+class EmbedPoolXTables:
+    """Tables of azk_nnx_embed_pool, kept alive with their ctypes descriptor.  t: dict of CUDA tensors - wt_ext float64 [D+16, kp] (conv
+    weight, folded score rows, mean row); cpos_tok, xnconst_tok f32 [T+1, D]; score_tok, wconst_tok f32 [T+1, 16]; z_all f32 [16, D]
+    (head-major, converted to accumulator order here); l_all, score_msum, score_ref f32 [16]."""
+
+    WT_SCALE = 4096.0      # weights (|w| < 0.2 here) x 2^12: hi and lo fp16 terms both in the normal range down to |w| ~ 6e-5
+
+    def __init__(self, t, num_heads, ksize, embed_dim, eps=1e-5):
+        torch = _torch()
+        assert embed_dim == 512
+        dev = t["cpos_tok"].device
+        self.t = {k: v.contiguous() for k, v in t.items() if k not in ("wt_ext", "z_all")}
+        T1 = self.t["cpos_tok"].shape[0]
+        for k, shape in dict(cpos_tok=(T1, embed_dim), xnconst_tok=(T1, embed_dim), score_tok=(T1, 16), wconst_tok=(T1, 16), l_all=(16,),
+                             score_msum=(16,), score_ref=(16,)).items():
+            assert tuple(self.t[k].shape) == shape and self.t[k].dtype == torch.float32 and self.t[k].is_cuda, k
+        w = t["wt_ext"].double()
+        assert w.shape[0] == embed_dim + 16 and w.shape[1] % 32 == 0 and float(w.abs().max()) * self.WT_SCALE < 60000.0
+        kp = w.shape[1]
+        hi, lo = split_fp16(w, self.WT_SCALE)
+        ct, l = torch.arange(33, device=dev)[:, None], torch.arange(64, device=dev)[None, :]
+        col = torch.where(ct < 32, 64 * (ct >> 2) + 4 * (l & 15) + (ct & 3), 512 + (l & 15))                 # [33, 64]
+        kidx = (32 * torch.arange(kp // 32, device=dev)[:, None, None] + 8 * (l[0] >> 4)[None, :, None]
+                + torch.arange(8, device=dev)[None, None, :])                                             # [KS, 64, 8]
+        fh, fl = hi[col[:, None, :, None], kidx[None]], lo[col[:, None, :, None], kidx[None]]              # [33, KS, 64, 8]
+        self.t["wt_frag"] = torch.stack([fh, fl], dim=2).contiguous()                                      # [33, KS, 2, 64, 8]
+        # z_all [16 heads, D] -> accumulator order [w][q][lane = 16 l4 + l15][j]: head 4 l4 + j, column 64 w + 4 l15 + q
+        za = t["z_all"].float().view(4, 4, 8, 16, 4)                          # [l4, j, w, l15, q]
+        self.t["z_all"] = za.permute(2, 4, 0, 3, 1).reshape(8, 4, 64, 4).contiguous()
+        self.tokens, self.num_heads, self.embed_dim = T1 - 1, num_heads, embed_dim
+        self.c = EmbedPoolXConsts(*[self.t[k].data_ptr() for k in ("wt_frag", "cpos_tok", "score_tok", "wconst_tok", "xnconst_tok", "z_all",
+                                                                  "l_all", "score_msum", "score_ref")],
+                                  num_heads, ksize, kp, embed_dim, float(eps), float(self.WT_SCALE), None)
+        self.work_stats = None
+
+    def enable_work_stats(self):
+        if self.work_stats is None:
+            self.work_stats = _torch().zeros(2, dtype=_torch().int64, device=self.t["cpos_tok"].device)
+            self.c.work_stats = self.work_stats.data_ptr()
+        return self.work_stats
+
+
+def nnx_embed_pool(boards, tables, rows, cols, sched, count=None, timers=None):
+    """azk_nnx_embed_pool: boards [n, C, R, Cc] bf16 / f32 (values 0 / 1) -> z float32 [n, H, 512]."""
+    torch = _torch()
+    assert boards.is_cuda and boards.is_contiguous() and boards.dtype in (torch.bfloat16, torch.float32)
+    assert rows * cols + 1 == tables.tokens and sched.dtype == torch.int32 and sched.numel() >= 2
+    n, Cc = boards.shape[0], boards.shape[1]
+    z = torch.empty((n, tables.num_heads, tables.embed_dim), dtype=torch.float32, device=boards.device)
+    args = (_p(boards), 1 if boards.dtype == torch.float32 else 0, C.byref(tables.c), _p(z), n, Cc, rows, cols, _p(count), _p(sched), _stream())
+    if timers is not None:
+        timers[0].start()
+    rc = lib().azk_nnx_embed_pool(*args)
+    if timers is not None:
+        timers[0].stop()
+    if rc != 0:
+        raise AzkError(f"azk_nnx_embed_pool failed ({rc})")
+    return z
+
+
+def nnx_embed_pool_leaves(src, tables, sched, timers=None):
+    """azk_nnx_embed_pool over an engine's pending leaves (LeafSource): z float32 [slots, H, 512], rows [0, n_leaf) valid."""
+    torch = _torch()
+    assert src.rows * src.cols + 1 == tables.tokens and sched.dtype == torch.int32 and sched.numel() >= 2
+    z = torch.empty((src.n_games, tables.num_heads, tables.embed_dim), dtype=torch.float32, device=sched.device)
+    args = (C.byref(src), C.byref(tables.c), _p(z), _p(sched), _stream())
+    if timers is not None:
+        timers[0].start()
+    rc = lib().azk_nnx_embed_pool_leaves(*args)
+    if timers is not None:
+        timers[0].stop()
+    if rc != 0:
+        raise AzkError(f"azk_nnx_embed_pool_leaves failed ({rc})")
+    return z
+
+
+def pack_linear_weight_x(w):
+    """nn.Linear weight [n_out, k] -> float32 tensor in azk_nnx_gemm's fragment order (n_out padded with zero rows to a multiple of 64)."""
+    torch = _torch()
+    n_out, k = w.shape
+    assert k % 16 == 0
+    npad = (n_out + 63) // 64 * 64
+    wp = torch.zeros(npad, k, dtype=torch.float32, device=w.device)
+    wp[:n_out] = w.float()
+    # [g, l15, c, s, l4, i] -> [g, s, c, l4, l15, i]
+    return wp.view(npad // 64, 16, 4, k // 16, 4, 4).permute(0, 3, 2, 4, 1, 5).contiguous()
+
+
+def nnx_gemm(a, w_packed, n_out, k, epilogue=TAIL_BF16, nbatch=1, a_batch_stride=0, bias=None, out=None, resid=None,
+             a_stats=None, stats_out=None, logits=None, values=None, action_dim=0, count=None, eps=1e-5):
+    """One link of the fp32 cls-row tail (azk_nnx_gemm): a float32 [m, lda] x packed float32 weights -> out float32 [m, nbatch * n_out]
+    (or logits / values for the heads epilogue).  epilogue: TAIL_BF16 (= plain) / TAIL_GELU / TAIL_RESID / TAIL_HEADS."""
+    torch = _torch()
+    assert a.dtype == torch.float32 and a.stride(1) == 1 and w_packed.dtype == torch.float32
+    d = GemmX()
+    d.a_f32, d.lda, d.a_batch_stride, d.w_packed = a.data_ptr(), a.stride(0), int(a_batch_stride), w_packed.data_ptr()
+    d.m, d.n_out, d.k, d.nbatch = a.shape[0], int(n_out), int(k), int(nbatch)
+    d.n_valid = count.data_ptr() if count is not None else None
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.layernorm_a, d.epilogue, d.ln_eps = (1 if a_stats is not None else 0), int(epilogue), float(eps)
+    d.a_stats = a_stats.data_ptr() if a_stats is not None else None
+    d.stats_out = stats_out.data_ptr() if stats_out is not None else None
+    if out is not None:
+        assert out.dtype == torch.float32 and out.stride(1) == 1
+        d.out_f32, d.ldo = out.data_ptr(), out.stride(0)
+    if resid is not None:
+        assert resid.dtype == torch.float32 and resid.stride(1) == 1
+        d.resid_f32, d.ldr = resid.data_ptr(), resid.stride(0)
+    if logits is not None:
+        d.logits_out, d.values_out, d.action_dim = logits.data_ptr(), values.data_ptr(), int(action_dim)
+    rc = lib().azk_nnx_gemm(C.byref(d), _stream())
+    if rc != 0:
+        raise AzkError(f"azk_nnx_gemm failed ({rc})")

@@ -161,11 +161,182 @@ class PolicyValueNet:
         self._hip = None
         self._fold = None
         self._gelu_epilogue = False
+        self._exact = None
         if self.device.type == "cuda" and self.dtype == torch.bfloat16:
             self._prepare_hip_embed()
             if self._hip is not None:
                 self._prepare_folded()
+        elif self.device.type == "cuda" and self.dtype == torch.float32:
+            self._prepare_exact()
         return self
+
+    def exact_fold(self, dev=None):
+        """Operands of the fp32-accurate folded cls path (csrc/azk_nnx.hip: k_embed_pool_x, k_gemm_x) before packing: the same folds
+        as _prepare_folded / _prepare_compact - cls query through W_k, LayerNorm affines into the consuming weights, constant-token
+        softmax terms - carried out in FLOAT64 from the float32 master weights and rounded once.  Returns None when the
+        configuration is not covered (depth 1, D = 512, 4 / 8 heads, <= 256 tokens, conv K <= 64, a static softmax reference
+        that cannot underflow); then the torch float32 paths stay."""
+        cfg, m = self.cfg, self.master
+        D, H, T, A = cfg.embed_dim, cfg.num_heads, cfg.tokens, cfg.action_dim
+        kreal = cfg.channels * cfg.patch_size ** 2
+        kp = (kreal + 31) // 32 * 32
+        if not (cfg.depth == 1 and D == 512 and H in (4, 8) and T <= 256 and kp <= 64 and cfg.channels in (2, 3) and cfg.patch_size in (3, 5)
+                and A + 1 <= 256):
+            return None
+        dev = self.device if dev is None else torch.device(dev)
+        dh, eps = D // H, 1e-5
+        dd = lambda k_: m[k_].to(dev, torch.float64)
+        Wc = dd("embedding.patch_embed.patch_embed.weight").reshape(D, kreal)
+        cpos = dd("embedding.pos_embedding")[0].clone()
+        cpos[0] += dd("embedding.cls_token")[0, 0]
+        cpos[1:] += dd("embedding.patch_embed.patch_embed.bias")
+        b = "blocks.0."
+        g1, b1 = dd(b + "norm1.weight"), dd(b + "norm1.bias")
+        Wi, bi = dd(b + "attn.in_proj_weight"), dd(b + "attn.in_proj_bias")
+        x0 = cpos[0]
+        h0 = F.layer_norm(x0, (D,), g1, b1, eps)
+        q = (Wi[:D] @ h0 + bi[:D]).view(H, dh)
+        m_n = torch.einsum("he,hed->hd", q, Wi[D:2 * D].view(H, dh, D)) * (1.0 / math.sqrt(dh)) * g1      # [H, D]: scale Wk_h^T q_h, gamma folded
+        bound = math.sqrt(D) * m_n.norm(dim=1)
+        if float(bound.max()) > 40.0:
+            return None                                       # the static softmax reference would underflow
+        wt_ext = torch.zeros(D + 16, kp, dtype=torch.float64, device=dev)
+        wt_ext[:D, :kreal] = Wc
+        wt_ext[D:D + H, :kreal] = m_n @ Wc                   # x . m' = (m'^T Wconv) . patch + m' . cpos
+        wt_ext[D + 15, :kreal] = Wc.mean(0)                  # row mean as one more GEMM column
+        sc = torch.zeros(T, 16, dtype=torch.float64, device=dev)
+        sc[:, :H] = cpos @ m_n.t()
+        sc[:, 15] = cpos.mean(1)
+        ms = torch.zeros(16, dtype=torch.float64, device=dev)
+        ms[:H] = m_n.sum(1)
+        ref = torch.zeros(16, dtype=torch.float64, device=dev)
+        ref[:H] = bound
+        # the kernel reads float32 tables: the constant-token terms are derived from the ROUNDED tables, with the kernel's formulas
+        cpos32, sc32, ms32, ref32 = cpos.float(), sc.float(), ms.float(), ref.float()
+        mean = sc32[:, 15].double()
+        var = ((cpos32.double() ** 2).sum(1) / D - mean * mean).clamp_min(0.0)
+        rstd = 1.0 / torch.sqrt(var + eps)
+        xnc32 = (cpos32.double() * rstd[:, None] - (mean * rstd)[:, None]).float()
+        s_c = rstd[:, None] * (sc32.double() - mean[:, None] * ms32.double()[None, :])
+        wc = torch.zeros(T, 16, dtype=torch.float64, device=dev)
+        wc[:, :H] = torch.exp(s_c[:, :H] - ref32.double()[None, :H])
+        wc32 = wc.float()
+        null_sc = torch.zeros(1, 16, device=dev)
+        null_sc[:, :H] = -1e30
+        zrow = torch.zeros(1, D, device=dev)
+        r = dict(wt_ext=wt_ext, cpos_tok=torch.cat([cpos32, zrow]), score_tok=torch.cat([sc32, null_sc]),
+                 wconst_tok=torch.cat([wc32, torch.zeros(1, 16, device=dev)]), xnconst_tok=torch.cat([xnc32, zrow]),
+                 z_all=(wc32.double().t() @ xnc32.double()).float(), l_all=wc32.double().sum(0).float(), score_msum=ms32, score_ref=ref32)
+        # ---- cls-row tail: u_h = Wv'_h z_h;  x1 = Wo u + bias1;  hh = GELU(LN2(x1) W0'^T + b0');  x2 = x1 + b3 + W3 hh;  heads(LNf(x2)) ----
+        Wv, bv = Wi[2 * D:].view(H, dh, D), bi[2 * D:]
+        bvn = bv + (Wv @ b1).reshape(-1)
+        Wo, bo = dd(b + "attn.out_proj.weight"), dd(b + "attn.out_proj.bias")
+        g2, b2 = dd(b + "norm2.weight"), dd(b + "norm2.bias")
+        W0, b0 = dd(b + "mlp.0.weight"), dd(b + "mlp.0.bias")
+        gf, bf_ = dd("norm.weight"), dd("norm.bias")
+        Wh = torch.zeros(256, D, dtype=torch.float64, device=dev)
+        bh = torch.zeros(256, dtype=torch.float64, device=dev)
+        Wh[:A], bh[:A] = dd("policy_head.weight"), dd("policy_head.bias")
+        Wh[A], bh[A] = dd("value_head.weight")[0], dd("value_head.bias")[0]
+        r.update(Wvn=(Wv * g1).float(),                       # sum_t a_t (g xn_t + b1) = g (sum_t a_t xn_t) + b1 since sum_t a_t = 1
+                 Wo=Wo.float(), bias1=(x0 + bo + Wo @ bvn).float().contiguous(), W0G=(W0 * g2[None, :]).float(),
+                 b0G=(W0 @ b2 + b0).float().contiguous(), W3=dd(b + "mlp.3.weight").float(), b3=dd(b + "mlp.3.bias").float().contiguous(),
+                 WhG=(Wh * gf[None, :]).float(), bhG=(Wh @ bf_ + bh).float().contiguous())
+        return r
+
+    def _prepare_exact(self):
+        import azk
+        cfg = self.cfg
+        self.fused_embed_pool = False
+        r = self.exact_fold()
+        if r is None:
+            return
+        H = cfg.num_heads
+        e = dict(tables=azk.EmbedPoolXTables({k_: r[k_] for k_ in ("wt_ext", "cpos_tok", "score_tok", "wconst_tok", "xnconst_tok", "z_all", "l_all",
+                                                                   "score_msum", "score_ref")}, H, cfg.patch_size, cfg.embed_dim, 1e-5))
+        e["WvX"] = torch.cat([azk.pack_linear_weight_x(r["Wvn"][h]).reshape(-1) for h in range(H)])
+        for k_ in ("Wo", "W0G", "W3", "WhG"):
+            e[k_ + "X"] = azk.pack_linear_weight_x(r[k_])
+        for k_ in ("bias1", "b0G", "b3", "bhG"):
+            e[k_] = r[k_]
+        self._exact = e
+        self.fused_embed_pool = True                          # the step graph may hand the engine's pending leaves straight to the kernel
+
+    def forward_exact_emulated(self, x, r=None):
+        """What k_embed_pool_x + k_gemm_x compute, step by step from the same folded tables, in float64 torch on any device: the
+        checker of the kernels (tests) and of the fold itself (against the plain forward, on the CPU)."""
+        cfg = self.cfg
+        r = r or self.exact_fold(x.device)
+        D, H, T, A, k = cfg.embed_dim, cfg.num_heads, cfg.tokens, cfg.action_dim, cfg.patch_size
+        n = x.shape[0]
+        f8 = lambda t: t.double()
+        cols = F.unfold(x.double(), kernel_size=k, padding=k // 2).transpose(1, 2)               # [n, R*C, C*k*k] patch bits
+        kreal = cols.shape[2]
+        patch = torch.zeros(n, T, r["wt_ext"].shape[1], dtype=torch.float64, device=x.device)
+        patch[:, 1:, :kreal] = cols                                                              # token 0 (cls) has no patch
+        dirty = patch.abs().sum(2) > 0                                                           # [n, T]
+        xx = patch @ r["wt_ext"][:D].t() + f8(r["cpos_tok"][:T])
+        ext = patch @ r["wt_ext"][D:].t() + f8(r["score_tok"][:T])                               # [n, T, 16]
+        mean = ext[..., 15]
+        rstd = 1.0 / torch.sqrt(((xx * xx).sum(2) / D - mean * mean).clamp_min(0.0) + 1e-5)
+        xn = (xx - mean[..., None]) * rstd[..., None]
+        sco = rstd[..., None] * (ext - mean[..., None] * f8(r["score_msum"]))
+        w = torch.exp(sco - f8(r["score_ref"]))[..., :H]                                         # [n, T, H]
+        wc, xnc = f8(r["wconst_tok"][:T, :H]), f8(r["xnconst_tok"][:T])
+        dm = dirty[..., None].double()
+        Z = f8(r["z_all"][:H])[None] + torch.einsum("nth,ntd->nhd", w * dm, xn) - torch.einsum("nth,td->nhd", dm * wc[None], xnc)
+        Lh = f8(r["l_all"][:H])[None] + ((w - wc[None]) * dm).sum(1)
+        z = Z / Lh[..., None]                                                                    # [n, H, D]
+        u = torch.einsum("nhd,hed->nhe", z, f8(r["Wvn"])).reshape(n, D)
+        x1 = u @ f8(r["Wo"]).t() + f8(r["bias1"])
+        ln = lambda t: (t - t.mean(1, keepdim=True)) / torch.sqrt(t.var(1, unbiased=False, keepdim=True) + 1e-5)
+        hh = F.gelu(ln(x1) @ f8(r["W0G"]).t() + f8(r["b0G"]))
+        x2 = x1 + hh @ f8(r["W3"]).t() + f8(r["b3"])
+        out = ln(x2) @ f8(r["WhG"]).t() + f8(r["bhG"])
+        return out[:, :A].float(), torch.tanh(out[:, A:A + 1]).float(), z.float()
+
+    def forward_exact(self, x):
+        """The fp32-accurate folded cls path: boards (or the engine's pending leaves) -> z float32 [n, H, D] -> logits, tanh(value)."""
+        import azk
+        cfg, e = self.cfg, self._exact
+        if self.leaf_source is not None:
+            z = azk.nnx_embed_pool_leaves(self.leaf_source, e["tables"], self._sched_for(self.leaf_source), timers=self.kernel_timers)
+        else:
+            if x.dtype not in (torch.bfloat16, torch.float32):
+                x = x.float()
+            z = azk.nnx_embed_pool(x.contiguous(), e["tables"], cfg.rows, cfg.cols, self._sched_for(None), count=self.live_count,
+                                   timers=self.kernel_timers)
+        return self.tail_fast(z)
+
+    def tail_exact(self, z):
+        """The cls-row tail as five float32 launches (csrc/azk_nnx.hip k_gemm_x), each honouring the device-side live count
+        (nn.py:54-60, 78-83 for the row the heads read)."""
+        import azk
+        cfg, e = self.cfg, self._exact
+        n, A, D, H = z.shape[0], cfg.action_dim, cfg.embed_dim, cfg.num_heads
+        dev, cnt = z.device, self.live_count
+        key = ("x", id(self.leaf_source) if self.leaf_source is not None else None)
+        ws = self._tail_ws.get(key)
+        if ws is None or ws["rows"] < n:
+            rows = n if ws is None else max(n, 2 * ws["rows"])
+            if ws is not None:
+                self._tail_ws_retired.append(ws)                 # never freed: captured graphs may hold these addresses
+            f32 = dict(dtype=torch.float32, device=dev)
+            ws = dict(rows=rows, u=torch.empty((rows, D), **f32), x1=torch.empty((rows, D), **f32), hh=torch.empty((rows, 4 * D), **f32),
+                      x2=torch.empty((rows, D), **f32), st1=torch.empty((rows, D // 64, 2), **f32), st2=torch.empty((rows, D // 64, 2), **f32))
+            self._tail_ws[key] = ws
+        ws = {k_: (v[:n] if k_ != "rows" else v) for k_, v in ws.items()}
+        azk.nnx_gemm(z.view(n, H * D), e["WvX"], D // H, D, azk.TAIL_BF16, nbatch=H, a_batch_stride=D, out=ws["u"], count=cnt)
+        azk.nnx_gemm(ws["u"], e["WoX"], D, D, azk.TAIL_BF16, bias=e["bias1"], out=ws["x1"], stats_out=ws["st1"], count=cnt)
+        azk.nnx_gemm(ws["x1"], e["W0GX"], 4 * D, D, azk.TAIL_GELU, bias=e["b0G"], out=ws["hh"], a_stats=ws["st1"], count=cnt)
+        azk.nnx_gemm(ws["hh"], e["W3X"], D, 4 * D, azk.TAIL_RESID, bias=e["b3"], resid=ws["x1"], out=ws["x2"], stats_out=ws["st2"], count=cnt)
+        if self.out_buffers is not None:
+            lb, vb = self.out_buffers
+        else:
+            lb = torch.empty((n, A), dtype=torch.float32, device=dev)
+            vb = torch.empty(n, dtype=torch.float32, device=dev)
+        azk.nnx_gemm(ws["x2"], e["WhGX"], 256, D, azk.TAIL_HEADS, bias=e["bhG"], a_stats=ws["st2"], logits=lb, values=vb, action_dim=A, count=cnt)
+        return lb, (vb if self.out_buffers is not None else vb[:, None])
 
     def _prepare_folded(self):
         """Operands of the folded cls-row attention of the LAST block (csrc/azk_nn.hip k_cls_attn):
@@ -412,6 +583,8 @@ class PolicyValueNet:
         return out
 
     def _tail_fast(self, z):
+        if z.dtype == torch.float32:
+            return self.tail_exact(z)
         if getattr(self, "chain_tail", False) and self.use_chain_tail:
             return self.tail_chain(z)
         if self.hip_tail and self.use_hip_tail:
@@ -597,6 +770,8 @@ class PolicyValueNet:
         x = x.to(self.device)
         self.last_value_pre_tanh = False     # set by the one path that hands back the raw value column (fast_outputs)
         depth = self.cfg.depth
+        if path == "clsfold" and self._exact is not None:
+            return self.forward_exact(x)
         if path == "clsfold":
             if self._fold is None:
                 raise RuntimeError("path 'clsfold' needs the HIP kernels (CUDA, bf16, supported embed_dim/heads)")

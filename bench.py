@@ -39,7 +39,8 @@ for p in (ROOT, os.path.join(ROOT, "alpha-zero_amd"), os.path.join(ROOT, "tests"
     if p not in sys.path:
         sys.path.insert(0, p)
 
-MFMA_BF16_PEAK_TFLOPS = 2500.0      # dense bf16 MFMA peak, MI355X_MICROARCH.md
+MFMA_BF16_PEAK_TFLOPS = 2500.0      # dense bf16 / fp16 MFMA peak, MI355X_MICROARCH.md
+MFMA_F32_PEAK_TFLOPS = 157.3        # f32-input MFMA (v_mfma_f32_16x16x4_f32) = the fp32 vector rate, MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 BF16_PEAK_TFLOPS = 2500.0      # dense bf16 MFMA
 
@@ -180,10 +181,12 @@ def main():
     ap.add_argument("--games", type=int, default=2048, help="concurrent games per GPU")
     ap.add_argument("--sims", type=int, default=800)
     ap.add_argument("--size", type=int, default=15)
-    ap.add_argument("--nn-path", default=None, choices=["clsfold", "cls", "full"], help="default: clsfold (bf16) / cls (fp32)")
+    ap.add_argument("--nn-path", default=None, choices=["clsfold", "cls", "full"],
+                    help="default: clsfold (hand-written kernels: azk_nn.hip for bf16, the fp32-accurate azk_nnx.hip for fp32); cls / full = torch library forward")
     ap.add_argument("--nn-dtype", default="bf16", choices=["bf16", "fp32"],
-                    help="fp32: the reference's own arithmetic (torch fp32 GEMMs) - the evaluator whose visit-count policies equal the "
-                         "reference's to the last visit; bf16 (default, north_star's MFMA bf16): the hand-written kernels")
+                    help="bf16 (default, north_star's MFMA bf16): the hand-written bf16 kernels; fp32: the hand-written fp32-accurate kernels "
+                         "(fp16 hi/lo conv on the 0/1 board, v_mfma_f32_16x16x4_f32 elsewhere) - the evaluator whose visit-count policies "
+                         "equal the reference's float32 network's to the last visit")
     ap.add_argument("--tail", default="chain", choices=["chain", "library"],
                     help="cls-row tail: the all-hand-written GEMM chain (azk_nn_tail_gemm: honours the live leaf count; default) or "
                          "hipBLASLt GEMMs + the hand-written LN / heads kernels (always runs the full 2048-row buffer)")
@@ -212,7 +215,7 @@ def main():
                          "all-reduced over RCCL) after every move, fed from the device-resident replay ring")
     args = ap.parse_args()
     if args.nn_path is None:
-        args.nn_path = "clsfold" if args.nn_dtype == "bf16" else "cls"
+        args.nn_path = "clsfold"
 
     if args.cpu_worker > 0:              # child of cpu_baseline's all-cores leg: CPU only, prints one JSON line
         sims, evals, hits, moves, dt = cpu_port_sample(args.sims, args.cpu_worker, 1)
@@ -263,7 +266,9 @@ def main():
         net = PolicyValueNet(cfg, seed=0, device=f"cuda:{local_rank}", dtype=nn_torch_dtype, path=args.nn_path)
         net.use_chain_tail = args.tail == "chain"
         kt = KernelTimer(stride=args.timer_stride)
-        ep_stats = net._compact.enable_work_stats() if getattr(net, "_compact", None) is not None else None   # boards / 16-token tiles evaluated
+        exact = getattr(net, "_exact", None) is not None and args.nn_path == "clsfold"      # fp32: the hand-written fp32-accurate kernels (csrc/azk_nnx.hip)
+        ep_tables = net._exact["tables"] if exact else getattr(net, "_compact", None)
+        ep_stats = ep_tables.enable_work_stats() if ep_tables is not None else None   # device counters: boards / 16-token tiles evaluated
         if args.train_step:
             from azk import DeviceReplay
             from trainer import Trainer
@@ -395,14 +400,20 @@ def main():
                 ep_traffic = next(v["bytes_per_launch"] for k_, v in pmc.items() if k_.startswith("k_embed_pool"))
             except Exception:
                 pass
-            compact = getattr(net, "_compact", None) is not None and getattr(net, "use_compact", False)
+            compact = exact or (getattr(net, "_compact", None) is not None and getattr(net, "use_compact", False))
             executed_share = None
             if compact and ep_stats is not None:
                 # share of the 16-token tiles the compacting kernel really evaluated IN THIS RUN (device counters of the kernel itself)
                 eb, et = (int(v) for v in ep_stats.tolist())
                 executed_share = et / max(1, eb) / ((T_tok + 15) // 16)
-            kernels.append({"kernel": "k_embed_pool_c" if compact else "k_embed_pool", "bound": "mfma", "achieved": fl / (ms * 1e-3) / 1e12,
-                            "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fl / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, "avg_launch_us": ms * 1e3,
+            ep_peak = MFMA_BF16_PEAK_TFLOPS
+            if exact:
+                # two matrix pipes rates in one kernel: conv / score columns on the fp16 pipe (weights as hi + lo: two MFMAs per product),
+                # the weighted token sum on v_mfma_f32_16x16x4_f32.  peak = the blended rate at which the algorithmic flops could issue
+                pool_fl = 2 * T_tok * cfg.num_heads * Dm
+                ep_peak = per_board / ((per_board - pool_fl) / MFMA_BF16_PEAK_TFLOPS + pool_fl / MFMA_F32_PEAK_TFLOPS)
+            kernels.append({"kernel": "k_embed_pool_x" if exact else ("k_embed_pool_c" if compact else "k_embed_pool"), "bound": "mfma", "achieved": fl / (ms * 1e-3) / 1e12,
+                            "peak": ep_peak, "unit": "TFLOP/s", "frac": fl / (ms * 1e-3) / 1e12 / ep_peak, "avg_launch_us": ms * 1e3,
                             "algorithmic_flops_per_launch": fl, "traffic": ep_traffic,
                             "traffic_source": traffic_src if ep_traffic else None, "event_samples": len(ch.pairs),
                             "executed_share_of_algorithmic_flops": executed_share if compact else 1.0,
@@ -416,19 +427,20 @@ def main():
             Hh, dh = cfg.num_heads, Dm // cfg.num_heads
             # value projection per head + output projection + MLP up + MLP down + merged heads, per row
             per_row = 2 * Hh * dh * Dm + 2 * Dm * Dm + 2 * 2 * Dm * 4 * Dm + 2 * Dm * (cfg.action_dim + 1)
-            rows = live if args.tail == "chain" else args.games * runner.leaves_per_step
+            rows = live if (args.tail == "chain" or exact) else args.games * runner.leaves_per_step
             fl = per_row * rows
-            kernels.append({"kernel": "k_tail_gemm x5 (cls-row tail)" if args.tail == "chain" else "library tail", "bound": "mfma",
-                            "achieved": fl / (ms * 1e-3) / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                            "frac": fl / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, "avg_launch_us": ms * 1e3,
+            tail_peak = MFMA_F32_PEAK_TFLOPS if exact else MFMA_BF16_PEAK_TFLOPS
+            kernels.append({"kernel": "k_gemm_x x5 (cls-row tail, f32 MFMA)" if exact else ("k_tail_gemm x5 (cls-row tail)" if args.tail == "chain" else "library tail"), "bound": "mfma",
+                            "achieved": fl / (ms * 1e-3) / 1e12, "peak": tail_peak, "unit": "TFLOP/s",
+                            "frac": fl / (ms * 1e-3) / 1e12 / tail_peak, "avg_launch_us": ms * 1e3,
                             "algorithmic_flops_per_launch": fl, "traffic": None, "event_samples": len(ch.pairs),
                             "note": f"{per_row} flop per row x {rows:.0f} rows per step; avg_launch_us = the whole tail (all of its launches, HIP events "
                                     "around them); the per-launch split is in the rocprofv3 summary under profiles/"})
-        dominant = max((k for k in kernels if not k["kernel"].startswith(("k_tail_gemm x5", "library tail"))), key=lambda k: k["avg_launch_us"]) if kernels else None
+        dominant = max((k for k in kernels if not k["kernel"].startswith(("k_tail_gemm x5", "library tail", "k_gemm_x x5"))), key=lambda k: k["avg_launch_us"]) if kernels else None
         flops = {"cls": cfg.flops_cls(), "full": cfg.flops_full(), "clsfold": flops_clsfold(cfg)}[args.nn_path]
         # Boards the network really processed: eager stepping and the hand-written tail chain honour the live leaf count; only the
         # library tail (--tail library) runs the whole fixed-size leaf buffer every step.
-        chain = args.tail == "chain" and getattr(net, "chain_tail", False) and args.nn_path == "clsfold"
+        chain = (exact or (args.tail == "chain" and getattr(net, "chain_tail", False))) and args.nn_path == "clsfold"
         full_buffer_rows = sims_all * runner.leaves_per_step
         evals = leaves_all if (args.no_graph or chain) else full_buffer_rows
         nn_flop_alg = evals * flops                     # algorithmic flops of the function on the boards processed

@@ -405,6 +405,49 @@ int32_t azk_nn_heads_finalize_sum(const float *partials_dev, int32_t nsplit, int
                                   int32_t action_dim, int32_t n, float *logits_out_dev, float *values_out_dev,
                                   const int32_t *n_valid_dev, void *stream);
 
+/* ---- fp32-accurate network path (csrc/azk_nnx.hip): the reference evaluates its network in float32 (ai/nn.py:74-84 called at
+ * ai/mcts.py:46), and north_star asks for visit-count policies within 1e-5 of it.  The same two stages as above - boards -> pooled
+ * tokens (azk_nn_embed_pool_compact's function) -> cls-row tail (azk_nn_tail_gemm's function) - in arithmetic that keeps float32
+ * accuracy end to end: the 0/1 board against the conv weight (and the folded score / mean columns) split into two fp16 terms
+ * (exact products, float32 accumulation on v_mfma_f32_16x16x32_f16), everything with two run-time operands on v_mfma_f32_16x16x4_f32,
+ * statistics / softmax / GELU(erf) / tanh in float32.  Tables as azk_embed_pool_consts, all float32, with
+ *   wt_frag     fp16 [33 column tiles][kp/32][2: hi, lo][64 lanes][8]: element [ct][s][p][l][i] = the p-th fp16 term of
+ *               wt_scale * wt_ext[col(ct, l)][32 s + 8 (l>>4) + i], col(ct, l) = 64 (ct>>2) + 4 (l&15) + (ct&3) for ct < 32, 512 + (l&15) for ct = 32
+ *   z_all       f32 [8][4][64][4]: sum_t wconst[t][h] * xnconst[t][col] at [w][q][lane][j]: h = 4 (lane>>4) + j, col = 64 w + 4 (lane&15) + q
+ * kp <= 64 (the hi / lo image must fit one CU's LDS), tokens <= 256.  z_out float32 [n][H][512]. */
+typedef struct azk_embed_pool_x_consts {
+    const void *wt_frag;
+    const float *cpos_tok, *score_tok, *wconst_tok, *xnconst_tok;
+    const float *z_all, *l_all, *score_msum, *score_ref;
+    int32_t num_heads, ksize, kp, embed_dim;
+    float ln_eps, wt_scale;
+    uint64_t *work_stats;   /* optional device uint64 [2]: += boards evaluated, += 16-token tiles evaluated */
+} azk_embed_pool_x_consts;
+int32_t azk_nnx_embed_pool(const void *boards_dev, int32_t boards_are_f32, const azk_embed_pool_x_consts *consts,
+                           float *z_out_f32_dev, int32_t n, int32_t channels, int32_t rows, int32_t cols,
+                           const int32_t *n_valid_dev, int32_t *sched_dev, void *stream);
+int32_t azk_nnx_embed_pool_leaves(const azk_leaf_source *src, const azk_embed_pool_x_consts *consts, float *z_out_f32_dev,
+                                  int32_t *sched_dev, void *stream);
+/* azk_nnx_gemm - azk_nn_tail_gemm in float32: a_f32 [m][lda], out_f32 / resid_f32 float32, w_packed = nbatch consecutive nn.Linear
+ * weights [n_out][k] as float32 in fragment order Wp[n_out/64][k/16][4][64 lanes][4]: element [g][s][c][lane][i] =
+ * W[64 g + 4 (lane&15) + c][16 s + 4 (lane>>4) + i].  k = 512 or 2048.  layernorm_a (k = 512): a_stats [m][8][2] as left by the producing
+ * call's stats_out.  Epilogues 0-3 as azk_nn_tail_gemm (GELU = exact erf form via erff). */
+typedef struct azk_gemm_x {
+    const float *a_f32; int32_t lda, a_batch_stride;
+    const float *w_packed;
+    int32_t m, n_out, k, nbatch;
+    const int32_t *n_valid;
+    const float *bias;
+    int32_t layernorm_a, epilogue;
+    float ln_eps;
+    const float *a_stats;
+    float *stats_out;
+    float *out_f32; int32_t ldo;
+    const float *resid_f32; int32_t ldr;
+    float *logits_out, *values_out; int32_t action_dim;
+} azk_gemm_x;
+int32_t azk_nnx_gemm(const azk_gemm_x *desc, void *stream);
+
 /* ---- vanilla mode: MCTS.mcts(model=None, ...) (mcts.py:57-59), MCTS.simulate (mcts.py:62-79), UCB1 of
  * utils.py:29-44 mode 'normal'.  A search is azk_begin_search(e, NULL) followed by azk_vanilla_search calls summing to
  * n simulations (each launch runs its simulations - select, expand, random rollout, backup - entirely on the device);

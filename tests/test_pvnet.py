@@ -55,3 +55,27 @@ def test_bad_state_dict_is_rejected():
     w.pop("norm.bias")
     with pytest.raises(KeyError):
         PolicyValueNet(cfg, w)
+
+
+def test_exact_fold_is_the_same_function():
+    """The float64 fold behind the fp32-accurate HIP path (pvnet.exact_fold: cls query through W_k, LayerNorm affines into the
+    weights, constant-token softmax terms, Z = ZALL + sum over dirty tokens) evaluated step by step in float64 torch against the
+    reference's seed-0 outputs (nn_small.npz full_*) and against the plain forward on boards with 0 .. 112 stones per side."""
+    cfg = NetConfig(15, 15, 2, 225, patch_size=5, embed_dim=512, num_heads=8, depth=1)
+    net = PolicyValueNet(cfg, seed=0, path="full")
+    x = torch.from_numpy(Z["full_x"])
+    le, ve, _ = net.forward_exact_emulated(x)
+    np.testing.assert_allclose(le.numpy(), Z["full_logits"], rtol=0, atol=5e-6)
+    np.testing.assert_allclose(ve.numpy(), Z["full_value"], rtol=0, atol=2e-6)
+    rng = np.random.RandomState(1)
+    xb = torch.zeros(6, 2, 15, 15)
+    for b, n in enumerate([0, 1, 5, 20, 60, 112]):
+        cells = rng.choice(225, size=2 * n, replace=False)
+        xb[b, 0].view(-1)[cells[:n]] = 1
+        xb[b, 1].view(-1)[cells[n:]] = 1
+    lf, vf = net(xb)
+    le, ve, _ = net.forward_exact_emulated(xb)
+    assert (lf - le).abs().max().item() < 5e-6 and (vf - ve).abs().max().item() < 2e-6
+    # configurations the fold does not cover are refused, not approximated
+    assert PolicyValueNet(NetConfig(15, 15, 2, 225, 5, 512, 8, 2), seed=0).exact_fold() is None
+    assert PolicyValueNet(NetConfig(7, 7, 2, 49, 5, 32, 4, 1), seed=0).exact_fold() is None

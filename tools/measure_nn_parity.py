@@ -3,7 +3,8 @@ reference's fp32 network?  (north_star: "within 1e-5 on visi
   1. logits / value of every evaluator path against the reference's seed-0 known answers (tests/golden/nn_small.npz 'full_*');
   2. 800-simulation searches from the positions of the reference's recorded 15x15 games, same Dirichlet noise, evaluator =
      the seed-0 network in (a) fp32 'full' (the reference's own arithmetic), (b) fp32 'cls' (same function, different
-     summation order: the sensitivity floor), (c) bf16 'clsfold' (the benched path): max |delta pi|, total variation, share of
+     summation order: the sensitivity floor), (c) fp32 'clsfold' (the hand-written fp32-accurate kernels, csrc/azk_nnx.hip),
+     (d) bf16 'clsfold' (the benched path): max |delta pi|, total variation, share of
      positions whose most-visited move changes.
 usage: measure_nn_parity.py [n_sims]      -> one JSON line"""
 import json
@@ -55,7 +56,9 @@ def main():
             "fp32_cls": PolicyValueNet(cfg, seed=0, device="cuda", dtype=torch.float32, path="cls"),
             "bf16_full": PolicyValueNet(cfg, seed=0, device="cuda", dtype=torch.bfloat16, path="full"),
             "bf16_cls": PolicyValueNet(cfg, seed=0, device="cuda", dtype=torch.bfloat16, path="cls"),
-            "bf16_clsfold": PolicyValueNet(cfg, seed=0, device="cuda", dtype=torch.bfloat16, path="clsfold")}
+            "bf16_clsfold": PolicyValueNet(cfg, seed=0, device="cuda", dtype=torch.bfloat16, path="clsfold"),
+            "fp32_clsfold": PolicyValueNet(cfg, seed=0, device="cuda", dtype=torch.float32, path="clsfold")}     # hand-written fp32-accurate kernels (azk_nnx.hip)
+    assert nets["fp32_clsfold"]._exact is not None
     kat = {}
     for name, net in nets.items():
         logits, v = net(x.to(net.dtype))
@@ -77,6 +80,8 @@ def main():
     xb = torch.from_numpy(xb).cuda()
     l32, v32 = nets["fp32_full"](xb)
     l16, v16 = nets["bf16_clsfold"](xb.to(torch.bfloat16))
+    lx, vx = nets["fp32_clsfold"](xb)
+    wide_x = {"boards": 256, "logits_max_abs": float((lx - l32).abs().max()), "value_max_abs": float((vx.reshape(-1) - v32.reshape(-1)).abs().max())}
     wide = {"boards": 256, "logits_max_abs": float((l16 - l32).abs().max()), "logits_mean_abs": float((l16 - l32).abs().mean()),
             "logits_std_of_reference": float(l32.std()), "value_max_abs": float((v16.reshape(-1) - v32.reshape(-1)).abs().max()),
             "policy_tv_max": float(0.5 * (torch.softmax(l16, 1) - torch.softmax(l32, 1)).abs().sum(1).max())}
@@ -85,7 +90,7 @@ def main():
     G = len(positions)
     noise = torch.from_numpy(np.random.RandomState(7).dirichlet([0.03] * 225, size=G)).cuda()
     pis = {}
-    for name, dt in (("fp32_full", "float32"), ("fp32_cls", "float32"), ("bf16_clsfold", "bfloat16")):
+    for name, dt in (("fp32_full", "float32"), ("fp32_cls", "float32"), ("fp32_clsfold", "float32"), ("bf16_clsfold", "bfloat16")):
         pis[name] = search_pis(nets[name], dt, positions, n_sims, noise)
     again = search_pis(nets["bf16_clsfold"], "bfloat16", positions, n_sims, noise)
     ref_pi, ref_q = pis["fp32_full"]
@@ -97,8 +102,8 @@ def main():
                 "tv_mean": float(0.5 * d.sum(1).mean()), "tv_max": float(0.5 * d.sum(1).max()),
                 "argmax_changed_share": float((pi.argmax(1) != ref_pi.argmax(1)).mean()),
                 "positions_with_identical_pi": int((d.max(1) == 0).sum()), "max_abs_dq": float(np.abs(q - ref_q).max())}
-    out = {"n_sims": n_sims, "positions": G, "kat_vs_reference_seed0": kat, "clsfold_vs_fp32_full_on_256_boards": wide,
-           "search_vs_fp32_full": {"fp32_cls": dev("fp32_cls"), "bf16_clsfold": dev("bf16_clsfold")},
+    out = {"n_sims": n_sims, "positions": G, "kat_vs_reference_seed0": kat, "clsfold_vs_fp32_full_on_256_boards": wide, "fp32_clsfold_vs_fp32_full_on_256_boards": wide_x,
+           "search_vs_fp32_full": {"fp32_cls": dev("fp32_cls"), "fp32_clsfold": dev("fp32_clsfold"), "bf16_clsfold": dev("bf16_clsfold")},
            "bf16_clsfold_rerun_identical": bool(np.array_equal(again[0], pis["bf16_clsfold"][0]))}
     print(json.dumps(out))
 
