@@ -147,7 +147,7 @@ __device__ __forceinline__ void backup_path(const Dev &d, size_t base, const int
     for (int i = azk_lane(); i <= depth; i += AZK_WAVE) {
         int nd = path[i];
         double sv = ((depth - i) & 1) ? -value : value;
-        if (undo_virtual_loss) { d.W[base + nd] += sv + 1.0; continue; }      // the visit was counted at selection
+        if (undo_virtual_loss) { d.W[base + nd] = (d.W[base + nd] + sv) + 1.0; continue; }      // the visit was counted at selection (same association as the short-path form)
         d.N[base + nd] += 1;
         d.W[base + nd] += sv;
     }

@@ -1283,6 +1283,7 @@ __global__ __launch_bounds__(256, 2) void k_embed_pool_c(EmbedPoolCArgs a) {
     long long nt_acc = 0, nb_acc = 0;
 #define AZK_STAMP(i) do { } while (0)
 #endif
+    int ws_boards = 0, ws_tiles = 0;
     if (board >= nvalid) __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): no LDS-DMA may outlive the workgroup
     if (board < nvalid) {                                         // (workgroups without a board go straight to the sign-off below)
     union BF { uint4 u; bf16x8 v; };
@@ -1451,7 +1452,8 @@ __global__ __launch_bounds__(256, 2) void k_embed_pool_c(EmbedPoolCArgs a) {
 
         AZK_STAMP(2);                                             // patch bits + compaction
         if (stamp) nt_acc += ntile;
-        if (a.wstats != nullptr && tid == 0) { atomicAdd(a.wstats, 1ull); atomicAdd(a.wstats + 1, (unsigned long long)ntile); }
+        ws_boards += 1; ws_tiles += ntile;                  // (uniform; one pair of atomics per workgroup at the very end: an atomic here sits in
+                                                            //  the vmcnt queue in front of the tile's gathers, which wait for it - measured +7 us per launch)
         float L = 0.f;                                    // per head (lane&15 < NH): this lane>>4 group's share of sum (w - wc)
         // The per-token constants are GATHERED (by token index, L2) and every tile would wait a full round trip for them, so they
         // run one phase ahead: the conv MFMAs start from zero and the constants are added behind them; the registers they leave
@@ -1604,6 +1606,7 @@ __global__ __launch_bounds__(256, 2) void k_embed_pool_c(EmbedPoolCArgs a) {
         if (stamp) nb_acc += 1;
     }
     }
+    if (a.wstats != nullptr && tid == 0 && ws_boards) { atomicAdd(a.wstats, (unsigned long long)ws_boards); atomicAdd(a.wstats + 1, (unsigned long long)ws_tiles); }
 #undef AZK_STAMP
 #ifdef AZK_EP_STAMPS
     if (stamp) {

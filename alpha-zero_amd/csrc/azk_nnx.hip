@@ -167,6 +167,7 @@ __global__ __launch_bounds__(512, 2) void k_embed_pool_x(EmbedPoolXArgs a) {
         nvalid = a.count ? min(a.n, *a.count) : a.n;
     }
     int board = blockIdx.x;
+    int ws_boards = 0, ws_tiles = 0;
     if (board >= nvalid) __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): no LDS-DMA may outlive the workgroup
     if (board < nvalid) {
     union BF { uint4 u; f16x8 v; };
@@ -323,7 +324,7 @@ __global__ __launch_bounds__(512, 2) void k_embed_pool_x(EmbedPoolXArgs a) {
         }
         if (tid < 16 && nd + tid < ntile * 16) { dlist[nd + tid] = T; pbits[nd + tid] = make_uint4(0u, 0u, 0u, 0u); }   // null tokens fill the last tile
         __syncthreads();
-        if (a.wstats != nullptr && tid == 0) { atomicAdd(a.wstats, 1ull); atomicAdd(a.wstats + 1, (unsigned long long)ntile); }
+        ws_boards += 1; ws_tiles += ntile;                  // (one pair of atomics per workgroup at the very end, never in front of the gathers)
 
         float L = 0.f;
         // the per-token constants are gathered by token index and run one phase ahead of their use (see k_embed_pool_c)
@@ -458,6 +459,7 @@ __global__ __launch_bounds__(512, 2) void k_embed_pool_x(EmbedPoolXArgs a) {
         board = scan[8];
     }
     }
+    if (a.wstats != nullptr && tid == 0 && ws_boards) { atomicAdd(a.wstats, (unsigned long long)ws_boards); atomicAdd(a.wstats + 1, (unsigned long long)ws_tiles); }
 }
 
 template <int NC, int KSZ, int NH, bool SRC>
@@ -616,6 +618,8 @@ __global__ __launch_bounds__(256, 1) void k_gemm_x(GemmXArgs a) {
         for (int ch = 0; ch < NCH; ch++) {
             const int cur = ch & 1;
             if (ch + 1 < NCH) fetch(cur ^ 1, ch + 1);
+            __builtin_amdgcn_sched_barrier(0);                // the next iteration's loads are ISSUED here (left alone, hipcc sinks every load to
+                                                              // just before its first use and waits for it there: one exposed round trip per k-step)
 #pragma unroll
             for (int s = 0; s < 2; s++) {
                 if (AMODE == 1) {
@@ -631,6 +635,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_x(GemmXArgs a) {
 #pragma unroll
                         for (int c = 0; c < 4; c++) acc[i][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cur][i][s][e], bf[cur][s][c][e], acc[i][c], 0, 0, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (row0 >= nvalid) continue;                          // (uniform per wave tile; with NWK > 1 per workgroup)
         if (NWK > 1) {

@@ -556,6 +556,120 @@ int azo_mcts(const azo_game_t *g, azo_tree_t *t, float *board, int n_iter,
     return 0;
 }
 
+/* ---------------------------------------------------------------------------------------
+ * Virtual-loss expansion: the engine's OPT-IN mode (azk_config.leaves_per_step = K > 1; csrc/azk_engine.hip
+ * k_tree<.., MULTI> with K slots) restated sequentially.  NOT reference behaviour - ai/mcts.py:16-60 is strictly
+ * sequential, north_star asks for "virtual-loss expansion" on top of it - so there is no reference output to pin
+ * this function to: it pins the KERNEL to a plain sequential statement of the schedule, built from the pinned
+ * pieces above (select_child, the rules, the expansion of azo_mcts).
+ *
+ * Schedule.  A search runs "launches"; in a launch the game's K slots take turns k = 0 .. K-1, each:
+ *   1. if the slot holds a pending leaf (selected in an earlier launch): evaluate it, expand it exactly as
+ *      azo_mcts does (mcts.py:46-55) and back its value up along the recorded path.  The visit was counted at
+ *      selection and the path carries a lost game, so the backup is W = (W + value_i) + 1, N unchanged;
+ *   2. if the game has started fewer than n_sims simulations: start one - the PUCT walk of mcts.py:20-23 on the
+ *      tree as it stands (virtual losses of the other slots included).  A walk that ends on a node whose
+ *      expansion is pending (first_child == -2) gives up and does not count.  A terminal leaf (mcts.py:25-32) is
+ *      backed up at once, normally.  Otherwise the leaf becomes the slot's pending leaf: every node of the path
+ *      gets N += 1, W -= 1 (a visit and a lost game) and the leaf is marked first_child = -2.
+ * The search ends after the launch in which n_sims simulations have been started and no slot is pending.
+ * Returns the number of launches, or < 0 on callback failure.
+ * ------------------------------------------------------------------------------------- */
+typedef struct {
+    int node, depth, nv, player;
+    int trace[AZO_MAX_CELLS + 2], moves[AZO_MAX_CELLS];
+    float canon[3 * AZO_MAX_CELLS];
+} azo_vl_slot_t;
+
+int azo_mcts_vl(const azo_game_t *g, azo_tree_t *t, float *board, int n_sims, int K,
+                azo_eval_fn eval, void *ectx, const double *noise, azo_cache_t *cache, azo_counters_t *cnt) {
+    if (K < 1 || K > 64 || !eval) return -1;
+    azo_vl_slot_t *slots = calloc((size_t)K, sizeof *slots);
+    float priors[AZO_MAX_CELLS];
+    int started = 0, launches = 0, rc = 0;
+    for (int k = 0; k < K; k++) slots[k].node = -1;
+    for (;;) {
+        launches++;
+        for (int k = 0; k < K && rc == 0; k++) {
+            azo_vl_slot_t *s = &slots[k];
+            if (s->node >= 0) {                                            /* 1. expand + backup of the pending leaf */
+                float value;
+                int hit = 0;
+                if (cache) {
+                    long e = cache_find(cache, (const uint8_t *)s->canon, &hit);
+                    if (hit) { memcpy(priors, cache->priors + (size_t)e * g->action_dim, sizeof(float) * g->action_dim); value = cache->values[e]; if (cnt) cnt->matched++; }
+                }
+                if (!hit) {
+                    if (eval(ectx, s->canon, priors, &value) != 0) { rc = -2; break; }
+                    if (cnt) cnt->evals++;
+                    if (cache) cache_put(cache, (const uint8_t *)s->canon, priors, value);
+                }
+                int nv = s->nv, node = s->node;
+                tree_grow(t, t->n_nodes + nv);
+                int fc = t->n_nodes, mix = s->depth == 0 && noise != NULL;
+                if (s->depth == 0) t->root_prior_f64 = mix;
+                for (int i = 0; i < nv; i++) {                             /* Node.expand: node.py:50-59 */
+                    int a = azo_action_idx(g, s->moves[i]);
+                    double p = mix ? (double)(0.75f * priors[a]) + 0.25 * noise[a] : (double)priors[a];
+                    t->N[fc + i] = 0; t->W[fc + i] = 0.0; t->P[fc + i] = p; t->cell[fc + i] = (int16_t)s->moves[i];
+                    t->first_child[fc + i] = -1; t->n_children[fc + i] = 0;
+                }
+                t->first_child[node] = fc; t->n_children[node] = nv; t->n_nodes += nv;
+                if (cnt) { cnt->edges_created += nv; cnt->expansions++; cnt->trace_nodes += s->depth + 1; }
+                const double v = -(double)value;                           /* mcts.py:56 */
+                for (int i = 0; i <= s->depth; i++) {
+                    const double sv = ((s->depth - i) & 1) ? -v : v;
+                    t->W[s->trace[i]] = (t->W[s->trace[i]] + sv) + 1.0;    /* the visit was counted at selection */
+                }
+                s->node = -1;
+            }
+            if (started >= n_sims) continue;                               /* 2. a new simulation */
+            started++;
+            int node = 0, depth = 0, trace[AZO_MAX_CELLS + 2];
+            trace[0] = 0;
+            while (t->n_children[node] > 0) {                              /* mcts.py:20-23 */
+                if (cnt) cnt->edges_scanned += t->n_children[node];
+                int child = select_child(t, node, 1);
+                int mover = (t->root_player + depth) & 1;
+                node = child; depth++; trace[depth] = node;
+                azo_make_move(g, board, mover, t->cell[node]);
+            }
+            const int node_player = (t->root_player + depth) & 1, node_mc = t->root_move_count + depth;
+            int keep = 0;
+            if (t->first_child[node] == -2) {
+                started--;                                                 /* expansion pending in another slot: no simulation */
+            } else {
+                if (cnt) cnt->mcts_count++;
+                int term = -1;
+                if (depth > 0) {                                           /* mcts.py:25-32 */
+                    if (azo_check_winner(g, board, 1 - node_player, t->cell[node]) != -1) term = 1;
+                    else if (node_mc == g->state_dim) term = 0;
+                }
+                if (term >= 0) {
+                    if (cnt) { cnt->terminal_sims++; cnt->trace_nodes += depth + 1; }
+                    double value = (double)term;
+                    for (int i = depth; i >= 0; i--) { t->N[trace[i]] += 1; t->W[trace[i]] += value; value = -value; }
+                } else keep = 1;
+            }
+            if (keep) {
+                s->nv = azo_get_valid_moves(g, board, s->moves);           /* mcts.py:34 */
+                azo_canonical_board(g, board, node_player, s->canon);      /* mcts.py:37 */
+                for (int i = 0; i <= depth; i++) { t->N[trace[i]] += 1; t->W[trace[i]] -= 1.0; s->trace[i] = trace[i]; }
+                t->first_child[node] = -2;
+                s->node = node; s->depth = depth; s->player = node_player;
+            }
+            for (int i = depth; i > 0; i--) azo_undo_move(g, board, (t->root_player + i) & 1, t->cell[trace[i]]);   /* the caller's board comes back as it was */
+        }
+        if (rc != 0) break;
+        int pending = 0;
+        for (int k = 0; k < K; k++) pending |= slots[k].node >= 0;
+        if (started >= n_sims && !pending) break;
+        if (launches > 4 * n_sims + 16) { rc = -3; break; }                /* cannot happen: every launch starts or finishes a simulation */
+    }
+    free(slots);
+    return rc != 0 ? rc : launches;
+}
+
 /* accessors */
 int azo_tree_n_nodes(const azo_tree_t *t) { return t->n_nodes; }
 long long azo_tree_root_visit(const azo_tree_t *t) { return t->N[0]; }

@@ -77,6 +77,7 @@ def lib():
         L.azo_cache_size.argtypes = [C.c_void_p]
         L.azo_mcts.argtypes = [P(_GameT), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                C.c_void_p, C.c_void_p, C.c_void_p, P(Counters)]
+        L.azo_mcts_vl.argtypes = [P(_GameT), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, P(Counters)]
         L.azo_tree_n_nodes.argtypes = [C.c_void_p]
         L.azo_tree_root_visit.argtypes = [C.c_void_p]
         L.azo_tree_root_visit.restype = C.c_longlong
@@ -274,6 +275,37 @@ def mcts(game, tree, board, n_iter, evaluator=None, noise=None, cache=None, rand
         raise err[0]
     if rc != 0:
         raise RuntimeError(f"azo_mcts failed: {rc}")
+
+
+def mcts_vl(game, tree, board, n_sims, K, evaluator, noise=None, cache=None, counters=None):
+    """The engine's OPT-IN virtual-loss mode (leaves_per_step = K > 1) restated sequentially (azo_mcts_vl): K pending leaves per
+    game, a visit and a lost game on a selected path until the leaf's value arrives.  Not reference behaviour (ai/mcts.py:16-60
+    is sequential): this pins the HIP kernel's K-slot schedule to a plain statement of it.  Returns the number of launches."""
+    shape = (game.planes, game.rows, game.cols)
+    err = []
+
+    def _eval(ctx, canon_p, pri_p, val_p):
+        try:
+            canon = np.ctypeslib.as_array(canon_p, shape=shape)
+            pri, v = evaluator(canon)
+            np.ctypeslib.as_array(pri_p, shape=(game.action_dim,))[:] = np.asarray(pri, np.float32)
+            val_p[0] = float(v)
+            return 0
+        except Exception as e:  # never raise across the C frame
+            err.append(e)
+            return -1
+
+    ecb = EVAL_FN(_eval)
+    assert board.dtype == np.float32 and board.flags.c_contiguous
+    nz = np.ascontiguousarray(noise, np.float64) if noise is not None else None
+    rc = lib().azo_mcts_vl(C.byref(game.g), tree.h, _ptr(board), int(n_sims), int(K), C.cast(ecb, C.c_void_p), None,
+                           _ptr(nz) if nz is not None else None, cache.h if cache is not None else None,
+                           C.byref(counters) if counters is not None else None)
+    if err:
+        raise err[0]
+    if rc < 0:
+        raise RuntimeError(f"azo_mcts_vl failed: {rc}")
+    return rc
 
 
 def self_play(game, evaluator, n_sims, noise_fn=None, uniform_fn=None, cache=None, randint=None,

@@ -1,7 +1,8 @@
 """OPT-IN virtual-loss expansion (north_star: "virtual-loss expansion"): K leaves in flight per game.  A
 selection leaves a visit and a lost game on its path until the leaf's value is backed up, so the same game's next selections go
 elsewhere; the evaluator batch holds up to G * K boards per launch.  It is NOT the reference's search (ai/mcts.py:16-60 is strictly
-sequential) - results differ from parity mode by design - so it is tested through its own invariants:
+sequential) - results differ from parity mode by design - so it is pinned to a SEQUENTIAL RESTATEMENT of its schedule in the
+oracle (oracle/az_oracle.c azo_mcts_vl: whole trees bit for bit) and tested through its own invariants:
   K = 1 is the parity mode bit for bit; visit conservation; no virtual loss left behind; legality; determinism."""
 import numpy as np
 import pytest
@@ -77,6 +78,50 @@ def test_invariants_and_k1_is_parity(K, case):
         assert len(set(kids.tolist())) == len(kids)
         eng.close()
     assert digs[0] == digs[1]                                       # deterministic, and the eval cache stays transparent
+
+
+@pytest.mark.parametrize("K", [2, 4])
+def test_trees_equal_the_sequential_statement_of_the_schedule(K):
+    """the K-slot schedule of k_tree<.., MULTI> against its sequential restatement in the oracle
+    (oracle/az_oracle.c azo_mcts_vl: slot k expands its pending leaf, then selects with N += 1, W -= 1 on the path; a walk that
+    ends on a node whose expansion is pending gives up; exactly n_sims simulations) - whole trees, every node (depth, action, N,
+    W, P) bit for bit, on every golden position (three games, with and without root noise, tie-heavy evaluators, near-terminal
+    positions), with the eval cache off and on."""
+    import azk
+    from test_gpu_engine import digest
+    from oracle import az_oracle as ao
+    checked = 0
+    for m in _SMETA:
+        if m["n_sims"] > 400:
+            continue
+        k = f"c{m['case']}_"
+        game = ao.OracleGame(m["game"], m["size"] or None)
+        b, player = game.new_board(), 0
+        for cell in _SZ[k + "actions"]:
+            player = game.make_move(b, player, game.rc(int(cell)))
+        tree = ao.OracleTree(game)
+        tree.reset(player, len(_SZ[k + "actions"]))
+
+        def ev(canon, game=game, m=m):
+            logits, v = fixture_logits_value(torch.from_numpy(np.ascontiguousarray(canon))[None], game.action_dim, m["variant"])
+            return ao.softmax_det(logits[0].numpy()), float(v[0])
+        launches = ao.mcts_vl(game, tree, b, m["n_sims"], K, ev, _SZ[k + "noise"] if m["dirichlet"] else None)
+        want = digest(tree.export())
+        cells = (b[0] + 2 * b[1]).astype(np.int8).reshape(-1)
+        G = 2
+        noise = torch.from_numpy(np.tile(_SZ[k + "noise"], (G, 1))).cuda() if m["dirichlet"] else None
+        for entries in (0, 256):
+            eng = azk.Engine(m["game"], G, m["n_sims"], size=m["size"] or None, leaves_per_step=K, cache_entries=entries)
+            eng.set_positions(np.tile(cells, (G, 1)), [player] * G, [len(_SZ[k + "actions"])] * G)
+            got_launches = eng.search_budget(_ev(game.action_dim, m["variant"]), m["n_sims"], noise)
+            eng.check_error()
+            for g in range(G):
+                assert digest(eng.export_tree(g)) == want, (m["case"], K, entries)
+            if entries == 0:
+                assert got_launches == launches, (m["case"], K, got_launches, launches)
+            eng.close()
+        checked += 1
+    assert checked >= 15
 
 
 def test_whole_games_and_runner():

@@ -99,3 +99,49 @@ def test_det_softmax_tree_matches_numpy_softmax_tree():
         ch = tree.root_children()
         assert ch["visit"].tolist() == _Z[k + "child_visit"].tolist(), m
         np.testing.assert_allclose(ch["prior"], _Z[k + "child_prior"], rtol=1e-6, atol=0)
+
+
+def _vl_tree(m, K, cache=False, counters=None):
+    k = f"c{m['case']}_"
+    game = ao.OracleGame(m["game"], m["size"] or None)
+    board, player = replay_position(game, _Z[k + "actions"])
+    tree = ao.OracleTree(game)
+    tree.reset(player, len(_Z[k + "actions"]))
+    before = board.copy()
+    launches = ao.mcts_vl(game, tree, board, m["n_sims"], K, make_evaluator(game, m["variant"], ao.softmax_det),
+                          _Z[k + "noise"] if m["dirichlet"] else None, ao.OracleCache(game) if cache else None, counters)
+    assert np.array_equal(board, before)                 # the caller's board comes back as it was
+    return tree, launches
+
+
+@pytest.mark.parametrize("K", [2, 4])
+def test_virtual_loss_oracle_invariants(K):
+    """azo_mcts_vl - the sequential statement of the engine's OPT-IN K-slot virtual-loss schedule (not reference behaviour, so
+    nothing of the reference pins it; the HIP kernel is compared with it bit for bit under -m gpu).  Checked here on every golden
+    position: exactly n_sims simulations (root visits), visit conservation (an expanded node was visited once to expand it plus
+    once per visit of a child), no virtual loss left behind (|W| <= N), determinism, the eval cache transparent, fewer launches
+    than simulations, and a different tree than the sequential search (it is a different algorithm)."""
+    differs = 0
+    for m in _META:
+        if m["n_sims"] > 400:
+            continue
+        cnt = ao.Counters()
+        tree, launches = _vl_tree(m, K, counters=cnt)
+        e = tree.export()
+        depth, visit, value = e["depth"], e["visit"], e["value"]
+        assert visit[0] == m["n_sims"] == cnt.mcts_count and cnt.expansions + cnt.terminal_sims == m["n_sims"]
+        child_sum, has_child, stack = np.zeros(len(depth), np.int64), np.zeros(len(depth), bool), []
+        for i, dpt in enumerate(depth):
+            while stack and depth[stack[-1]] >= dpt:
+                stack.pop()
+            if stack:
+                child_sum[stack[-1]] += visit[i]
+                has_child[stack[-1]] = True
+            stack.append(i)
+        assert np.array_equal(visit[has_child], 1 + child_sum[has_child])
+        assert (np.abs(value) <= visit + 1e-9).all()
+        assert m["n_sims"] / K <= launches <= m["n_sims"] + 2
+        assert digest_of(_vl_tree(m, K)[0]) == digest_of(tree)                       # deterministic
+        assert digest_of(_vl_tree(m, K, cache=True)[0]) == digest_of(tree)           # MCTS.cache stays transparent
+        differs += digest_of(tree)[0] != m["digest"]
+    assert differs > 0
