@@ -33,6 +33,7 @@ SYMBOLS = [
     "azk_leaf_source_of", "azk_nn_embed_pool_leaves", "azk_nn_embed_pool_compact", "azk_nn_embed_pool_compact_leaves",
     "azk_nn_tail_gemm", "azk_begin_search_budget", "azk_search_unfinished",
     "azk_nnx_embed_pool", "azk_nnx_embed_pool_leaves", "azk_nnx_gemm",
+    "azk_async_begin", "azk_async_step", "azk_async_drain", "azk_async_set_budget",
 ]
 
 
@@ -88,6 +89,14 @@ class GemmX(C.Structure):
                 ("a_stats", C.c_void_p), ("stats_out", C.c_void_p), ("out_f32", C.c_void_p), ("ldo", C.c_int32),
                 ("resid_f32", C.c_void_p), ("ldr", C.c_int32), ("logits_out", C.c_void_p), ("values_out", C.c_void_p),
                 ("action_dim", C.c_int32)]
+
+
+class AsyncConfig(C.Structure):
+    """azk_async_config (include/azk.h)."""
+    _fields_ = [("n_sims", C.c_int32), ("max_sims_per_launch", C.c_int32), ("sample_until_move", C.c_int32), ("dirichlet", C.c_int32),
+                ("recycle", C.c_int32), ("reserved0", C.c_int32), ("seed", C.c_uint64), ("first_global_game", C.c_int64), ("alpha", C.c_double),
+                ("stats_dev", C.c_void_p), ("record_capacity", C.c_int64), ("rec_meta_dev", C.c_void_p), ("rec_q_dev", C.c_void_p),
+                ("rec_pi_dev", C.c_void_p)]
 
 
 class Counters(C.Structure):
@@ -181,6 +190,10 @@ def lib():
     L.azk_nnx_embed_pool.argtypes = [vp, i32, C.POINTER(EmbedPoolXConsts), vp, i32, i32, i32, i32, vp, vp, vp]
     L.azk_nnx_embed_pool_leaves.argtypes = [C.POINTER(LeafSource), C.POINTER(EmbedPoolXConsts), vp, vp, vp]
     L.azk_nnx_gemm.argtypes = [C.POINTER(GemmX), vp]
+    L.azk_async_begin.argtypes = [vp, C.POINTER(AsyncConfig), vp]
+    L.azk_async_step.argtypes = [vp, vp, vp, i32, vp]
+    L.azk_async_set_budget.argtypes = [vp, i32, i32, vp]
+    L.azk_async_drain.argtypes = [vp, vp, vp, vp, i64, vp, vp]
     L.azk_nn_ln_heads.argtypes = [vp, vp, vp, C.c_float, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]
     L.azk_nn_gemm_rows.argtypes = [vp, i32, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]
     L.azk_nn_layernorm_sum.argtypes = [vp, i32, i32, vp, vp, vp, vp, C.c_float, vp, vp, vp, i32, i32, vp, vp]
@@ -408,6 +421,39 @@ class Engine:
         if self.cache_entries and self.K == 1:
             self.step_expand_backup(self._no_logits, self._no_values)       # leaves served by the cache in the last launch
         return launches
+
+    # ---- asynchronous self-play (azk_async_*) -----------------------------------------------------
+    def async_begin(self, n_sims, per_launch, sample_until, seed, first_global_game, alpha=0.03, dirichlet=True, recycle=True, record_capacity=0):
+        """Every game starts its first search; from now on azk_async_step moves each game as soon as its own search is done.
+        Returns (stats int64 [16] CUDA, records dict or None) - caller-visible tensors the engine writes (include/azk.h)."""
+        torch = self.torch
+        self.async_stats = torch.zeros(16, dtype=torch.int64, device=self.device)
+        rec = None
+        if record_capacity:
+            rec = dict(meta=torch.zeros((record_capacity, 4), dtype=torch.int32, device=self.device),
+                       q=torch.zeros(record_capacity, dtype=torch.float64, device=self.device),
+                       pi=torch.zeros((record_capacity, self.action_dim), dtype=torch.float64, device=self.device))
+        self.async_records = rec
+        c = AsyncConfig()
+        c.n_sims, c.max_sims_per_launch, c.sample_until_move = int(n_sims), int(per_launch), int(min(sample_until, 1 << 30))
+        c.dirichlet, c.recycle, c.seed, c.first_global_game, c.alpha = int(bool(dirichlet)), int(bool(recycle)), int(seed), int(first_global_game), float(alpha)
+        c.stats_dev, c.record_capacity = self.async_stats.data_ptr(), int(record_capacity)
+        if rec is not None:
+            c.rec_meta_dev, c.rec_q_dev, c.rec_pi_dev = rec["meta"].data_ptr(), rec["q"].data_ptr(), rec["pi"].data_ptr()
+        self._chk(self.L.azk_async_begin(self.h, C.byref(c), _stream()))
+        return self.async_stats, rec
+
+    def async_step(self, logits, values, phases=3):
+        self._chk(self.L.azk_async_step(self.h, _p(logits), _p(values), int(phases), _stream()))
+
+    def async_set_budget(self, n_sims, per_launch):
+        self._chk(self.L.azk_async_set_budget(self.h, int(n_sims), int(per_launch), _stream()))
+
+    def async_drain(self, replay=None):
+        if replay is None:
+            self._chk(self.L.azk_async_drain(self.h, None, None, None, 0, None, _stream()))
+        else:
+            self._chk(self.L.azk_async_drain(self.h, _p(replay.states), _p(replay.pis), _p(replay.zs), replay.capacity, _p(replay.cursor), _stream()))
 
     # ---- vanilla mode (model=None) ----------------------------------------------------------------
     def vanilla_set_rng(self, states, first=0):

@@ -961,22 +961,15 @@ __global__ __launch_bounds__(AZK_WAVE) void k_root_stats(Dev d, double *pi, doub
     }
 }
 
-// gomoku.py:143-162: choose (sample ~ visits | first max-visit child), make_move, check_winner, draw
-__global__ __launch_bounds__(AZK_WAVE) void k_advance(Dev d, const double *uniforms, int sample_until,
-                                                       int *chosen, int *winner_out, int *done_out) {
-    const int g = blockIdx.x, lane = azk_lane();
+// gomoku.py:143-162 for one game (one wave): choose (sample ~ visits | first max-visit child), record pi / the action in the
+// trajectory, make_move, check_winner, draw.  Returns the chosen cell (-1: state error, already reported); *win_out / *done_out as
+// k_advance's outputs; pi of the move is left in L.cnt / sum_out (visit counts per action and their sum).
+__device__ __forceinline__ int advance_one(const Dev &d, LdsView &L, int g, bool have_u, double u, int sample_until, int *win_out, int *done_out,
+                                           int *sum_out) {
+    const int lane = azk_lane();
     const GameDesc &gd = d.g;
     const size_t base = (size_t)g * d.cap;
     const int A = gd.action_dim, rc = gd.rc;
-    LdsView L = carve(gd, d.path_cap, d.table_size);
-    if (uniform_i32(d.done[g]) != 0) {
-        if (lane == 0) {
-            if (chosen) chosen[g] = -1;
-            if (winner_out) winner_out[g] = d.winner[g];
-            if (done_out) done_out[g] = 1;
-        }
-        return;
-    }
     const int fc = uniform_i32(d.first_child[base]), nch = uniform_i32(meta_nch(d.meta[base]));
     const int mc = uniform_i32(d.move_count[g]), mover = uniform_i32(d.to_move[g]);
     for (int i = lane; i < rc; i += AZK_WAVE) L.board[i] = d.cells[(size_t)g * d.rc_pad + i];
@@ -990,18 +983,19 @@ __global__ __launch_bounds__(AZK_WAVE) void k_advance(Dev d, const double *unifo
     }
     sum = wave_sum_i32(sum);
     __syncthreads();
+    *sum_out = sum;
     int cellc = -1;
     if (nch <= 0 || sum <= 0) {
         if (lane == 0) atomicExch(d.err, AZK_ERR_STATE);
-        return;
+        return -1;
     }
-    if (uniforms != nullptr && mc < sample_until) {
+    if (have_u && mc < sample_until) {
         // Node.sample_child (node.py:83-93) -> legacy np.random.choice(p=pi): cdf = cumsum(pi); cdf /= cdf[-1];
         // index = searchsorted(cdf, u, side='right').  cumsum is sequential in float64.
         if (lane == 0) {
             double acc = 0.0;
             for (int a = 0; a < A; a++) { acc += (double)L.cnt[a] / (double)sum; L.cdf[a] = acc; }
-            const double lastv = L.cdf[A - 1], u = uniforms[g];
+            const double lastv = L.cdf[A - 1];
             int lo = 0, hi = A;
             while (lo < hi) { int mid = (lo + hi) >> 1; if (u < L.cdf[mid] / lastv) hi = mid; else lo = mid + 1; }
             L.path[0] = lo < A ? lo : A - 1;                         // action drawn (path scratch: cnt[] is still needed)
@@ -1027,7 +1021,7 @@ __global__ __launch_bounds__(AZK_WAVE) void k_advance(Dev d, const double *unifo
     cellc = uniform_i32(cellc);
     if (cellc < 0) {
         if (lane == 0) atomicExch(d.err, AZK_ERR_STATE);
-        return;
+        return -1;
     }
     if (d.traj_pi != nullptr && mc < gd.state_dim) {               // gomoku.py:138-146: pi and the action of this ply
         double *tp = d.traj_pi + ((size_t)g * gd.state_dim + mc) * A;
@@ -1040,18 +1034,39 @@ __global__ __launch_bounds__(AZK_WAVE) void k_advance(Dev d, const double *unifo
     }
     __syncthreads();
     const int w = azk_check_winner(L.board, gd, mover, cellc);      // gomoku.py:150
+    int win = -2, dn = 0;
+    if (w != -1) { win = w; dn = 1; }
+    else if (mc + 1 == gd.state_dim) { win = -1; dn = 1; }
     if (lane == 0) {
         d.cells[(size_t)g * d.rc_pad + cellc] = L.board[cellc];
         d.to_move[g] = 1 - mover;
         d.move_count[g] = mc + 1;
-        int win = -2, dn = 0;
-        if (w != -1) { win = w; dn = 1; }
-        else if (mc + 1 == gd.state_dim) { win = -1; dn = 1; }
         d.winner[g] = win; d.done[g] = dn;
+        d.counters[(size_t)CNT_MOVES * d.G + g] += 1;
+    }
+    *win_out = win; *done_out = dn;
+    return cellc;
+}
+
+__global__ __launch_bounds__(AZK_WAVE) void k_advance(Dev d, const double *uniforms, int sample_until,
+                                                       int *chosen, int *winner_out, int *done_out) {
+    const int g = blockIdx.x, lane = azk_lane();
+    LdsView L = carve(d.g, d.path_cap, d.table_size);
+    if (uniform_i32(d.done[g]) != 0) {
+        if (lane == 0) {
+            if (chosen) chosen[g] = -1;
+            if (winner_out) winner_out[g] = d.winner[g];
+            if (done_out) done_out[g] = 1;
+        }
+        return;
+    }
+    int win = -2, dn = 0, sum = 0;
+    const int cellc = advance_one(d, L, g, uniforms != nullptr, uniforms != nullptr ? uniforms[g] : 0.0, sample_until, &win, &dn, &sum);
+    if (cellc < 0) return;
+    if (lane == 0) {
         if (chosen) chosen[g] = cellc;
         if (winner_out) winner_out[g] = win;
         if (done_out) done_out[g] = dn;
-        d.counters[(size_t)CNT_MOVES * d.G + g] += 1;
     }
 }
 
@@ -1090,12 +1105,18 @@ __device__ __forceinline__ int d4_source(int t, int i, int j, int N) {
     return si * N + sj;
 }
 
+template <bool LIST>     // LIST: the grid walks a list of finished games (asynchronous drain) instead of covering all G
 __global__ __launch_bounds__(AZK_WAVE) void k_emit_tuples(Dev d, float *states, double *pis, float *zs, long long capacity,
-                                                            const unsigned long long *cursor) {
+                                                            const unsigned long long *cursor, const int *list, const int *n_list) {
     const int S = d.g.state_dim, A = d.g.action_dim, rc = d.g.rc, F = d.g.planes, N = d.g.rows;
-    const int g = blockIdx.x / S, i = blockIdx.x - g * S, lane = azk_lane();
+    const int lane = azk_lane();
+    const int nb = LIST ? *n_list * S : (int)gridDim.x;
+    for (int blk = blockIdx.x; blk < nb; blk += gridDim.x) {
+    if (LIST && blk != (int)blockIdx.x) __syncthreads();
+    const int gi = blk / S, i = blk - gi * S;
+    const int g = LIST ? list[gi] : gi;
     const long long base = d.emit_base[g];
-    if (base < 0 || i >= d.move_count[g]) return;
+    if (base < 0 || i >= d.move_count[g]) continue;
     extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
     uint8_t *cells = sm;                                          // board before ply i
     for (int c = lane; c < rc; c += AZK_WAVE) cells[c] = 0;
@@ -1123,6 +1144,7 @@ __global__ __launch_bounds__(AZK_WAVE) void k_emit_tuples(Dev d, float *states, 
             po[e] = pi[src];                                        // square boards: action index == cell index
         }
         if (lane == 0) zs[slot] = z;
+    }
     }
 }
 
@@ -1163,19 +1185,17 @@ __device__ __forceinline__ double u53(uint32_t hi, uint32_t lo) {     // uniform
     return ((double)x + 0.5) * (1.0 / 9007199254740992.0);
 }
 
-__global__ __launch_bounds__(AZK_WAVE) void k_gen_noise(int A, unsigned long long seed, long long first_game, int move,
-                                                         double alpha, double *noise, double *uniforms) {
-    const int g = blockIdx.x, lane = azk_lane();
-    const unsigned long long gg = (unsigned long long)(first_game + g);
+// the uniform of (seed, global game, move): np.random.choice's draw of that move
+__device__ __forceinline__ double noise_uniform(unsigned long long seed, unsigned long long gg, int move) {
+    uint32_t c[4] = {(uint32_t)gg, (uint32_t)(gg >> 32), (uint32_t)move, 0xFFFFFFFFu};
+    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    return (double)((((unsigned long long)c[0] << 32) | c[1]) >> 11) * (1.0 / 9007199254740992.0);   // [0,1)
+}
+
+// the Dirichlet(alpha) row of (seed, global game, move), by one wave; red: 64 doubles of LDS scratch
+__device__ __forceinline__ void noise_row(int A, unsigned long long seed, unsigned long long gg, int move, double alpha, double *row, double *red) {
+    const int lane = azk_lane();
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-    __shared__ double red[AZK_WAVE];
-    if (uniforms && lane == 0) {
-        uint32_t c[4] = {(uint32_t)gg, (uint32_t)(gg >> 32), (uint32_t)move, 0xFFFFFFFFu};
-        philox4x32_10(c, k0, k1);
-        double u = (double)((((unsigned long long)c[0] << 32) | c[1]) >> 11) * (1.0 / 9007199254740992.0);   // [0,1)
-        uniforms[g] = u;
-    }
-    if (!noise) return;
     double part = 0.0;
     for (int a = lane; a < A; a += AZK_WAVE) {
         const double d = alpha + 1.0 - 1.0 / 3.0, cc = 1.0 / sqrt(9.0 * d);
@@ -1192,16 +1212,129 @@ __global__ __launch_bounds__(AZK_WAVE) void k_gen_noise(int A, unsigned long lon
             const double v = t * t * t;
             if (log(u3) < 0.5 * x * x + d - d * v + d * log(v)) { gam = d * v * pow(u4, 1.0 / alpha); break; }
         }
-        noise[(size_t)g * A + a] = gam;
+        row[a] = gam;
         part += gam;
     }
     red[lane] = part;
     __syncthreads();
     for (int o = 32; o > 0; o >>= 1) { if (lane < o) red[lane] += red[lane + o]; __syncthreads(); }
     const double tot = red[0];
-    for (int a = lane; a < A; a += AZK_WAVE) {
-        const size_t i = (size_t)g * A + a;
-        noise[i] = tot > 0.0 ? noise[i] / tot : 1.0 / (double)A;
+    for (int a = lane; a < A; a += AZK_WAVE) row[a] = tot > 0.0 ? row[a] / tot : 1.0 / (double)A;
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(AZK_WAVE) void k_gen_noise(int A, unsigned long long seed, long long first_game, int move,
+                                                         double alpha, double *noise, double *uniforms) {
+    const int g = blockIdx.x, lane = azk_lane();
+    const unsigned long long gg = (unsigned long long)(first_game + g);
+    __shared__ double red[AZK_WAVE];
+    if (uniforms && lane == 0) uniforms[g] = noise_uniform(seed, gg, move);
+    if (!noise) return;
+    noise_row(A, seed, gg, move, alpha, noise + (size_t)g * A, red);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Asynchronous self-play (games/gomoku.py:132-162: a game moves as soon as ITS search is done).  After every tree launch
+// k_move_async looks at every game: one whose search is complete (its simulation budget used up, nothing pending) gets its move
+// - root statistics, pi into the trajectory, sampled / most-visited child, make_move, check_winner, a record into the device
+// ring - and, unless the game ended, its next search at once: fresh root, Dirichlet row of (seed, global game, the slot's move
+// counter).  Finished games wait for azk_async_drain ((state, pi, z) emission, statistics, restart), which the host runs every
+// few launches.  Random numbers are keyed by (seed, global game index, per-slot move counter): exactly the keys of the lock-step
+// driver, so a slot plays the same sequence of games move for move, whatever the timing.
+// ------------------------------------------------------------------------------------------------
+struct AsyncDev {
+    int n_sims, sample_until, dirichlet;
+    unsigned long long seed;
+    long long first_game;
+    double alpha;
+    long long *slot_moves;     // [G] moves this slot has played since azk_async_begin (all its games): the RNG's move key
+    double *noise;             // [G][A] engine-owned: the Dirichlet row of each game's CURRENT search
+    long long *stats;          // caller's int64 [16]: games, plies, wins 0 / 1, draws, moves, record cursor, searches begun
+    long long rec_cap;
+    int *rec_meta; double *rec_q; double *rec_pi;
+    int *fin_list, *fin_count; // games found finished by the drain
+};
+
+// Node(None, None, player, move_count) + this search's noise row, for one game (one wave)
+__device__ __forceinline__ void begin_search_one(const Dev &d, const AsyncDev &p, int g, double *red) {
+    const int lane = azk_lane();
+    if (lane == 0) {
+        drop_pending_cache_claim(d, g);
+        const size_t base = (size_t)g * d.cap;
+        d.N[base] = 0; d.W[base] = 0.0; d.P[base] = 0.f; d.meta[base] = meta_pack(0xffff, 0);
+        d.first_child[base] = -1;
+        d.arena_top[g] = 1; d.root_f64[g] = 0;
+        clear_leaf_slots(d, g);
+        d.sims_done[g] = 0;
+        atomicAdd((unsigned long long *)&p.stats[7], 1ull);
+    }
+    if (p.dirichlet) noise_row(d.g.action_dim, p.seed, (unsigned long long)(p.first_game + g), (int)p.slot_moves[g], p.alpha, p.noise + (size_t)g * d.g.action_dim, red);
+}
+
+__global__ __launch_bounds__(AZK_WAVE) void k_move_async(Dev d, AsyncDev p) {
+    const int g = blockIdx.x, lane = azk_lane();
+    // one vector load for the three words that decide whether this game moves now (almost never: the wave then ends at once)
+    const int *up = d.done + g;
+    up = lane == 1 ? d.sims_done + g : up;
+    up = lane == 2 ? d.leaf_node + g : up;
+    up = lane == 3 ? d.budget : up;                                // (the simulation budget lives in device memory: azk_async_set_budget)
+    const int uw = *up;
+    if (__builtin_amdgcn_readlane(uw, 0) != 0 || __builtin_amdgcn_readlane(uw, 1) < __builtin_amdgcn_readlane(uw, 3) || __builtin_amdgcn_readlane(uw, 2) >= 0) return;
+    LdsView L = carve(d.g, d.path_cap, d.table_size);
+    const int A = d.g.action_dim;
+    const size_t base = (size_t)g * d.cap;
+    const long long mv = p.slot_moves[g];
+    const double q = d.W[base] / (double)d.N[base];                 // root.value / root.visit (gomoku.py:140), before the tree is reset
+    int win = -2, dn = 0, sum = 0;
+    const double u = noise_uniform(p.seed, (unsigned long long)(p.first_game + g), (int)mv);
+    const int cellc = advance_one(d, L, g, true, u, p.sample_until, &win, &dn, &sum);
+    if (cellc < 0) return;
+    if (p.rec_cap > 0) {                                           // the move's record: what the reference's self_play keeps per ply
+        long long slot = 0;
+        if (lane == 0) slot = (long long)(atomicAdd((unsigned long long *)&p.stats[6], 1ull) % (unsigned long long)p.rec_cap);
+        slot = ((long long)__builtin_amdgcn_readfirstlane((int)(slot >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)slot);
+        for (int a = lane; a < A; a += AZK_WAVE) p.rec_pi[(size_t)slot * A + a] = (double)L.cnt[a] / (double)sum;
+        if (lane == 0) {
+            p.rec_q[slot] = q;
+            int *m = p.rec_meta + (size_t)slot * 4;
+            m[0] = g; m[1] = (int)mv; m[2] = cellc; m[3] = win;
+        }
+    }
+    __syncthreads();
+    if (lane == 0) {
+        p.slot_moves[g] = mv + 1;
+        atomicAdd((unsigned long long *)&p.stats[5], 1ull);
+    }
+    __syncthreads();
+    if (!dn) begin_search_one(d, p, g, L.cdf);                      // (slot_moves[g] is the NEW search's key; re-read inside)
+}
+
+// drain, step 1: list the finished games (done == 1) - the emission and restart kernels work through the list only
+__global__ void k_async_list(Dev d, AsyncDev p) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < d.G && d.done[g] != 0) p.fin_list[atomicAdd(p.fin_count, 1)] = g;
+}
+
+// drain, step 3: statistics + Game() + the next search for every listed game
+__global__ __launch_bounds__(AZK_WAVE) void k_async_restart(Dev d, AsyncDev p, int recycle) {
+    const int lane = azk_lane();
+    LdsView L = carve(d.g, d.path_cap, d.table_size);
+    const int n = *p.fin_count;
+    for (int f = blockIdx.x; f < n; f += gridDim.x) {
+        const int g = p.fin_list[f];
+        if (uniform_i32(d.done[g]) == 3) continue;                 // already counted by an earlier drain (recycle off: the slot stays finished)
+        if (lane == 0) {
+            atomicAdd((unsigned long long *)&p.stats[0], 1ull);
+            atomicAdd((unsigned long long *)&p.stats[1], (unsigned long long)d.move_count[g]);
+            const int w = d.winner[g];
+            atomicAdd((unsigned long long *)&p.stats[w == 0 ? 2 : (w == 1 ? 3 : 4)], 1ull);
+        }
+        if (!recycle) { if (lane == 0) d.done[g] = 3; continue; }
+        for (int i = lane; i < d.rc_pad; i += AZK_WAVE) d.cells[(size_t)g * d.rc_pad + i] = 0;
+        if (lane == 0) { d.to_move[g] = 0; d.move_count[g] = 0; d.done[g] = 0; d.winner[g] = -2; }
+        __syncthreads();
+        begin_search_one(d, p, g, L.cdf);
+        __syncthreads();
     }
 }
 
@@ -1316,6 +1449,9 @@ struct azk_engine {
     int lntab_n = 0;
     bool multi = false;                  // budget stepping (azk_begin_search_budget): the MULTI instantiation of k_tree
     int budget_host[2] = {0, 1};
+    AsyncDev ad;                         // asynchronous self-play (azk_async_begin); ad.slot_moves == nullptr: not set up
+    bool async_on = false;
+    int async_recycle = 1;
 };
 
 #define HIPCHK(e, call)                                                                 \
@@ -1350,6 +1486,7 @@ int32_t azk_create(const azk_config *cfg, azk_engine **out) {
     e->cfg = *cfg;
     Dev &d = e->d;
     memset(&d, 0, sizeof d);
+    memset(&e->ad, 0, sizeof e->ad);
     auto fail = [&](int code, const std::string &msg) { g_create_error = msg; azk_destroy(e); return code; };
     std::string gerr;
     if (!make_game(cfg->game, cfg->rows, cfg->cols, &d.g, &gerr)) return fail(AZK_ERR_ARG, gerr);
@@ -1494,6 +1631,80 @@ int32_t azk_begin_search_budget(azk_engine *e, const double *noise_dev, int32_t 
         HIPCHK(e, hipStreamSynchronize((hipStream_t)stream));
     }
     k_begin_search<<<(unsigned)((e->d.G + 255) / 256), 256, 0, (hipStream_t)stream>>>(e->d);
+    HIPCHK(e, hipGetLastError());
+    return AZK_OK;
+}
+
+// ---- asynchronous self-play ---------------------------------------------------------------------------------------------
+int32_t azk_async_begin(azk_engine *e, const azk_async_config *c, void *stream) {
+    if (!e || !c || !c->stats_dev || c->n_sims < 1 || c->n_sims > e->cfg.max_sims || c->max_sims_per_launch < 1 || !(c->alpha > 0.0)) {
+        if (e) e->err = "azk_async_begin: bad argument";
+        return AZK_ERR_ARG;
+    }
+    if (c->record_capacity < 0 || (c->record_capacity > 0 && (!c->rec_meta_dev || !c->rec_q_dev || !c->rec_pi_dev))) { e->err = "azk_async_begin: record ring pointers missing"; return AZK_ERR_ARG; }
+    Dev &d = e->d;
+    if (d.K > 1) { e->err = "azk_async_begin: asynchronous moves run the sequential search (leaves_per_step = 1)"; return AZK_ERR_ARG; }
+    hipStream_t st = (hipStream_t)stream;
+    AsyncDev &a = e->ad;
+    if (!a.slot_moves) {
+        HIPCHK(e, dalloc(e, &a.slot_moves, (size_t)d.G));
+        HIPCHK(e, dalloc(e, &a.noise, (size_t)d.G * d.g.action_dim));
+        HIPCHK(e, dalloc(e, &a.fin_list, (size_t)d.G));
+        HIPCHK(e, dalloc(e, &a.fin_count, 1));
+    }
+    a.n_sims = c->n_sims; a.sample_until = c->sample_until_move; a.dirichlet = c->dirichlet ? 1 : 0;
+    a.seed = c->seed; a.first_game = c->first_global_game; a.alpha = c->alpha;
+    a.stats = (long long *)c->stats_dev; a.rec_cap = c->record_capacity; a.rec_meta = c->rec_meta_dev; a.rec_q = c->rec_q_dev; a.rec_pi = c->rec_pi_dev;
+    e->async_recycle = c->recycle ? 1 : 0;
+    HIPCHK(e, hipMemsetAsync(a.slot_moves, 0, sizeof(long long) * (size_t)d.G, st));
+    HIPCHK(e, hipMemsetAsync(a.stats, 0, sizeof(long long) * 16, st));
+    // the simulation budget lives in device memory (a captured step graph keeps working when it changes)
+    e->budget_host[0] = c->n_sims; e->budget_host[1] = c->max_sims_per_launch;
+    HIPCHK(e, hipMemcpyAsync(d.budget, e->budget_host, sizeof e->budget_host, hipMemcpyHostToDevice, st));
+    HIPCHK(e, hipStreamSynchronize(st));
+    d.noise = a.dirichlet ? a.noise : nullptr;
+    e->multi = true;
+    e->async_on = true;
+    // first search of every game: fresh roots + the Dirichlet rows of move key 0
+    k_begin_search<<<(unsigned)((d.G + 255) / 256), 256, 0, st>>>(d);
+    if (a.dirichlet) k_gen_noise<<<d.G, AZK_WAVE, 0, st>>>(d.g.action_dim, a.seed, a.first_game, 0, a.alpha, a.noise, nullptr);
+    HIPCHK(e, hipGetLastError());
+    return AZK_OK;
+}
+
+int32_t azk_async_step(azk_engine *e, const float *logits_dev, const float *values_dev, int32_t phases, void *stream) {
+    if (!e || !e->async_on) { if (e) e->err = "azk_async_step: call azk_async_begin first"; return AZK_ERR_STATE; }
+    const Dev &d = e->d;
+    hipStream_t st = (hipStream_t)stream;
+    if (phases & 1) k_tree<true, true, false, true><<<d.G, AZK_WAVE, d.lds_bytes, st>>>(d, logits_dev, values_dev);
+    if (phases & 2) k_move_async<<<d.G, AZK_WAVE, d.lds_bytes, st>>>(d, e->ad);
+    HIPCHK(e, hipGetLastError());
+    return AZK_OK;
+}
+
+int32_t azk_async_set_budget(azk_engine *e, int32_t n_sims, int32_t max_sims_per_launch, void *stream) {
+    if (!e || !e->async_on || n_sims < 1 || n_sims > e->cfg.max_sims || max_sims_per_launch < 1) { if (e) e->err = "azk_async_set_budget: bad argument"; return AZK_ERR_ARG; }
+    e->budget_host[0] = n_sims; e->budget_host[1] = max_sims_per_launch;
+    HIPCHK(e, hipMemcpyAsync(e->d.budget, e->budget_host, sizeof e->budget_host, hipMemcpyHostToDevice, (hipStream_t)stream));
+    HIPCHK(e, hipStreamSynchronize((hipStream_t)stream));
+    return AZK_OK;
+}
+
+int32_t azk_async_drain(azk_engine *e, float *states_dev, double *pis_dev, float *zs_dev, int64_t capacity, int64_t *cursor_dev, void *stream) {
+    if (!e || !e->async_on) { if (e) e->err = "azk_async_drain: call azk_async_begin first"; return AZK_ERR_STATE; }
+    const Dev &d = e->d;
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(e, hipMemsetAsync(e->ad.fin_count, 0, sizeof(int), st));
+    k_async_list<<<(unsigned)((d.G + 255) / 256), 256, 0, st>>>(d, e->ad);
+    if (states_dev) {
+        if (!pis_dev || !zs_dev || !cursor_dev || capacity < 1 || !d.traj_pi) { e->err = "azk_async_drain: bad replay arguments"; return AZK_ERR_ARG; }
+        k_emit_alloc<<<(unsigned)((d.G + 255) / 256), 256, 0, st>>>(d, (unsigned long long *)cursor_dev, nullptr);
+        const int blocks = d.G * d.g.state_dim < 16384 ? d.G * d.g.state_dim : 16384;
+        k_emit_tuples<true><<<(unsigned)blocks, AZK_WAVE, up16(d.g.rc), st>>>(d, states_dev, pis_dev, zs_dev, (long long)capacity,
+                                                                            (const unsigned long long *)cursor_dev, e->ad.fin_list, e->ad.fin_count);
+        k_emit_mark<<<(unsigned)((d.G + 255) / 256), 256, 0, st>>>(d);
+    }
+    k_async_restart<<<(unsigned)(d.G < 256 ? d.G : 256), AZK_WAVE, d.lds_bytes, st>>>(d, e->ad, e->async_recycle);
     HIPCHK(e, hipGetLastError());
     return AZK_OK;
 }
@@ -1655,8 +1866,8 @@ int32_t azk_emit_finished(azk_engine *e, float *states_dev, double *pis_dev, flo
     if (!d.traj_pi) { e->err = "azk_emit_finished: (state, pi, z) emission needs a square board with one action per cell"; return AZK_ERR_ARG; }
     hipStream_t st = (hipStream_t)stream;
     k_emit_alloc<<<(unsigned)((d.G + 255) / 256), 256, 0, st>>>(d, (unsigned long long *)cursor_dev, (long long *)game_base_dev);
-    k_emit_tuples<<<(unsigned)(d.G * d.g.state_dim), AZK_WAVE, up16(d.g.rc), st>>>(d, states_dev, pis_dev, zs_dev, (long long)capacity,
-                                                                                  (const unsigned long long *)cursor_dev);
+    k_emit_tuples<false><<<(unsigned)(d.G * d.g.state_dim), AZK_WAVE, up16(d.g.rc), st>>>(d, states_dev, pis_dev, zs_dev, (long long)capacity,
+                                                                                         (const unsigned long long *)cursor_dev, nullptr, nullptr);
     k_emit_mark<<<(unsigned)((d.G + 255) / 256), 256, 0, st>>>(d);
     HIPCHK(e, hipGetLastError());
     return AZK_OK;

@@ -101,6 +101,29 @@ def init_weights(cfg, seed=0):
     return {k_: v.clone() for k_, v in w.items()}
 
 
+def _same_structure(a, b):
+    """Two nests of dicts / tensors / table objects have the same keys, shapes, dtypes and devices."""
+    if isinstance(a, torch.Tensor) or isinstance(b, torch.Tensor):
+        return (isinstance(a, torch.Tensor) and isinstance(b, torch.Tensor) and a.shape == b.shape and a.dtype == b.dtype
+                and a.device == b.device)
+    if isinstance(a, dict) or isinstance(b, dict):
+        return isinstance(a, dict) and isinstance(b, dict) and a.keys() == b.keys() and all(_same_structure(a[k_], b[k_]) for k_ in a)
+    if hasattr(a, "t") and isinstance(getattr(a, "t"), dict):           # azk.EmbedPoolTables / EmbedPoolXTables: their tensors live in .t
+        return type(a) is type(b) and _same_structure(a.t, b.t)
+    return type(a) is type(b) and (a is None or not isinstance(a, (int, float, str, bool)) or a == b)
+
+
+def _copy_into(dst, src):
+    """dst <- src for every tensor of two nests with the same structure, in place (addresses unchanged)."""
+    if isinstance(dst, torch.Tensor):
+        dst.copy_(src)
+    elif isinstance(dst, dict):
+        for k_ in dst:
+            _copy_into(dst[k_], src[k_])
+    elif hasattr(dst, "t") and isinstance(getattr(dst, "t"), dict):
+        _copy_into(dst.t, src.t)
+
+
 class PolicyValueNet:
     """Callable evaluator: net(boards[n,C,R,Cc]) -> (logits [n,A] float32, value [n,1] float32)."""
 
@@ -143,14 +166,30 @@ class PolicyValueNet:
     def from_state_dict(cls, cfg, sd, **kw):
         return cls(cfg, weights=sd, **kw)
 
-    def load_state_dict(self, sd):
-        """nn.Module.load_state_dict for the reference's keys: replaces the weights in place (device copies and the folded
-        constants of the HIP paths are rebuilt; a captured step graph must be re-captured by its owner)."""
+    def load_state_dict(self, sd, in_place=True):
+        """nn.Module.load_state_dict for the reference's keys (main.py:59 `older_model.load_state_dict(...)`: promotion).
+        in_place: every device buffer the kernels read - weight copies, folded constants, per-token tables, packed fragments - is
+        recomputed from the new weights (on the device) and COPIED INTO THE EXISTING TENSORS, so their addresses do not change
+        and a captured step graph keeps working without re-capture.  Returns True when that was possible; False when the new
+        weights changed which kernels apply (e.g. the static softmax reference no longer fits) and the structures were rebuilt -
+        the owner of a captured graph must then re-capture.  The caller clears the engine's eval cache (main.py:55-57)."""
         want = reference_key_shapes(self.cfg)
         for k_, shape in want.items():
             assert k_ in sd and tuple(sd[k_].shape) == tuple(shape), k_
+        names = ("w", "_hip", "_fold", "_compact", "_exact")
+        old = {n_: getattr(self, n_, None) for n_ in names}
+        old_flags = (self.fused_embed_pool, self.chain_tail, self.hip_tail, self._gelu_epilogue)
         self.master = {k_: torch.as_tensor(sd[k_]).detach().to("cpu", torch.float32).clone() for k_ in want}
         self.to(self.device, self.dtype)
+        if not in_place:
+            return False
+        new = {n_: getattr(self, n_, None) for n_ in names}
+        if old_flags != (self.fused_embed_pool, self.chain_tail, self.hip_tail, self._gelu_epilogue) or not _same_structure(old, new):
+            return False
+        _copy_into(old, new)
+        for n_ in names:
+            setattr(self, n_, old[n_])
+        return True
 
     def to(self, device, dtype=None):
         self.device = torch.device(device)

@@ -426,6 +426,197 @@ class SelfPlayRunner:
             h.eng.check_error()
 
 
+class AsyncSelfPlayRunner:
+    """Continuous self-play with ASYNCHRONOUS moves (games/gomoku.py:132-162: a game moves as soon as ITS search is done - in the
+    batched engine: no game waits for the slowest search of the batch) and budget stepping (a game keeps simulating inside a tree
+    launch while its simulations need no evaluator - terminal leaves, eval-cache hits -, at most `per_launch` simulations per
+    launch).  Trees, moves and games are those of the lock-step runner, slot for slot and move for move: a game's simulations stay
+    sequential, the random keys are (seed, global game, the slot's move counter) (tests/test_gpu_async.py).
+
+    One step = k_tree (budget-stepped) -> k_move_async (moves every game whose search is complete, starts its next search) ->
+    evaluator over the pending leaves; `steps_per_graph` steps are captured in one hipGraph.  After every graph replay the host
+    enqueues the drain (finished games: (state, pi, z) emission into `replay`, statistics, restart) and an asynchronous copy of
+    the statistics; it looks at them one replay late, so the GPU never waits for the host.
+
+    play_move() keeps the lock-step runner's contract for its callers (bench.py): it returns once the batch has played G more
+    moves in total (one move per resident game on average) - G x n_sims simulations, the same work as one lock-step move."""
+
+    def __init__(self, game, evaluator, n_games, n_sims, size=None, seed=0, first_global_game=0, dirichlet=True, alpha=0.03, device=0,
+                 leaf_dtype="float32", recycle=True, on_records=None, kernel_timer=None, replay=None, cache_entries=0, cache_shared=False,
+                 per_launch=2, steps_per_graph=32, record_capacity=None, use_graph=True):
+        import torch
+        self.torch, self.replay, self.evaluator = torch, replay, evaluator
+        self.eng = Engine(game, n_games, n_sims, size=size, device=device, leaf_dtype=leaf_dtype, cache_entries=cache_entries, cache_shared=cache_shared)
+        e = self.eng
+        self.G, self._n_sims, self.n_split, self.leaves_per_step = n_games, n_sims, 1, 1
+        self.per_launch, self.steps_per_graph, self.use_graph = int(per_launch), max(1, int(steps_per_graph)), use_graph
+        self.kernel_timer, self.on_records = kernel_timer, on_records
+        self.halves = [_Half(torch, e, False)]              # (logits / values step buffers; .eng for callers that walk the groups)
+        self.h = self.halves[0]
+        self.leaf_source_ok = True
+        e.reset_games()
+        cap = (4 * n_games if record_capacity is None else record_capacity) if (on_records is not None or record_capacity) else 0
+        self.stats, self.records = e.async_begin(n_sims, self.per_launch, SAMPLE_UNTIL[game], seed, first_global_game, alpha, dirichlet, recycle, cap)
+        self.rec_cap, self.rec_read, self.copy_stream = cap, 0, None
+        self.h_stats = [torch.zeros(16, dtype=torch.int64, pin_memory=True) for _ in range(2)]
+        self.events = [None, None]
+        self.launches = 0               # simulation-step launches issued
+        self.chunks = 0
+        self.move_target = 0
+        self._graph = None
+        self._seen = torch.zeros(16, dtype=torch.int64)
+        self.move_idx = 0
+
+    @property
+    def n_sims(self):
+        return self._n_sims
+
+    @n_sims.setter
+    def n_sims(self, v):
+        """Simulations per search from now on (bench.py's cheap pre-roll); read from device memory by the captured graphs."""
+        if int(v) != self._n_sims:
+            self._n_sims = int(v)
+            self.eng.async_set_budget(self._n_sims, self.per_launch)
+
+    # the lock-step runner's step body, with the asynchronous tree step in front
+    def _step_body(self, timer=None):
+        h, e, ev = self.h, self.eng, self.evaluator
+        from_leaves = getattr(ev, "fused_embed_pool", False) and self.leaf_source_ok
+        if hasattr(ev, "leaf_source"):
+            ev.leaf_source = e.leaf_source() if from_leaves else None
+        if timer is not None:
+            timer.start()
+            e.async_step(h.logits_buf, h.values_buf, 1)     # k_tree alone between the events
+            timer.stop()
+            e.async_step(h.logits_buf, h.values_buf, 2)
+        else:
+            e.async_step(h.logits_buf, h.values_buf, 3)
+        if not from_leaves:
+            e.step_gather()
+        had_fast = getattr(ev, "fast_outputs", False)
+        if hasattr(ev, "live_count"):
+            ev.live_count, ev.fast_outputs = e.n_leaf, True
+        if hasattr(ev, "kernel_timers"):
+            ev.kernel_timers = None if timer is None else ((timer.child("k_embed_pool"), timer.child("k_tail")) if getattr(ev, "fused_embed_pool", False)
+                                                            else (timer.child("k_embed"), timer.child("k_cls_pool"), timer.child("k_tail")))
+        if hasattr(ev, "out_buffers"):
+            ev.out_buffers = (h.logits_buf, h.values_buf)
+        logits, values = ev(e.leaf_boards)
+        if logits.data_ptr() != h.logits_buf.data_ptr():
+            h.logits_buf.copy_(logits)
+            h.values_buf.copy_(values.reshape(-1))
+        if hasattr(ev, "out_buffers"):
+            ev.out_buffers = None
+        if hasattr(ev, "leaf_source"):
+            ev.leaf_source = None
+        if hasattr(ev, "live_count"):
+            ev.live_count, ev.fast_outputs = None, had_fast
+
+    def _capture(self):
+        torch = self.torch
+        cur = torch.cuda.current_stream()
+        side = torch.cuda.Stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            for _ in range(3):                              # allocator warm-up; these steps count
+                self._step_body()
+        cur.wait_stream(side)
+        torch.cuda.synchronize()
+        self.launches += 3
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            for _ in range(self.steps_per_graph):
+                self._step_body()
+
+    def run_chunk(self):
+        """`steps_per_graph` steps, the drain, and an asynchronous copy of the statistics (read one chunk late)."""
+        torch = self.torch
+        if not self.use_graph:
+            for _ in range(self.steps_per_graph):
+                self._step_body()
+        else:
+            if self._graph is None:
+                self._capture()
+            kt = self.kernel_timer
+            if kt is not None and kt.enabled and len(kt.pairs) < kt.max and self.chunks % max(1, kt.stride // self.steps_per_graph) == 0:
+                self._step_body(timer=kt)                   # a sampled step runs eagerly so HIP events can bracket its kernels
+                self.launches += 1
+            self._graph.replay()
+        self.launches += self.steps_per_graph
+        self.eng.async_drain(self.replay)
+        i = self.chunks & 1
+        self.h_stats[i].copy_(self.stats, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.events[i] = ev
+        self.chunks += 1
+
+    def _look(self, i):
+        """Statistics of the chunk before last (its copy has certainly landed once its event is done)."""
+        if self.events[i] is not None:
+            self.events[i].synchronize()
+            self._seen = self.h_stats[i].clone()
+            self._deliver_records()
+
+    def _deliver_records(self):
+        if self.on_records is None or self.records is None:
+            return
+        cursor = int(self._seen[6])
+        if cursor - self.rec_read > self.rec_cap:
+            raise RuntimeError("move-record ring overrun: raise record_capacity or drain more often")
+        if cursor == self.rec_read:
+            return
+        # on a stream of their own: the entries are complete (their chunk's event is done) and the copies must not queue behind the
+        # chunk that is running now
+        if self.copy_stream is None:
+            self.copy_stream = self.torch.cuda.Stream(device=self.eng.device)
+        with self.torch.cuda.stream(self.copy_stream):
+            idx = self.torch.arange(self.rec_read, cursor, device=self.eng.device) % self.rec_cap
+            meta, q, pi = self.records["meta"][idx].cpu().numpy(), self.records["q"][idx].cpu().numpy(), self.records["pi"][idx].cpu().numpy()
+        self.rec_read = cursor
+        self.on_records(meta, q, pi)
+
+    def run_until_moves(self, total_moves):
+        """Run until the batch has played `total_moves` moves since construction (all slots together)."""
+        while int(self._seen[5]) < total_moves:
+            self.run_chunk()
+            self._look((self.chunks & 1))                   # the OTHER buffer: the chunk before the one just enqueued
+        return int(self._seen[5])
+
+    def play_move(self):
+        self.move_target += self.G
+        self.run_until_moves(self.move_target)
+        self.move_idx += 1
+
+    def finish(self):
+        """Wait for everything enqueued and read the final statistics."""
+        self.torch.cuda.synchronize()
+        self._seen = self.stats.cpu()
+        self._deliver_records()
+        return self._seen
+
+    @property
+    def plies_played(self):
+        return int(self._seen[5])
+
+    @property
+    def games_finished(self):
+        return int(self._seen[0])
+
+    @property
+    def finished_plies(self):
+        return int(self._seen[1])
+
+    def counters(self):
+        return self.eng.counters()
+
+    def reset_counters(self):
+        self.eng.reset_counters()
+
+    def check_error(self):
+        self.eng.check_error()
+
+
 class KernelTimer:
     """HIP-event timing of one kernel on the stream it is launched on (torch's current stream)."""
 

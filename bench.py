@@ -205,6 +205,10 @@ def main():
                          "hits) - same trees.  Measured SLOWER under per-move lock-step (236 vs 126 ms/move): the launch count of a move is set "
                          "by its slowest game (early-ply games miss the cache almost always) while every launch lasts as long as its busiest "
                          "wave; it needs asynchronous moves to pay (DESIGN.md section 10).  0 (default): one simulation per game and launch")
+    ap.add_argument("--async-moves", type=int, default=0,
+                    help="1: asynchronous per-game moves (a game moves as soon as ITS search is done: azk_async_*) with budget stepping - the same "
+                         "trees, moves and games as lock-step (tests/test_gpu_async.py); a step is then G moves of the batch in total")
+    ap.add_argument("--per-launch", type=int, default=2, help="with --async-moves: most simulations a game runs inside one tree launch")
     ap.add_argument("--virtual-loss", type=int, default=1, metavar="K",
                     help="OPT-IN, NOT the headline: K > 1 leaves in flight per game with a virtual loss on their paths (north_star's 'virtual-loss "
                          "expansion').  Changes search results (the reference's search is sequential), so the line is reported under its own metric key")
@@ -213,6 +217,9 @@ def main():
     ap.add_argument("--train-step", action="store_true",
                     help="BASELINE.json configs[4]: one train.py step (batch 512 per GPU, Adam lr 2.5e-4, one fused gradient bucket "
                          "all-reduced over RCCL) after every move, fed from the device-resident replay ring")
+    ap.add_argument("--promote-every", type=int, default=8,
+                    help="with --train-step: every n-th move the trained weights are promoted into the self-play evaluator (main.py:55-59: "
+                         "load_state_dict + MCTS.cache.clear()), in place - the captured step graphs keep replaying; 0 = never")
     args = ap.parse_args()
     if args.nn_path is None:
         args.nn_path = "clsfold"
@@ -274,12 +281,20 @@ def main():
             from trainer import Trainer
             replay = DeviceReplay(400000, cfg.channels, cfg.rows, cfg.cols, cfg.action_dim, device=torch.device("cuda", local_rank))
             trainer = Trainer(cfg, net.state_dict(), device=f"cuda:{local_rank}", dropout=0.1)      # main.py:134 trains with dropout 0.1
-        runner = SelfPlayRunner("gomoku", net, args.games, args.sims, size=args.size, seed=args.seed,
-                                first_global_game=shard_range(args.games, rank)[0], device=local_rank,
-                                leaf_dtype="bfloat16" if args.nn_dtype == "bf16" else "float32",
-                                recycle=True, kernel_timer=kt, use_graph=not args.no_graph, n_split=args.split, cache_entries=args.cache_entries,
-                                cache_shared=args.cache == "shared", replay=replay, budget_stepping=bool(args.budget_stepping), steps_per_graph=args.steps_per_graph,
-                                leaves_per_step=args.virtual_loss)
+        if args.async_moves:
+            from selfplay import AsyncSelfPlayRunner
+            runner = AsyncSelfPlayRunner("gomoku", net, args.games, args.sims, size=args.size, seed=args.seed,
+                                         first_global_game=shard_range(args.games, rank)[0], device=local_rank,
+                                         leaf_dtype="bfloat16" if args.nn_dtype == "bf16" else "float32", recycle=True, kernel_timer=kt,
+                                         cache_entries=args.cache_entries, cache_shared=args.cache == "shared", replay=replay,
+                                         per_launch=args.per_launch, steps_per_graph=args.steps_per_graph, use_graph=not args.no_graph)
+        else:
+            runner = SelfPlayRunner("gomoku", net, args.games, args.sims, size=args.size, seed=args.seed,
+                                    first_global_game=shard_range(args.games, rank)[0], device=local_rank,
+                                    leaf_dtype="bfloat16" if args.nn_dtype == "bf16" else "float32",
+                                    recycle=True, kernel_timer=kt, use_graph=not args.no_graph, n_split=args.split, cache_entries=args.cache_entries,
+                                    cache_shared=args.cache == "shared", replay=replay, budget_stepping=bool(args.budget_stepping),
+                                    steps_per_graph=args.steps_per_graph, leaves_per_step=args.virtual_loss)
 
     def train_one():
         """train.train with one iteration (train.py:85-123): fresh Adam, the reference's loss, gradient bucket all-reduce.
@@ -292,6 +307,21 @@ def main():
         trainer.train([replay.sample(512)], 0.00025, dist=dist if world > 1 else None)
         b.record()
         train_ms.append((a, b))
+
+    promote_ms = []
+
+    def promote():
+        """main.py:55-59: the new weights become the self-play model and MCTS.cache is cleared.  The evaluator's device buffers are
+        refreshed in place (PolicyValueNet.load_state_dict), so the captured step graphs stay valid."""
+        torch.cuda.synchronize()
+        t_ = time.perf_counter()
+        in_place = net.load_state_dict(trainer.state_dict())
+        if not in_place:
+            runner._graph = None
+        for h in runner.halves:
+            h.eng.clear_cache()
+        torch.cuda.synchronize()
+        promote_ms.append(((time.perf_counter() - t_) * 1e3, in_place))
 
     def sync_all():
         if not stub:
@@ -323,12 +353,16 @@ def main():
     kt.enabled = True
     sync_all()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i_ in range(args.steps):
         runner.play_move()
         if args.train_step:
             train_one()
+            if args.promote_every > 0 and (i_ + 1) % args.promote_every == 0 and train_ms:
+                promote()
     sync_all()
     dt = time.perf_counter() - t0
+    if hasattr(runner, "finish"):
+        runner.finish()                                     # asynchronous runner: the final statistics of everything it enqueued
     kt.enabled = False
     runner.check_error()
     c = runner.counters()
@@ -468,6 +502,9 @@ def main():
                            "hit_rate_rank0": c.get("cache_hits", 0) / max(1, c.get("cache_hits", 0) + c["leaves_evaluated"])},
             "nn_tflops_algorithmic": nn_flop_alg / dt_max / 1e12, "nn_tflops_issued": nn_flop_issued / dt_max / 1e12,
             "nn_flops_per_board": flops, "nn_boards_evaluated": evals,
+            "moves": ("asynchronous: every game moves as soon as its own search is complete (k_move_async), at most "
+                      f"{args.per_launch} simulation(s) per game and tree launch; a step = {args.games} moves of the batch in total") if args.async_moves
+                     else "lock-step: all games of the batch move together",
             "stepping": "eager+sync" if args.no_graph else f"hipGraph replay, {runner.steps_per_graph} simulation step(s) per graph, {runner.n_split} game group(s) (per simulation: k_tree, the network kernels taking the pending leaves straight from the engine, no host sync)",
             "value_definition": value_src, "games_per_sec_renewal_estimate": est_games_per_s,
             "mean_plies_per_game": mean_plies, "game_length_source": src, "games_finished_in_window": fin_window,
@@ -495,7 +532,12 @@ def main():
             out["config"]["workload"] += " + one train step (batch 512 per GPU, fp32 autograd, fused gradient bucket all-reduce) after every move (BASELINE.json configs[4])"
             out["train_step"] = {"steps": len(train_ms), "ms_per_train_step": (sum(x.elapsed_time(y) for x, y in train_ms) / len(train_ms)) if train_ms else None,
                                  "batch_per_gpu": 512, "replay_tuples_rank0": replay.size(),
-                                 "note": "the network weights used for self-play are not refreshed inside the timed window (promotion happens per iteration in train_loop.py)"}
+                                 "promotions_in_window": len(promote_ms), "promote_every_moves": args.promote_every,
+                                 "ms_per_promotion": (sum(m for m, _ in promote_ms) / len(promote_ms)) if promote_ms else None,
+                                 "promotions_in_place": sum(1 for _, ip in promote_ms if ip),
+                                 "note": "promotion (main.py:55-59) = trained weights -> the self-play evaluator's device buffers, refreshed IN PLACE "
+                                         "(folded constants and packed fragments recomputed on the device, same addresses: the captured step graphs "
+                                         "are not re-captured) + eval-cache clear; its wall time is inside the timed window"}
         if args.cpu_seconds > 0 and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.sims, args.cpu_seconds, mean_plies)
             out["gpu_over_cpu"] = games_per_s / out["cpu_baseline"]["value"]

@@ -117,6 +117,39 @@ int32_t azk_begin_search(azk_engine *e, const double *noise_dev, void *stream);
 int32_t azk_begin_search_budget(azk_engine *e, const double *noise_dev, int32_t n_sims, int32_t max_sims_per_launch, void *stream);
 int32_t azk_search_unfinished(azk_engine *e, int32_t *count_host, void *stream);
 
+/* ---- asynchronous self-play: a game moves as soon as ITS search is done (games/gomoku.py:132-162 runs one game at a time; in
+ * the batched engine that means no game waits for the slowest search of its batch).  Drive it as
+ *     azk_async_begin;  loop { azk_async_step(logits, values);  evaluator over the pending leaves;  every few steps: azk_async_drain }
+ * azk_async_step = one budget-stepped tree launch (as azk_step_tree after azk_begin_search_budget: a game's simulations stay strictly
+ * sequential, so every tree is bit-identical to one-simulation-per-call stepping) followed by the per-game move kernel: a game whose
+ * n_sims simulations are complete gets root statistics, pi recorded, the move chosen (sampled while move_count < sample_until_move with
+ * the uniform of (seed, global game, slot move counter), else the first most-visited child), make_move / check_winner / draw, a record
+ * into the caller's ring, and - unless it ended - its next search at once (fresh root, the Dirichlet row of its next move key).
+ * azk_async_drain handles the games that ended: (state, pi, z) emission into the caller's replay ring (as azk_emit_finished; pass
+ * states_dev = NULL to skip), statistics, and - with recycle - Game() + first search of the next game in the slot.
+ * The random keys are those of the lock-step drivers (azk_gen_noise with move_index = the slot's move counter), so a slot plays the
+ * same games move for move.  Both calls only enqueue kernels (capturable).
+ *   stats_dev  int64 [16], zeroed by azk_async_begin: [0] games finished, [1] their plies, [2] wins of player 0, [3] of player 1,
+ *              [4] draws, [5] moves played, [6] records written (ring cursor), [7] searches begun
+ *   record ring (optional, record_capacity entries; entry r % capacity): rec_meta int32 [cap][4] = slot, the slot's move counter,
+ *              chosen cell, winner (-2 running, -1 draw, 0 / 1); rec_q float64 [cap] = root.value / root.visit; rec_pi float64 [cap][A] */
+typedef struct azk_async_config {
+    int32_t n_sims, max_sims_per_launch, sample_until_move, dirichlet, recycle, reserved0;
+    uint64_t seed;
+    int64_t first_global_game;
+    double alpha;
+    int64_t *stats_dev;
+    int64_t record_capacity;
+    int32_t *rec_meta_dev;
+    double *rec_q_dev, *rec_pi_dev;
+} azk_async_config;
+int32_t azk_async_begin(azk_engine *e, const azk_async_config *cfg, void *stream);
+/* phases: bit 0 = the tree launch, bit 1 = the move kernel (3 = both; separately for per-kernel timing) */
+int32_t azk_async_step(azk_engine *e, const float *logits_dev, const float *values_dev, int32_t phases, void *stream);
+/* change the simulation budget of every later launch (it lives in device memory, so captured step graphs pick it up); synchronises */
+int32_t azk_async_set_budget(azk_engine *e, int32_t n_sims, int32_t max_sims_per_launch, void *stream);
+int32_t azk_async_drain(azk_engine *e, float *states_dev, double *pis_dev, float *zs_dev, int64_t capacity, int64_t *cursor_dev, void *stream);
+
 /* One simulation per active game (ai/mcts.py:16-60), split around the evaluator:
  *   azk_step_select   - mcts.py:18-37: PUCT walk (node.py:42-47, utils.py:29-44), make_move along the
  *                       path, terminal test + immediate backup, get_valid_moves, canonical board.

