@@ -20,6 +20,8 @@ namespace {
 
 enum { CNT_SIMS = 0, CNT_SCANNED, CNT_TRACE, CNT_CREATED, CNT_LEAVES, CNT_TERMINAL, CNT_MOVES, CNT_CACHE_HITS, CNT_N };
 
+struct __attribute__((aligned(16))) NodeH { int N; float P; uint32_t meta; int fc; };
+
 struct Dev {               // device view of the engine, passed to kernels by value
     GameDesc g;
     int G, cap, path_cap, rc_pad, leaf_dtype, table_size, lds_bytes;
@@ -29,11 +31,10 @@ struct Dev {               // device view of the engine, passed to kernels by va
     uint8_t *cells;        // [G][rc_pad]  cell codes (1 = player 0, 2 = player 1)
     int *to_move, *move_count, *done, *winner;   // [G]
     // tree arena, [G][cap] each (ai/node.py:21-40 as columns)
-    int *N;                // Node.visit
+    NodeH *H;              // per node, ONE 16-byte record: Node.visit N, Node.prior P (float32 softmax entry), meta = (Node.prevAction as
+                           // r*cols+c) << 16 | len(Node.children) (cell 0xFFFF = root), fc = index of children[0] in this game's arena
+                           // (-1 = not expanded): a PUCT candidate costs one 16-byte load + W instead of five column loads
     double *W;             // Node.value (running sum)
-    float *P;              // Node.prior (float32 softmax entries)
-    uint32_t *meta;        // (Node.prevAction as r*cols+c) << 16 | len(Node.children); cell 0xFFFF = root
-    int *first_child;      // index of children[0] in this game's arena, -1 = not expanded
     double *rootP;         // [G][rc] float64 root priors after Dirichlet mixing (utils.py:24-25), by child position
     int *root_f64;         // [G] root children use rootP (float64 UCB) instead of P (float32 UCB)
     int *arena_top;        // [G] bump allocator
@@ -148,7 +149,7 @@ __device__ __forceinline__ void backup_path(const Dev &d, size_t base, const int
         int nd = path[i];
         double sv = ((depth - i) & 1) ? -value : value;
         if (undo_virtual_loss) { d.W[base + nd] = (d.W[base + nd] + sv) + 1.0; continue; }      // the visit was counted at selection (same association as the short-path form)
-        d.N[base + nd] += 1;
+        d.H[base + nd].N += 1;
         d.W[base + nd] += sv;
     }
 }
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev dd, const float *__restri
     const Dev &d = dd;
     const int ablate = DBG ? dd.ablate : 0;
     const int g = blockIdx.x;
-    const int lane = azk_lane();
+    const int lane0 = azk_lane();
     const GameDesc &gd = d.g;
     const int A = gd.action_dim, rc = gd.rc;
     const size_t base = (size_t)g * (size_t)d.cap;
@@ -181,6 +182,11 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev dd, const float *__restri
     int done_sims = MULTI ? d.sims_done[g] : 0;
     const int sim_target = MULTI ? d.budget[0] : 0, max_iter = MULTI ? d.budget[1] : 1;
     for (int it = 0; it < max_iter; it++) {
+    // MULTI: the lane index is made opaque per iteration - left alone, the compiler hoists every lane-dependent address of the loop
+    // body (the ~40 per-lane loads of a simulation) out of the loop and keeps them live across it: 294 VGPRs, one wave per SIMD,
+    // the 2 048 waves of a launch in TWO rounds (measured 63 us for one simulation per launch against 36 us for the plain kernel)
+    int lane = lane0;
+    if (MULTI) asm volatile("" : "+v"(lane));
     if (MULTI && it > 0) __syncthreads();       // the previous simulation's LDS scratch is free and its tree / leaf writes are done
     // virtual-loss mode (K > 1, opt-in, changes search results): iteration k serves slot k - it expands the slot's pending leaf,
     // then selects a new one with a virtual loss left on its path so that the other slots' selections move elsewhere
@@ -210,9 +216,9 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev dd, const float *__restri
         up = lane == 8 ? d.to_move + g : up;
         up = lane == 9 ? d.move_count + g : up;
         up = lane == 10 ? d.root_f64 + g : up;
-        up = lane == 11 ? d.first_child + base : up;
-        up = lane == 12 ? d.N + base : up;
-        up = lane == 13 ? (const int *)(d.meta + base) : up;
+        up = lane == 11 ? &d.H[base].fc : up;
+        up = lane == 12 ? &d.H[base].N : up;
+        up = lane == 13 ? (const int *)&d.H[base].meta : up;
         uw = *up;
     } else {
         e_node = EXPAND ? d.leaf_node[vi] : -1; e_slot = EXPAND ? d.leaf_slot[vi] : 0; e_depth = EXPAND ? d.leaf_depth[vi] : 0;
@@ -221,8 +227,8 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev dd, const float *__restri
         cstamp = shared ? d.cache_stamp[0] : 0u;
         s_done = SELECT ? d.done[g] : 1; s_player = SELECT ? d.to_move[g] : 0; s_mc = SELECT ? d.move_count[g] : 0;
         s_rootf64 = SELECT ? d.root_f64[g] : 0;
-        r_fc = SELECT ? d.first_child[base] : -1; r_N = SELECT ? d.N[base] : 0;
-        r_meta = SELECT ? d.meta[base] : 0u;
+        r_fc = SELECT ? d.H[base].fc : -1; r_N = SELECT ? d.H[base].N : 0;
+        r_meta = SELECT ? d.H[base].meta : 0u;
     }
     unsigned long long e_key = 0ull;
     if (EXPAND && shared) e_key = d.leaf_key[(size_t)vi * d.key_words + min(lane, d.key_words - 1)];
@@ -275,14 +281,14 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev dd, const float *__restri
             // (unconditional, the lanes beyond the path read the root: a load under a lane predicate is followed by a wait for it,
             //  which put a whole round trip between these two loads and the logits below)
             const int bnode = (shortpath && lane <= depth) ? e_path : 0;
-            const int bN = d.N[base + bnode];
+            const int bN = d.H[base + bnode].N;
             const double bW = d.W[base + bnode];
             // second (and last) round trip of the expansion, all straight-line: logits, value, the node's header, root noise
             float lgv[KSL];
 #pragma unroll
             for (int k4 = 0; k4 < KSL; k4++) { const int i = lane + AZK_WAVE * k4; lgv[k4] = lg[i < A ? i : A - 1]; }
             const float vraw = hit ? (shared ? d.hit_value[vi] : d.cache_value[crow]) : values[slot];
-            const uint32_t node_meta = d.meta[base + node];
+            const uint32_t node_meta = d.H[base + node].meta;
             const bool mix = depth == 0 && d.noise != nullptr;        // mcts.py:42-43,52-53
             double nzv[KSL] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
             if (mix) {
@@ -333,13 +339,12 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev dd, const float *__restri
                     const int a = azk_action_idx(gd, cell);
                     const float p = L.e[a] / s;
                     const size_t idx = base + fc + i;
-                    d.N[idx] = 0; d.W[idx] = 0.0; d.P[idx] = p; d.meta[idx] = meta_pack(cell, 0);
-                    d.first_child[idx] = -1;
+                    d.H[idx] = NodeH{0, p, meta_pack(cell, 0), -1}; d.W[idx] = 0.0;
                     if (mix) d.rootP[(size_t)g * rc + i] = (double)(0.75f * p) + 0.25 * nzv[k4];   // utils.py:24-25
                 }
                 if (lane == 0) {
-                    d.first_child[base + node] = fc;
-                    d.meta[base + node] = (node_meta & 0xffff0000u) | (uint32_t)nv;
+                    d.H[base + node].fc = fc;
+                    d.H[base + node].meta = (node_meta & 0xffff0000u) | (uint32_t)nv;
                     d.arena_top[g] = fc + nv;
                     if (depth == 0) d.root_f64[g] = mix ? 1 : 0;
                     count_add(d, CNT_CREATED, g, nv);
@@ -352,7 +357,7 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev dd, const float *__restri
             if (shortpath) {                                          // Node.backup (node.py:62-74) on the operands fetched above
                 if (lane <= depth) {
                     // virtual-loss mode: the visit was already counted at selection and the value carries the loss (-1) left there
-                    d.N[base + e_path] = vl ? bN : bN + 1;
+                    d.H[base + e_path].N = vl ? bN : bN + 1;
                     d.W[base + e_path] = bW + (((depth - lane) & 1) ? -v : v) + (vl ? 1.0 : 0.0);
                 }
             } else {
@@ -410,11 +415,11 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev dd, const float *__restri
                 // argmax as a DPP maximum + ballot - "first maximum wins" (node.py:47) is the lowest lane holding the maximum
                 const bool valid = lane < nch;
                 const size_t ci = base + fc + (valid ? lane : 0);
-                const int Nc = d.N[ci];
+                const NodeH hc = d.H[ci];                             // one 16-byte load: N, P, meta, first_child
                 const double Wc = d.W[ci];
-                const uint32_t mc = d.meta[ci];
-                const int fcc = d.first_child[ci];
-                const float P32 = d.P[ci];
+                const int Nc = hc.N, fcc = hc.fc;
+                const uint32_t mc = hc.meta;
+                const float P32 = hc.P;
                 unsigned long long winners;
                 if (f64) {                                            // root after Dirichlet mixing: float64 priors => float64 UCB
                     const double P64 = d.rootP[(size_t)g * rc + (valid ? lane : 0)];
@@ -440,11 +445,11 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev dd, const float *__restri
                 // 64 candidates, on every level of a late-game walk.)  First maximum wins: indices below 64 before the others.
                 const bool va = true, vb = lane + AZK_WAVE < nch;
                 const size_t ca = base + fc + lane, cb = base + fc + (vb ? lane + AZK_WAVE : 0);
-                const int Na = d.N[ca], Nb = d.N[cb];
+                const NodeH ha = d.H[ca], hb = d.H[cb];
                 const double Wa = d.W[ca], Wb = d.W[cb];
-                const uint32_t ma = d.meta[ca], mb = d.meta[cb];
-                const int fa = d.first_child[ca], fb = d.first_child[cb];
-                const float Pa = d.P[ca], Pb = d.P[cb];
+                const int Na = ha.N, Nb = hb.N, fa = ha.fc, fb = hb.fc;
+                const uint32_t ma = ha.meta, mb = hb.meta;
+                const float Pa = ha.P, Pb = hb.P;
                 unsigned long long wa, wb;
                 if (f64) {
                     const double Qa = d.rootP[(size_t)g * rc + lane], Qb = d.rootP[(size_t)g * rc + (vb ? lane + AZK_WAVE : 0)];
@@ -480,7 +485,8 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev dd, const float *__restri
                 for (int k = 0; k < 4; k++) {
                     const int i = c0 + lane + AZK_WAVE * k;
                     const size_t ci = base + fc + (i < nch ? i : 0);
-                    Nc[k] = d.N[ci]; Wc[k] = d.W[ci]; mc[k] = d.meta[ci]; fcc[k] = d.first_child[ci]; P32[k] = d.P[ci];
+                    const NodeH hk = d.H[ci];
+                    Nc[k] = hk.N; Wc[k] = d.W[ci]; mc[k] = hk.meta; fcc[k] = hk.fc; P32[k] = hk.P;
                 }
                 if (f64) {                                            // root after Dirichlet mixing: float64 priors by child position
 #pragma unroll
@@ -592,8 +598,8 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev dd, const float *__restri
         for (int i = lane; i < rc; i += AZK_WAVE) d.leaf_cells[(size_t)vi * d.rc_pad + i] = L.board[i];
         for (int i = lane; i <= depth; i += AZK_WAVE) d.path[(size_t)vi * d.path_cap + i] = L.path[i];
         if (vl) {                                                     // virtual loss: the path counts a visit now and a lost game until its value arrives
-            for (int i = lane; i <= depth; i += AZK_WAVE) { const int nd = L.path[i]; d.N[base + nd] += 1; d.W[base + nd] -= 1.0; }
-            if (lane == 0) d.first_child[base + node] = -2;           // "expansion pending": a second slot arriving here gives up
+            for (int i = lane; i <= depth; i += AZK_WAVE) { const int nd = L.path[i]; d.H[base + nd].N += 1; d.W[base + nd] -= 1.0; }
+            if (lane == 0) d.H[base + node].fc = -2;           // "expansion pending": a second slot arriving here gives up
         }
         bool cached = false;
         if (d.cache_entries) {                                        // mcts.py:37-44: key = canonical board bytes
@@ -662,7 +668,7 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev dd, const float *__restri
     if (vl) continue;
     break;
     }
-    if (MULTI && lane == 0) d.sims_done[g] = done_sims;
+    if (MULTI && lane0 == 0) d.sims_done[g] = done_sims;
 }
 
 // Leaf compaction: slot = number of leaf games with a lower index (deterministic order); writes the
@@ -787,9 +793,9 @@ __global__ __launch_bounds__(AZK_WAVE) void k_vanilla(Dev d, int n_sims, uint32_
         if (lane == 0) L.path[0] = 0;
         __syncthreads();
         int node = 0, depth = 0, node_cell = -1, scanned = 0;
-        int fc = uniform_i32(d.first_child[base]);
-        int Np = uniform_i32(d.N[base]);
-        uint32_t nmeta = (uint32_t)uniform_i32((int)d.meta[base]);
+        int fc = uniform_i32(d.H[base].fc);
+        int Np = uniform_i32(d.H[base].N);
+        uint32_t nmeta = (uint32_t)uniform_i32((int)d.H[base].meta);
         for (;;) {                                                    // mcts.py:20-23 with node.select('normal')
             const int nch = meta_nch(nmeta);
             if (nch <= 0) break;
@@ -800,11 +806,12 @@ __global__ __launch_bounds__(AZK_WAVE) void k_vanilla(Dev d, int n_sims, uint32_
             uint32_t bmeta = 0;
             for (int i = lane; i < nch; i += AZK_WAVE) {
                 const size_t ci = base + fc + i;
-                const int Nc = d.N[ci];
+                const NodeH hc = d.H[ci];
+                const int Nc = hc.N;
                 const double Wc = d.W[ci];
                 double u = sqrt(l2 / (double)(Nc + 1));               // utils.py:36,43
                 if (Nc != 0) u = Wc / (double)Nc + u;
-                if (best == 0x7fffffff || u > bu) { bu = u; best = i; bN = Nc; bmeta = d.meta[ci]; bfc = d.first_child[ci]; }
+                if (best == 0x7fffffff || u > bu) { bu = u; best = i; bN = Nc; bmeta = hc.meta; bfc = hc.fc; }
             }
             wave_argmax_first<double>(bu, best);
             best = uniform_i32(best);
@@ -848,12 +855,11 @@ __global__ __launch_bounds__(AZK_WAVE) void k_vanilla(Dev d, int n_sims, uint32_
             if (afc + nv > d.cap) { if (lane == 0) atomicExch(d.err, AZK_ERR_ARENA_FULL); return; }
             for (int i = lane; i < nv; i += AZK_WAVE) {               // node.expand(valid_moves, None, Game): node.py:50-59
                 const size_t idx = base + afc + i;
-                d.N[idx] = 0; d.W[idx] = 0.0; d.P[idx] = 0.f; d.meta[idx] = meta_pack(L.moves[i], 0);
-                d.first_child[idx] = -1;
+                d.H[idx] = NodeH{0, 0.f, meta_pack(L.moves[i], 0), -1}; d.W[idx] = 0.0;
             }
             if (lane == 0) {
-                d.first_child[base + node] = afc;
-                d.meta[base + node] = (d.meta[base + node] & 0xffff0000u) | (uint32_t)nv;
+                d.H[base + node].fc = afc;
+                d.H[base + node].meta = (d.H[base + node].meta & 0xffff0000u) | (uint32_t)nv;
                 d.arena_top[g] = afc + nv;
                 d.counters[(size_t)CNT_CREATED * d.G + g] += nv;
             }
@@ -906,8 +912,7 @@ __global__ void k_begin_search(Dev d) {
     if (g == 0 && d.cache_entries && d.cache_shared) d.cache_stamp[0] += 1u;
     drop_pending_cache_claim(d, g);
     const size_t base = (size_t)g * d.cap;
-    d.N[base] = 0; d.W[base] = 0.0; d.P[base] = 0.f; d.meta[base] = meta_pack(0xffff, 0);
-    d.first_child[base] = -1;
+    d.H[base] = NodeH{0, 0.f, meta_pack(0xffff, 0), -1}; d.W[base] = 0.0;
     d.arena_top[g] = 1; d.root_f64[g] = 0;
     clear_leaf_slots(d, g);
     d.sims_done[g] = 0;
@@ -943,21 +948,21 @@ __global__ __launch_bounds__(AZK_WAVE) void k_root_stats(Dev d, double *pi, doub
     const size_t base = (size_t)g * d.cap;
     const int A = d.g.action_dim;
     LdsView L = carve(d.g, d.path_cap, d.table_size);
-    const int fc = d.first_child[base], nch = meta_nch(d.meta[base]);
+    const int fc = d.H[base].fc, nch = meta_nch(d.H[base].meta);
     for (int a = lane; a < A; a += AZK_WAVE) L.cnt[a] = 0;
     __syncthreads();
     int sum = 0;
     for (int i = lane; i < nch; i += AZK_WAVE) {
-        const int n = d.N[base + fc + i];
-        L.cnt[azk_action_idx(d.g, meta_cell(d.meta[base + fc + i]))] = n;
+        const int n = d.H[base + fc + i].N;
+        L.cnt[azk_action_idx(d.g, meta_cell(d.H[base + fc + i].meta))] = n;
         sum += n;
     }
     sum = wave_sum_i32(sum);
     __syncthreads();
     if (pi) for (int a = lane; a < A; a += AZK_WAVE) pi[(size_t)g * A + a] = (double)L.cnt[a] / (double)sum;
     if (lane == 0) {
-        if (q) q[g] = d.W[base] / (double)d.N[base];
-        if (root_visit) root_visit[g] = d.N[base];
+        if (q) q[g] = d.W[base] / (double)d.H[base].N;
+        if (root_visit) root_visit[g] = d.H[base].N;
     }
 }
 
@@ -970,15 +975,15 @@ __device__ __forceinline__ int advance_one(const Dev &d, LdsView &L, int g, bool
     const GameDesc &gd = d.g;
     const size_t base = (size_t)g * d.cap;
     const int A = gd.action_dim, rc = gd.rc;
-    const int fc = uniform_i32(d.first_child[base]), nch = uniform_i32(meta_nch(d.meta[base]));
+    const int fc = uniform_i32(d.H[base].fc), nch = uniform_i32(meta_nch(d.H[base].meta));
     const int mc = uniform_i32(d.move_count[g]), mover = uniform_i32(d.to_move[g]);
     for (int i = lane; i < rc; i += AZK_WAVE) L.board[i] = d.cells[(size_t)g * d.rc_pad + i];
     for (int a = lane; a < A; a += AZK_WAVE) L.cnt[a] = 0;
     __syncthreads();
     int sum = 0;
     for (int i = lane; i < nch; i += AZK_WAVE) {
-        const int n = d.N[base + fc + i];
-        L.cnt[azk_action_idx(gd, meta_cell(d.meta[base + fc + i]))] = n;
+        const int n = d.H[base + fc + i].N;
+        L.cnt[azk_action_idx(gd, meta_cell(d.H[base + fc + i].meta))] = n;
         sum += n;
     }
     sum = wave_sum_i32(sum);
@@ -1004,19 +1009,19 @@ __device__ __forceinline__ int advance_one(const Dev &d, LdsView &L, int g, bool
         const int act = L.path[0];
         int found = 0x7fffffff;
         for (int i = lane; i < nch; i += AZK_WAVE)
-            if (azk_action_idx(gd, meta_cell(d.meta[base + fc + i])) == act && i < found) found = i;
+            if (azk_action_idx(gd, meta_cell(d.H[base + fc + i].meta)) == act && i < found) found = i;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) { int o = __shfl_xor(found, off); found = o < found ? o : found; }
-        cellc = found != 0x7fffffff ? meta_cell(d.meta[base + fc + found]) : -1;
+        cellc = found != 0x7fffffff ? meta_cell(d.H[base + fc + found].meta) : -1;
     } else {
         // Node.max_visit_child (node.py:76-81): first child with the most visits
         int best = 0x7fffffff, bn = 0;
         for (int i = lane; i < nch; i += AZK_WAVE) {
-            const int n = d.N[base + fc + i];
+            const int n = d.H[base + fc + i].N;
             if (best == 0x7fffffff || n > bn) { bn = n; best = i; }
         }
         wave_argmax_first<int>(bn, best);
-        cellc = meta_cell(d.meta[base + fc + uniform_i32(best)]);
+        cellc = meta_cell(d.H[base + fc + uniform_i32(best)].meta);
     }
     cellc = uniform_i32(cellc);
     if (cellc < 0) {
@@ -1261,8 +1266,7 @@ __device__ __forceinline__ void begin_search_one(const Dev &d, const AsyncDev &p
     if (lane == 0) {
         drop_pending_cache_claim(d, g);
         const size_t base = (size_t)g * d.cap;
-        d.N[base] = 0; d.W[base] = 0.0; d.P[base] = 0.f; d.meta[base] = meta_pack(0xffff, 0);
-        d.first_child[base] = -1;
+        d.H[base] = NodeH{0, 0.f, meta_pack(0xffff, 0), -1}; d.W[base] = 0.0;
         d.arena_top[g] = 1; d.root_f64[g] = 0;
         clear_leaf_slots(d, g);
         d.sims_done[g] = 0;
@@ -1284,7 +1288,7 @@ __global__ __launch_bounds__(AZK_WAVE) void k_move_async(Dev d, AsyncDev p) {
     const int A = d.g.action_dim;
     const size_t base = (size_t)g * d.cap;
     const long long mv = p.slot_moves[g];
-    const double q = d.W[base] / (double)d.N[base];                 // root.value / root.visit (gomoku.py:140), before the tree is reset
+    const double q = d.W[base] / (double)d.H[base].N;                 // root.value / root.visit (gomoku.py:140), before the tree is reset
     int win = -2, dn = 0, sum = 0;
     const double u = noise_uniform(p.seed, (unsigned long long)(p.first_game + g), (int)mv);
     const int cellc = advance_one(d, L, g, true, u, p.sample_until, &win, &dn, &sum);
@@ -1512,7 +1516,7 @@ int32_t azk_create(const azk_config *cfg, azk_engine **out) {
     hipError_t s = hipSuccess;
 #define DA(ptr, count) if (s == hipSuccess) s = dalloc(e, &ptr, (count))
     DA(d.cells, G * d.rc_pad); DA(d.to_move, G); DA(d.move_count, G); DA(d.done, G); DA(d.winner, G);
-    DA(d.N, nodes); DA(d.W, nodes); DA(d.P, nodes); DA(d.meta, nodes); DA(d.first_child, nodes);
+    DA(d.H, nodes); DA(d.W, nodes);
     DA(d.rootP, G * g.rc); DA(d.root_f64, G); DA(d.arena_top, G);
     d.K = cfg->leaves_per_step > 1 ? cfg->leaves_per_step : 1;
     const size_t GV = G * (size_t)d.K;                            // pending-leaf slots
@@ -1927,13 +1931,12 @@ static int32_t fetch_tree(azk_engine *e, int game, HostTree *t, hipStream_t st) 
     const size_t n = (size_t)t->top, base = (size_t)game * d.cap;
     t->N.resize(n); t->first_child.resize(n); t->W.resize(n); t->P.resize(n); t->cell.resize(n); t->nch.resize(n); t->meta.resize(n);
     t->rootP.resize(d.g.rc);
-    HIPCHK(e, hipMemcpyAsync(t->N.data(), d.N + base, n * sizeof(int), hipMemcpyDeviceToHost, st));
-    HIPCHK(e, hipMemcpyAsync(t->first_child.data(), d.first_child + base, n * sizeof(int), hipMemcpyDeviceToHost, st));
+    std::vector<NodeH> recs(n);
+    HIPCHK(e, hipMemcpyAsync(recs.data(), d.H + base, n * sizeof(NodeH), hipMemcpyDeviceToHost, st));
     HIPCHK(e, hipMemcpyAsync(t->W.data(), d.W + base, n * sizeof(double), hipMemcpyDeviceToHost, st));
-    HIPCHK(e, hipMemcpyAsync(t->P.data(), d.P + base, n * sizeof(float), hipMemcpyDeviceToHost, st));
-    HIPCHK(e, hipMemcpyAsync(t->meta.data(), d.meta + base, n * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     HIPCHK(e, hipMemcpyAsync(t->rootP.data(), d.rootP + (size_t)game * d.g.rc, d.g.rc * sizeof(double), hipMemcpyDeviceToHost, st));
     HIPCHK(e, hipStreamSynchronize(st));
+    for (size_t i = 0; i < n; i++) { t->N[i] = recs[i].N; t->first_child[i] = recs[i].fc; t->P[i] = recs[i].P; t->meta[i] = recs[i].meta; }
     for (size_t i = 0; i < n; i++) {
         const int c = (int)(t->meta[i] >> 16);
         t->cell[i] = c == 0xffff ? -1 : c;
