@@ -78,7 +78,8 @@ class EmbedPoolXConsts(C.Structure):
     _fields_ = [("wt_frag", C.c_void_p), ("cpos_tok", C.c_void_p), ("score_tok", C.c_void_p), ("wconst_tok", C.c_void_p),
                 ("xnconst_tok", C.c_void_p), ("z_all", C.c_void_p), ("l_all", C.c_void_p), ("score_msum", C.c_void_p),
                 ("score_ref", C.c_void_p), ("num_heads", C.c_int32), ("ksize", C.c_int32), ("kp", C.c_int32),
-                ("embed_dim", C.c_int32), ("ln_eps", C.c_float), ("wt_scale", C.c_float), ("work_stats", C.c_void_p)]
+                ("embed_dim", C.c_int32), ("ln_eps", C.c_float), ("wt_scale", C.c_float), ("work_stats", C.c_void_p),
+                ("wconst_h16_tok", C.c_void_p), ("pool_scale", C.c_float)]
 
 
 class GemmX(C.Structure):
@@ -1017,12 +1018,13 @@ class EmbedPoolXTables:
     (head-major, converted to accumulator order here); l_all, score_msum, score_ref f32 [16]."""
 
     WT_SCALE = 4096.0      # weights (|w| < 0.2 here) x 2^12: hi and lo fp16 terms both in the normal range down to |w| ~ 6e-5
+    WC_SCALE, XNC_SCALE = 64.0, 16.0     # constant tokens' softmax weights (in (0, 1]) and normalised rows (|x| < 23) as two fp16 terms each
 
     def __init__(self, t, num_heads, ksize, embed_dim, eps=1e-5):
         torch = _torch()
         assert embed_dim == 512
         dev = t["cpos_tok"].device
-        self.t = {k: v.contiguous() for k, v in t.items() if k not in ("wt_ext", "z_all")}
+        self.t = {k: v.contiguous() for k, v in t.items() if k not in ("wt_ext", "z_all")}      # (z_all is rebuilt below from the split constant terms)
         T1 = self.t["cpos_tok"].shape[0]
         for k, shape in dict(cpos_tok=(T1, embed_dim), xnconst_tok=(T1, embed_dim), score_tok=(T1, 16), wconst_tok=(T1, 16), l_all=(16,),
                              score_msum=(16,), score_ref=(16,)).items():
@@ -1037,13 +1039,28 @@ class EmbedPoolXTables:
                 + torch.arange(8, device=dev)[None, None, :])                                             # [KS, 64, 8]
         fh, fl = hi[col[:, None, :, None], kidx[None]], lo[col[:, None, :, None], kidx[None]]              # [33, KS, 64, 8]
         self.t["wt_frag"] = torch.stack([fh, fl], dim=2).contiguous()                                      # [33, KS, 2, 64, 8]
-        # z_all [16 heads, D] -> accumulator order [w][q][lane = 16 l4 + l15][j]: head 4 l4 + j, column 64 w + 4 l15 + q
-        za = t["z_all"].float().view(4, 4, 8, 16, 4)                          # [l4, j, w, l15, q]
+        # the constant tokens' part of the weighted token sum runs on v_mfma_f32_16x16x32_f16 with both operands as (hi, lo) fp16
+        # pairs (all four partial products in two instructions): -wconst * WC_SCALE per (token, head) as one uint32 (hi | lo << 16),
+        # xnconst * XNC_SCALE per (token, 4 columns) as 16 bytes (hi0..hi3, lo0..lo3); the accumulators then run in units of
+        # POOL_SCALE = WC_SCALE * XNC_SCALE (the kernel scales the stone-touched tokens' weights by it, z_all comes pre-scaled)
+        wc, xnc = self.t["wconst_tok"].double(), self.t["xnconst_tok"].double()
+        assert float(wc.max()) <= 1.0 + 1e-6 and float(xnc.abs().max()) * self.XNC_SCALE < 60000.0
+        wh, wl = split_fp16(-wc, self.WC_SCALE)
+        self.t["wconst_h16"] = (wh.view(torch.int16).to(torch.int32) & 0xffff | (wl.view(torch.int16).to(torch.int32) << 16)).contiguous()
+        xh, xl = split_fp16(xnc, self.XNC_SCALE)
+        self.t["xnconst_h16"] = torch.cat([xh.view(T1, embed_dim // 4, 4), xl.view(T1, embed_dim // 4, 4)], dim=2).contiguous()   # [T+1, 128, 8] fp16
+        self.pool_scale = self.WC_SCALE * self.XNC_SCALE
+        wc_eff = -(wh.double() + wl.double()) / self.WC_SCALE                # what the kernel subtracts per dirty token ...
+        xnc_eff = (xh.double() + xl.double()) / self.XNC_SCALE
+        zall = (wc_eff.t() @ xnc_eff) * self.pool_scale                      # ... so the sum over ALL tokens uses the same terms
+        # z_all [16 heads, D] -> accumulator order [g][q][lane = 16 l4 + l15][j]: head 4 l4 + j, column 64 g + 4 l15 + q
+        za = zall.float().view(4, 4, 8, 16, 4)                                # [l4, j, g, l15, q]
         self.t["z_all"] = za.permute(2, 4, 0, 3, 1).reshape(8, 4, 64, 4).contiguous()
         self.tokens, self.num_heads, self.embed_dim = T1 - 1, num_heads, embed_dim
-        self.c = EmbedPoolXConsts(*[self.t[k].data_ptr() for k in ("wt_frag", "cpos_tok", "score_tok", "wconst_tok", "xnconst_tok", "z_all",
+        self.c = EmbedPoolXConsts(*[self.t[k].data_ptr() for k in ("wt_frag", "cpos_tok", "score_tok", "wconst_tok", "xnconst_h16", "z_all",
                                                                   "l_all", "score_msum", "score_ref")],
-                                  num_heads, ksize, kp, embed_dim, float(eps), float(self.WT_SCALE), None)
+                                  num_heads, ksize, kp, embed_dim, float(eps), float(self.WT_SCALE), None,
+                                  self.t["wconst_h16"].data_ptr(), float(self.pool_scale))
         self.work_stats = None
 
     def enable_work_stats(self):

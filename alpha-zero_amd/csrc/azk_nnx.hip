@@ -59,7 +59,8 @@ struct EmbedPoolXArgs {
     const float *cposT;            // [T + 1][512]  bias + positional term per token; row T (the null token) = 0
     const float *scoreT;           // [T + 1][16]   score constants per token (column 15: row mean); row T: -1e30 in the head columns
     const float *wcT;              // [T + 1][16]   softmax weight of the token taken as an empty-patch token; row T = 0
-    const float *xncT;             // [T + 1][512]  normalised empty-patch token (float32); row T = 0
+    const void *xncT;              // [T + 1][128][8] fp16: normalised empty-patch token x 16 as (hi, lo) terms per 4 columns; row T = 0
+    const unsigned *wcH;           // [T + 1][16]   -wc x 64 as (hi | lo << 16) fp16 terms
     const float *zall;             // accumulator order [8 waves][4][64 lanes][4]: ZALL[head 4 (lane>>4) + j][64 w + 4 (lane&15) + q]
     const float *lall;             // [16]
     const float *msum, *sref;      // [16]
@@ -69,36 +70,44 @@ struct EmbedPoolXArgs {
     unsigned long long *wstats;    // optional [2]: boards / 16-token tiles evaluated
     int n, R, Cc, T;
     float eps, wscale_inv;         // 1 / S
+    float pscale;                  // unit of zall and of the Z accumulators (64 x 16: the constant tokens' fp16 terms)
     azk_leaf_source src;
 };
 
-// Eight waves per workgroup (one workgroup per CU: the fp16 hi/lo weight image is 135 KB of LDS), wave w owns the 64 output
-// columns [64 w, 64 w + 64) of every 16-token tile: four 16-column MFMA tiles with column(q, lane) = 64 w + 4 (lane&15) + q, so a
-// lane's four accumulators of a token are four consecutive columns (one 16-byte gather / store), plus the extra tile (head
-// scores, row mean) that every wave computes for itself.  Token patch bits, dirty-token compaction and the leaf ranks are the
-// work of threads 0..255 (one thread per token), exactly as in k_embed_pool_c.
+// One workgroup (four waves, one per SIMD; one workgroup per CU: the fp16 hi / lo weight image is 135 KB of LDS) per board; a
+// WAVE owns whole 16-token tiles - all 512 columns of them - so LayerNorm's row statistics never leave the wave and the tile loop
+// has no barrier: a tile is 132 fp16 MFMAs (33 column tiles x 2 k-steps x hi / lo) and 256 float32 MFMAs (32 column tiles x
+// (4 real + 4 constant) token quads) issued back to back, ~10 k matrix-pipe cycles with the VALU work (bias / positional add,
+// squares, normalisation: ~400 instructions) and the token-indexed gathers interleaved.  (Round 3's first form split the COLUMNS
+// over eight waves and met at a barrier per tile for the sum of squares: 128 us per launch, four times the matrix-pipe time.)
+// Tiles t = wave, wave + 4, ... of the board's compacted dirty-token list; each wave accumulates its own Z[8 heads][512] (128
+// accumulator registers) and L, and the four partial sums meet in LDS at the end of the board, added in a fixed wave order
+// (deterministic: the same board gives the same bits whatever else is in the batch).
+// Column map: column tile ct = 4 g + q covers columns 64 g + 4 (lane&15) + q, so a lane's four accumulators of a token and a
+// group g are four consecutive columns (one 16-byte gather / store).  Token patch bits, compaction and leaf ranks: one thread per
+// token, exactly as in k_embed_pool_c.
 template <int NC, int KSZ, int NH, bool SRC>
-__global__ __launch_bounds__(512, 2) void k_embed_pool_x(EmbedPoolXArgs a) {
+__global__ __launch_bounds__(256, 1) void k_embed_pool_x(EmbedPoolXArgs a) {
     constexpr int KS = (NC * KSZ * KSZ + 31) / 32;
     constexpr int D = 512;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint4 *alut = (uint4 *)smem;                                  // [256] A fragment (fp16 0 / 1) of 8 patch bits
-    float *part = (float *)(alut + 256);                          // [2 parities][16 rows][8 waves] partial sums of squares
     const int Tp16 = ((a.T + 15) >> 4) << 4;
-    uint4 *pbits = (uint4 *)(part + 256);                         // [Tp16] patch bits of the compacted dirty tokens
+    uint4 *pbits = alut + 256;                                    // [Tp16] patch bits of the compacted dirty tokens
     int *dlist = (int *)(pbits + Tp16);                           // [Tp16] their token indices (null token = T past the end)
     int *scan = dlist + Tp16;                                     // [4..7] dirty counts per wave, [8] next board, [9] game, [16..31] class totals
-    uint4 *rankv = (uint4 *)(scan + 32);                          // SRC: [256 threads] ranks of the thread's first eight games, 16 bits each
+    float *lred = (float *)(scan + 32);                           // [4 waves][16] partial softmax denominators
+    f32x4 *zred = (f32x4 *)(lred + 64);                           // [3 waves][8 column tiles][32 lanes] partial Z of one column quarter
+    uint4 *rankv = (uint4 *)(zred + 3 * 8 * 32);                  // SRC: [256 threads] ranks of the thread's first eight games, 16 bits each
     uint4 *bimg = rankv + (SRC ? 256 : 0);                        // [33 column tiles][KS][2][64 lanes] weight B fragments
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
-    const bool tokw = wave < 4;                                   // the waves that hold one token per thread
     int nvalid, my_lo = 0, my_per = 0;
     unsigned long long cb_lo = 0ull, cb_hi = 0ull;
-    constexpr int NF = 33 * KS * 2 * 64, PER = (NF + 511) / 512;
+    constexpr int NF = 33 * KS * 2 * 64, PER = (NF + 255) / 256;
     unsigned long long myflags = 0ull;
-    if (SRC && tokw) {
+    if (SRC) {
         my_per = ((((a.src.n_games + 255) >> 8) + 7) >> 3) << 3;
         my_lo = tid * my_per;
         if (my_lo < a.src.flag_bytes) myflags = *(const unsigned long long *)(a.src.leaf_flag + my_lo);
@@ -106,22 +115,21 @@ __global__ __launch_bounds__(512, 2) void k_embed_pool_x(EmbedPoolXArgs a) {
     static_assert(NF % 64 == 0, "the weight image is copied in whole 1 KiB wave pieces");
 #pragma unroll
     for (int i = 0; i < PER; i++)
-        if (512 * i + 64 * wave < NF)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)((const uint4 *)a.wt_frag + tid + 512 * i),
-                                             (__attribute__((address_space(3))) void *)(bimg + 512 * i + 64 * wave), 16, 0, 0);
+        if (256 * i + 64 * wave < NF)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)((const uint4 *)a.wt_frag + tid + 256 * i),
+                                             (__attribute__((address_space(3))) void *)(bimg + 256 * i + 64 * wave), 16, 0, 0);
     if (SRC) {
         // leaf ranks: (cost class descending, game index ascending), every workgroup derives the same ones - see k_embed_pool_c
         unsigned long long c_lo = 0ull, c_hi = 0ull;
-        if (tokw)
-            for (int w = 0; w < my_per; w += 8)
-                if (my_lo + w < a.src.flag_bytes) {
-                    const unsigned long long f = w == 0 ? myflags : *(const unsigned long long *)(a.src.leaf_flag + my_lo + w);
+        for (int w = 0; w < my_per; w += 8)
+            if (my_lo + w < a.src.flag_bytes) {
+                const unsigned long long f = w == 0 ? myflags : *(const unsigned long long *)(a.src.leaf_flag + my_lo + w);
 #pragma unroll
-                    for (int q = 0; q < 8; q++) {
-                        const unsigned c = (unsigned)((f >> (8 * q)) & 0xffull);
-                        if (c) { if (c <= 4) c_lo += 1ull << (16 * (c - 1)); else c_hi += 1ull << (16 * (c - 5)); }
-                    }
+                for (int q = 0; q < 8; q++) {
+                    const unsigned c = (unsigned)((f >> (8 * q)) & 0xffull);
+                    if (c) { if (c <= 4) c_lo += 1ull << (16 * (c - 1)); else c_hi += 1ull << (16 * (c - 5)); }
                 }
+            }
         unsigned long long i_lo = c_lo, i_hi = c_hi;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
@@ -129,7 +137,7 @@ __global__ __launch_bounds__(512, 2) void k_embed_pool_x(EmbedPoolXArgs a) {
             if (lane >= off) { i_lo += v_lo; i_hi += v_hi; }
         }
         unsigned long long *wtot = (unsigned long long *)(scan + 16);           // [4 waves][2]
-        if (tokw && lane == 63) { wtot[2 * wave] = i_lo; wtot[2 * wave + 1] = i_hi; }
+        if (lane == 63) { wtot[2 * wave] = i_lo; wtot[2 * wave + 1] = i_hi; }
         __syncthreads();
         unsigned long long b_lo = 0ull, b_hi = 0ull, t_lo = 0ull, t_hi = 0ull;
         for (int w = 0; w < 4; w++) {
@@ -146,22 +154,20 @@ __global__ __launch_bounds__(512, 2) void k_embed_pool_x(EmbedPoolXArgs a) {
             start += tot;
         }
         nvalid = (int)start;
-        if (tokw) {
-            unsigned run = 0;
-            unsigned myrank[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+        unsigned run = 0;
+        unsigned myrank[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
 #pragma unroll
-            for (int q = 0; q < 8; q++) {
-                const unsigned c = (unsigned)((myflags >> (8 * q)) & 0xffull);
-                unsigned r = 0xffffu;
-                if (c) {
-                    const unsigned bsel = (unsigned)(((c <= 4 ? cb_lo : cb_hi) >> (16 * ((c - 1) & 3))) & 0xffffull);
-                    r = bsel + ((run >> (4 * (c - 1))) & 0xfu);
-                    run += 1u << (4 * (c - 1));
-                }
-                myrank[q >> 1] = (q & 1) ? ((myrank[q >> 1] & 0x0000ffffu) | (r << 16)) : ((myrank[q >> 1] & 0xffff0000u) | r);
+        for (int q = 0; q < 8; q++) {
+            const unsigned c = (unsigned)((myflags >> (8 * q)) & 0xffull);
+            unsigned r = 0xffffu;
+            if (c) {
+                const unsigned bsel = (unsigned)(((c <= 4 ? cb_lo : cb_hi) >> (16 * ((c - 1) & 3))) & 0xffffull);
+                r = bsel + ((run >> (4 * (c - 1))) & 0xfu);
+                run += 1u << (4 * (c - 1));
             }
-            rankv[tid] = make_uint4(myrank[0], myrank[1], myrank[2], myrank[3]);
+            myrank[q >> 1] = (q & 1) ? ((myrank[q >> 1] & 0x0000ffffu) | (r << 16)) : ((myrank[q >> 1] & 0xffff0000u) | r);
         }
+        rankv[tid] = make_uint4(myrank[0], myrank[1], myrank[2], myrank[3]);
         if (blockIdx.x == 0 && tid == 0) { *a.src.n_leaf = nvalid; if (a.src.cache_stamp) *a.src.cache_stamp += 1u; }
     } else {
         nvalid = a.count ? min(a.n, *a.count) : a.n;
@@ -171,8 +177,8 @@ __global__ __launch_bounds__(512, 2) void k_embed_pool_x(EmbedPoolXArgs a) {
     if (board >= nvalid) __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): no LDS-DMA may outlive the workgroup
     if (board < nvalid) {
     union BF { uint4 u; f16x8 v; };
-    const uint4 *bwv = bimg + (size_t)wave * 4 * KS * 2 * 64 + lane, *bev = bimg + (size_t)32 * KS * 2 * 64 + lane;
-    if (tid < 256) {
+    const uint4 *bfr = bimg + lane;                               // fragment (ct, s, p) at bfr[((ct * KS + s) * 2 + p) * 64]
+    {
         unsigned r[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) r[i] = (((tid >> (2 * i)) & 1) ? 0x3C00u : 0u) | (((tid >> (2 * i + 1)) & 1) ? 0x3C000000u : 0u);   // fp16 1.0
@@ -181,9 +187,9 @@ __global__ __launch_bounds__(512, 2) void k_embed_pool_x(EmbedPoolXArgs a) {
     constexpr int ksz = KSZ, kk = KSZ * KSZ, pad = KSZ / 2;
     const int RC = a.R * a.Cc, T = a.T, ncell = NC * RC;
     const float msum = a.msum[l15], sref = a.sref[l15], lall = a.lall[l15];
-    const int colofs = 64 * wave + 4 * l15;
+    const int colofs = 4 * l15;
     const float sinv = a.wscale_inv;
-    int par = 0, nxt = 0;
+    int nxt = 0;
     __syncthreads();
 
     while (board < nvalid) {
@@ -198,38 +204,26 @@ __global__ __launch_bounds__(512, 2) void k_embed_pool_x(EmbedPoolXArgs a) {
         int game = 0, player = 0;
         if (SRC) {
             int g = -1;
-            if (tokw) {
-                const uint4 rk = rankv[tid];
-                const unsigned myrank[4] = {rk.x, rk.y, rk.z, rk.w};
+            const uint4 rk = rankv[tid];
+            const unsigned myrank[4] = {rk.x, rk.y, rk.z, rk.w};
 #pragma unroll
-                for (int q = 0; q < 8; q++) if (((myrank[q >> 1] >> (16 * (q & 1))) & 0xffffu) == (unsigned)board) g = my_lo + q;
-                if (my_per > 8) {
-                    unsigned long long run2 = 0ull;
-                    for (int w = 0; w < my_per; w++) {
-                        const unsigned c = my_lo + w < a.src.flag_bytes ? (unsigned)a.src.leaf_flag[my_lo + w] : 0u;
-                        if (!c) continue;
-                        const unsigned r = (unsigned)(((c <= 4 ? cb_lo : cb_hi) >> (16 * ((c - 1) & 3))) & 0xffffull) + (unsigned)((run2 >> (8 * (c - 1))) & 0xffull);
-                        run2 += 1ull << (8 * (c - 1));
-                        if (w >= 8 && r == (unsigned)board) g = my_lo + w;
-                    }
+            for (int q = 0; q < 8; q++) if (((myrank[q >> 1] >> (16 * (q & 1))) & 0xffffu) == (unsigned)board) g = my_lo + q;
+            if (my_per > 8) {
+                unsigned long long run2 = 0ull;
+                for (int w = 0; w < my_per; w++) {
+                    const unsigned c = my_lo + w < a.src.flag_bytes ? (unsigned)a.src.leaf_flag[my_lo + w] : 0u;
+                    if (!c) continue;
+                    const unsigned r = (unsigned)(((c <= 4 ? cb_lo : cb_hi) >> (16 * ((c - 1) & 3))) & 0xffffull) + (unsigned)((run2 >> (8 * (c - 1))) & 0xffull);
+                    run2 += 1ull << (8 * (c - 1));
+                    if (w >= 8 && r == (unsigned)board) g = my_lo + w;
                 }
             }
             if (g >= 0) { scan[9] = g; a.src.leaf_slot[g] = board; }
             __syncthreads();
             game = scan[9];
         }
-        // the workgroup's Z starts at the constant part
-        f32x4 Z[4];
-        if (l4 < (NH + 3) / 4) {
-            const f32x4 *zp = (const f32x4 *)a.zall + (size_t)wave * 4 * 64 + lane;
-#pragma unroll
-            for (int q = 0; q < 4; q++) Z[q] = zp[q * 64];
-        } else {
-#pragma unroll
-            for (int q = 0; q < 4; q++) Z[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
         unsigned long long plo = 0, phi = 0;
-        if (tokw) {                                     // (wave-uniform: waves 4-7 hold no token)
+        {
             unsigned wbits = 0;                         // lane i holds bits [32 (i-1), 32 i) of the board bit string (lane 0: zeros)
             constexpr int NQ = 8;
             if (ncell <= 64 * NQ) {
@@ -312,10 +306,10 @@ __global__ __launch_bounds__(512, 2) void k_embed_pool_x(EmbedPoolXArgs a) {
         }
         const bool dirty = (plo | phi) != 0ull;
         const unsigned long long dm = __ballot(dirty);
-        if (tokw && lane == 0) scan[4 + wave] = __popcll(dm);
-        __syncthreads();                                  // (also: every wave is done with the previous board's lists)
+        if (lane == 0) scan[4 + wave] = __popcll(dm);
+        __syncthreads();                                  // (also: every wave is done with the previous board's lists and reduction buffers)
         int dpos = __popcll(dm & ((1ull << lane) - 1ull));
-        for (int w = 0; w < wave && w < 4; w++) dpos += scan[4 + w];
+        for (int w = 0; w < wave; w++) dpos += scan[4 + w];
         const int nd = scan[4] + scan[5] + scan[6] + scan[7];
         const int ntile = (nd + 15) >> 4;
         if (dirty) {
@@ -325,34 +319,44 @@ __global__ __launch_bounds__(512, 2) void k_embed_pool_x(EmbedPoolXArgs a) {
         if (tid < 16 && nd + tid < ntile * 16) { dlist[nd + tid] = T; pbits[nd + tid] = make_uint4(0u, 0u, 0u, 0u); }   // null tokens fill the last tile
         __syncthreads();
         ws_boards += 1; ws_tiles += ntile;                  // (one pair of atomics per workgroup at the very end, never in front of the gathers)
+        if (tid == 0) {                                     // next board: the ticket's round trip hides under the tiles
+            __builtin_amdgcn_sched_barrier(0);
+            nxt = atomicAdd(a.sched, 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
 
+        // ---- this wave's tiles: t = wave, wave + 4, ...; its own partial Z (8 groups x 4 column tiles) and L ----
+        f32x4 Z[8][4];
+#pragma unroll
+        for (int g = 0; g < 8; g++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) Z[g][q] = f32x4{0.f, 0.f, 0.f, 0.f};
         float L = 0.f;
-        // the per-token constants are gathered by token index and run one phase ahead of their use (see k_embed_pool_c)
-        f32x4 c0[4], xr[4], scn, wcn;
-        auto gather_a = [&](int t) {
-            const int4 tk = *(const int4 *)(dlist + 16 * t + 4 * l4);
+        for (int tile = wave; tile < ntile; tile += 4) {
+            const int4 tk = *(const int4 *)(dlist + 16 * tile + 4 * l4);
             const int tks[4] = {tk.x, tk.y, tk.z, tk.w};
+            unsigned trow[4];                              // byte offset of this lane's 16 bytes in a token's 2 KB table row
+#pragma unroll
+            for (int r = 0; r < 4; r++) trow[r] = ((unsigned)tks[r] * (unsigned)D + (unsigned)colofs) * 4u;
+            f32x4 scn, wcn;
+            unsigned wch[4];
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                const unsigned orow = ((unsigned)tks[r] * (unsigned)D + (unsigned)colofs) * 4u, osc = ((unsigned)tks[r] * 16u + (unsigned)l15) * 4u;
-                c0[r] = *(const f32x4 *)((const char *)a.cposT + orow);
+                const unsigned osc = ((unsigned)tks[r] * 16u + (unsigned)l15) * 4u;
                 scn[r] = *(const float *)((const char *)a.scoreT + osc);
                 wcn[r] = *(const float *)((const char *)a.wcT + osc);
+                wch[r] = *(const unsigned *)((const char *)a.wcH + osc);
             }
-        };
-        auto gather_x = [&](int t) {
-            const int4 tk = *(const int4 *)(dlist + 16 * t + 4 * l4);
-            const int tks[4] = {tk.x, tk.y, tk.z, tk.w};
+            // Token-indexed table rows (16 bytes per token and group of 64 columns) run through ONE stream of sixteen row sets - the
+            // bias + positional rows of groups 0..7, then the constant tokens' normalised rows of groups 0..7 - in a ring of three
+            // buffers: a set is requested when the set three places earlier has been consumed, so three gathers are always in flight
+            f32x4 cb[3][4];
+            auto gather_rows = [&](int j) {
+                const char *tab = j < 8 ? (const char *)a.cposT : (const char *)a.xncT;
 #pragma unroll
-            for (int r = 0; r < 4; r++) xr[r] = *(const f32x4 *)((const char *)a.xncT + ((unsigned)tks[r] * (unsigned)D + (unsigned)colofs) * 4u);
-        };
-        if (ntile > 0) { gather_a(0); gather_x(0); }
-        for (int tile = 0; tile < ntile; tile++) {
-            if (tile == 0 && tid == 0) {                  // next board: the round trip hides under this tile
-                __builtin_amdgcn_sched_barrier(0);
-                nxt = atomicAdd(a.sched, 1);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+                for (int r = 0; r < 4; r++) cb[j % 3][r] = *(const f32x4 *)(tab + trow[r] + 256u * (unsigned)(j & 7));
+            };
+            gather_rows(0); gather_rows(1); gather_rows(2);
             // ---- A fragments: 8 patch bits of this lane's token (row lane&15) per k-step -> table (fp16 0 / 1) ----
             const uint4 pb = pbits[tile * 16 + l15];
             const unsigned pw[4] = {pb.x, pb.y, pb.z, pb.w};
@@ -363,93 +367,156 @@ __global__ __launch_bounds__(512, 2) void k_embed_pool_x(EmbedPoolXArgs a) {
                 af.u = alut[(pw[s] >> (8 * l4)) & 0xffu];
                 afrag[s] = af.v;
             }
-            f32x4 acc[4];
+            // ---- x = conv / S + (bias + positional term) for all 32 column tiles (+ the extra tile: head scores, row mean); the hi and
+            //      lo halves of the weights go through the same accumulator: every product is exact (0/1 inputs), the sum is float32.
+            //      One wave per SIMD: nobody else hides the LDS latency of the weight fragments, so they run through a ring of three
+            //      4-fragment steps issued TWO steps (eight MFMAs) ahead of their use; the four column tiles of a step are independent
+            //      accumulator chains. ----
+            constexpr int SPG = 2 * KS, NSTEP = 8 * SPG;          // steps (k-step, hi / lo) per group; steps per tile
+            f32x4 acc[8][4];
             f32x4 acce = {0.f, 0.f, 0.f, 0.f};
+            float ssq[4] = {0.f, 0.f, 0.f, 0.f};
+            BF ring[3][4], ext[SPG];
+            auto issue = [&](int t) {                             // step t = (group t / SPG, k-step (t % SPG) >> 1, half t & 1)
+                const int g = t / SPG, sp = t % SPG;
 #pragma unroll
-            for (int q = 0; q < 4; q++) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-            // hi and lo halves of the weights go through the same accumulator: every product is exact (0/1 inputs), the sum is float32
+                for (int q = 0; q < 4; q++) ring[t % 3][q].u = bfr[((4 * g + q) * SPG + sp) * 64];
+            };
+            auto conv_valu = [&](int g) {                         // bias / positional add and squares of group g
 #pragma unroll
-            for (int s = 0; s < KS; s++)
+                for (int r = 0; r < 4; r++)
 #pragma unroll
-                for (int p = 0; p < 2; p++) {
-                    { BF b; b.u = bev[(s * 2 + p) * 64]; acce = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag[s], b.v, acce, 0, 0, 0); }
+                    for (int q = 0; q < 4; q++) {
+                        const float x = __builtin_fmaf(acc[g][q][r], sinv, cb[g % 3][r][q]);
+                        acc[g][q][r] = x;
+                        ssq[r] = __builtin_fmaf(x, x, ssq[r]);
+                    }
+            };
 #pragma unroll
-                    for (int q = 0; q < 4; q++) { BF b; b.u = bwv[((q * KS + s) * 2 + p) * 64]; acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag[s], b.v, acc[q], 0, 0, 0); }
+            for (int sp = 0; sp < SPG; sp++) ext[sp].u = bfr[(32 * SPG + sp) * 64];
+            issue(0); issue(1);
+#pragma unroll
+            for (int g = 0; g < 8; g++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) acc[g][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < NSTEP; t++) {
+                const int g = t / SPG, sp = t % SPG;
+                if (t + 2 < NSTEP) issue(t + 2);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < 4; q++) acc[g][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag[sp >> 1], ring[t % 3][q].v, acc[g][q], 0, 0, 0);
+                if (t < SPG) acce = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag[t >> 1], ext[t].v, acce, 0, 0, 0);     // the extra tile rides along the first group
+                if (sp == 0 && g > 0) {
+                    conv_valu(g - 1);                             // (the previous group's MFMAs have retired, this group's are in flight)
+                    gather_rows(g - 1 + 3);
                 }
-            // ---- x = conv / S + (bias + positional term); score columns likewise ----
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            conv_valu(7);
+            gather_rows(10);
+            // ---- LayerNorm statistics of the full rows, inside the wave (mean = column 15 of the extra tile) ----
+            float mean[4], rstd[4], shift[4], w[4];
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                acc[0][r] = __builtin_fmaf(acc[0][r], sinv, c0[r][0]); acc[1][r] = __builtin_fmaf(acc[1][r], sinv, c0[r][1]);
-                acc[2][r] = __builtin_fmaf(acc[2][r], sinv, c0[r][2]); acc[3][r] = __builtin_fmaf(acc[3][r], sinv, c0[r][3]);
                 acce[r] = __builtin_fmaf(acce[r], sinv, scn[r]);
-            }
-            const f32x4 wc = wcn;
-            __builtin_amdgcn_sched_barrier(0);
-            const int tnext = min(tile + 1, ntile - 1);          // (the last tile refetches itself: no branch around loads)
-            gather_a(tnext);
-            __builtin_amdgcn_sched_barrier(0);
-            // ---- LayerNorm statistics of the full rows (mean = GEMM column 15 of the extra tile) ----
-            float mean[4], ssq[4];
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
                 mean[r] = __shfl(acce[r], (lane & 48) | 15);
-                float s2 = acc[0][r] * acc[0][r];
-                s2 = __builtin_fmaf(acc[1][r], acc[1][r], s2); s2 = __builtin_fmaf(acc[2][r], acc[2][r], s2); s2 = __builtin_fmaf(acc[3][r], acc[3][r], s2);
-                ssq[r] = row16_sum(s2);
-            }
-            // part layout [parity][row 0..15][wave 0..7]
-            if (l15 == 0) {
-#pragma unroll
-                for (int r = 0; r < 4; r++) part[(par * 16 + 4 * l4 + r) * 8 + wave] = ssq[r];
-            }
-            __syncthreads();
-            float rstd[4], shift[4];
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const f32x4 *pp = (const f32x4 *)(part + (par * 16 + 4 * l4 + r) * 8);
-                const f32x4 p0 = pp[0], p1 = pp[1];
-                const float s2 = ((p0[0] + p0[1]) + (p0[2] + p0[3])) + ((p1[0] + p1[1]) + (p1[2] + p1[3]));
+                const float s2 = row16_sum(ssq[r]);
                 const float var = __builtin_fmaf(-mean[r], mean[r], s2 * (1.0f / (float)D));
                 rstd[r] = 1.0f / sqrtf(fmaxf(var, 0.f) + a.eps);
                 shift[r] = -mean[r] * rstd[r];
-            }
-            par ^= 1;
-            // ---- scores (head = lane&15, tokens = rows) and softmax weights against the static reference ----
-            float w[4];
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
+                // scores (head = lane&15, tokens = rows) and softmax weights against the static reference
                 const float sc = rstd[r] * __builtin_fmaf(-mean[r], msum, acce[r]);
                 w[r] = exp_acc(sc - sref);
             }
-            L += ((w[0] - wc[0]) + (w[1] - wc[1])) + ((w[2] - wc[2]) + (w[3] - wc[3]));
-            // ---- Z += W^T Xn - Wc^T Xnc on v_mfma_f32_16x16x4_f32: instruction r sums over token 4 (lane>>4) + r of every lane group;
-            //      A[head = lane&15][k = lane>>4] = w / -wc, B[k = lane>>4][column = lane&15] = xn / xnc: both already where they are ----
+            L += ((w[0] - wcn[0]) + (w[1] - wcn[1])) + ((w[2] - wcn[2]) + (w[3] - wcn[3]));
+            // ---- Z += W^T Xn - Wc^T Xnc (in units of pscale).  The stone-touched tokens: both operands are run-time float32, so they
+            //      run on v_mfma_f32_16x16x4_f32 - instruction r sums over token 4 (lane>>4) + r of every lane group, A[head = lane&15]
+            //      [k = lane>>4] = w, B[k][column = lane&15] = xn, both already where they are.  The same tokens as CONSTANTS: -wc and xnc
+            //      are tables, stored as (hi, lo) fp16 terms, and one v_mfma_f32_16x16x32_f16 holds a lane group's four tokens twice in its
+            //      eight k-slots - B = (xh0..3, xl0..3) against A1 = (wh0..3, wh0..3) and against A2 = (wl0..3, wl0..3): all four partial
+            //      products in two 16-cycle instructions instead of four 32-cycle ones ----
+            f32x4 ws;
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
+            for (int r = 0; r < 4; r++) ws[r] = w[r] * a.pscale;
+            BF A1, A2;
+            A1.u.x = __builtin_amdgcn_perm(wch[1], wch[0], 0x05040100u); A1.u.y = __builtin_amdgcn_perm(wch[3], wch[2], 0x05040100u);
+            A1.u.z = A1.u.x; A1.u.w = A1.u.y;
+            A2.u.x = __builtin_amdgcn_perm(wch[1], wch[0], 0x07060302u); A2.u.y = __builtin_amdgcn_perm(wch[3], wch[2], 0x07060302u);
+            A2.u.z = A2.u.x; A2.u.w = A2.u.y;
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const float xn = __builtin_fmaf(acc[q][r], rstd[r], shift[r]);       // (x - mean) * rstd
-                    Z[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[r], xn, Z[q], 0, 0, 0);
+            for (int g = 0; g < 8; g++) {
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const float xn = __builtin_fmaf(acc[g][q][r], rstd[r], shift[r]);       // (x - mean) * rstd
+                        Z[g][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(ws[r], xn, Z[g][q], 0, 0, 0);
+                    }
+                // a gathered row = 16 bytes = (xh0 xh1 | xh2 xh3 | xl0 xl1 | xl2 xl3) of the token's four columns of this group
+                uint4 rw[4];
+#pragma unroll
+                for (int r = 0; r < 4; r++) rw[r] = __builtin_bit_cast(uint4, cb[(8 + g) % 3][r]);
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const unsigned sel = (q & 1) ? 0x07060302u : 0x05040100u;          // half q & 1 of each of two dwords
+                    const unsigned h0 = q < 2 ? rw[0].x : rw[0].y, h1 = q < 2 ? rw[1].x : rw[1].y, h2 = q < 2 ? rw[2].x : rw[2].y, h3 = q < 2 ? rw[3].x : rw[3].y;
+                    const unsigned l0 = q < 2 ? rw[0].z : rw[0].w, l1 = q < 2 ? rw[1].z : rw[1].w, l2 = q < 2 ? rw[2].z : rw[2].w, l3 = q < 2 ? rw[3].z : rw[3].w;
+                    BF B1;
+                    B1.u.x = __builtin_amdgcn_perm(h1, h0, sel); B1.u.y = __builtin_amdgcn_perm(h3, h2, sel);
+                    B1.u.z = __builtin_amdgcn_perm(l1, l0, sel); B1.u.w = __builtin_amdgcn_perm(l3, l2, sel);
+                    Z[g][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A1.v, B1.v, Z[g][q], 0, 0, 0);
+                    Z[g][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A2.v, B1.v, Z[g][q], 0, 0, 0);
                 }
-#pragma unroll
-                for (int r = 0; r < 4; r++) Z[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(-wc[r], xr[r][q], Z[q], 0, 0, 0);
+                if (8 + g + 3 < 16) gather_rows(8 + g + 3);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
-            gather_x(tnext);
         }
-        if (ntile == 0 && tid == 0) nxt = atomicAdd(a.sched, 1);
-        // ---- z[b][h][:] = (ZALL + Z)[h][:] / (LALL + L)[h] ----
+        // ---- the four waves' partial sums meet: L first, then Z one column quarter at a time (12 KB of LDS), fixed order ----
         float Lt = L + __shfl_xor(L, 16);
         Lt += __shfl_xor(Lt, 32);
-        Lt += lall;
+        if (l4 == 0) lred[wave * 16 + l15] = Lt;
+        constexpr int HL = 16 * ((NH + 3) / 4);             // lanes holding real heads (lane>>4 < NH / 4)
+        // the constant part of this wave's own column quarter (global, L2): requested now, used in its round below (a load inside
+        // the round would put a memory round trip between two barriers, four times per board)
+        f32x4 zq[2][4];
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int head = 4 * l4 + j;
-            const float Lh = __shfl(Lt, head & 15);
-            if (head < NH) {
-                const float inv = 1.0f / Lh;
-                *(f32x4 *)(a.z + ((size_t)board * NH + head) * D + colofs) = f32x4{Z[0][j] * inv, Z[1][j] * inv, Z[2][j] * inv, Z[3][j] * inv};
+        for (int gg = 0; gg < 2; gg++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) zq[gg][q] = *((const f32x4 *)a.zall + ((size_t)(2 * wave + gg) * 4 + q) * 64 + lane);
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            if (wave != c && lane < HL) {
+                const int slot = wave < c ? wave : wave - 1;
+#pragma unroll
+                for (int gg = 0; gg < 2; gg++)
+#pragma unroll
+                    for (int q = 0; q < 4; q++) zred[(slot * 8 + gg * 4 + q) * 32 + lane] = Z[2 * c + gg][q];
             }
+            __syncthreads();
+            if (wave == c && lane < HL) {
+                const float Ltot = lall + ((lred[l15] + lred[16 + l15]) + (lred[32 + l15] + lred[48 + l15]));
+                float inv[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) inv[j] = 1.0f / (__shfl(Ltot, (4 * l4 + j) & 15) * a.pscale);      // (Z runs in units of pscale)
+#pragma unroll
+                for (int gg = 0; gg < 2; gg++) {
+                    f32x4 zs[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        zs[q] = ((Z[2 * c + gg][q] + zred[(0 * 8 + gg * 4 + q) * 32 + lane]) + (zred[(1 * 8 + gg * 4 + q) * 32 + lane] + zred[(2 * 8 + gg * 4 + q) * 32 + lane])) + zq[gg][q];
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const int head = 4 * l4 + j;
+                        if (head < NH)
+                            *(f32x4 *)(a.z + ((size_t)board * NH + head) * D + 64 * (2 * c + gg) + colofs) =
+                                f32x4{zs[0][j] * inv[j], zs[1][j] * inv[j], zs[2][j] * inv[j], zs[3][j] * inv[j]};
+                    }
+                }
+            }
+            __syncthreads();
         }
         if (tid == 0) {
             if (nxt == nvalid - 1) a.sched[0] = 0;          // the holder of the last ticket leaves the queue zero for the next launch
@@ -466,7 +533,7 @@ template <int NC, int KSZ, int NH, bool SRC>
 int launch_embed_pool_x(const EmbedPoolXArgs &a, hipStream_t st) {
     constexpr int KS = (NC * KSZ * KSZ + 31) / 32;
     const int tp16 = ((a.T + 15) / 16) * 16;
-    const int lds = 256 * 16 + 1024 + tp16 * 16 + tp16 * 4 + 128 + (SRC ? 256 * 16 : 0) + 33 * KS * 2 * 64 * 16;     // 149 KB at KS = 2: one workgroup per CU
+    const int lds = 256 * 16 + tp16 * 16 + tp16 * 4 + 128 + 256 + 3 * 8 * 32 * 16 + (SRC ? 256 * 16 : 0) + 33 * KS * 2 * 64 * 16;     // 156 KB at KS = 2: one workgroup per CU
     if (lds > 160 * 1024) return AZK_ERR_ARG;
     static bool attr_set = false;
     if (!attr_set) {
@@ -479,7 +546,7 @@ int launch_embed_pool_x(const EmbedPoolXArgs &a, hipStream_t st) {
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
     }
     const int blocks = a.n < cus ? a.n : cus;                      // one resident workgroup per CU; each pulls boards until the queue is dry
-    k_embed_pool_x<NC, KSZ, NH, SRC><<<blocks, 512, lds, st>>>(a);
+    k_embed_pool_x<NC, KSZ, NH, SRC><<<blocks, 256, lds, st>>>(a);
     return hipGetLastError() == hipSuccess ? AZK_OK : AZK_ERR_HIP;
 }
 
@@ -490,6 +557,7 @@ static int32_t embed_pool_x_impl(const void *boards_dev, int32_t boards_are_f32,
                                  const int32_t *n_valid_dev, int32_t *sched_dev, void *stream) {
     if ((!boards_dev && !src) || !k || !z_out_dev || !sched_dev) return AZK_ERR_ARG;
     if (!k->wt_frag || !k->cpos_tok || !k->score_tok || !k->wconst_tok || !k->xnconst_tok || !k->z_all || !k->l_all || !k->score_msum || !k->score_ref) return AZK_ERR_ARG;
+    if (!k->wconst_h16_tok || !(k->pool_scale > 0.f)) return AZK_ERR_ARG;
     const int ksize = k->ksize, kp = k->kp;
     if (n < 0 || channels < 1 || rows < 1 || cols < 1 || ksize < 1 || (ksize & 1) == 0 || ksize > 7) return AZK_ERR_ARG;
     if (kp != (channels * ksize * ksize + 31) / 32 * 32 || kp > 64) return AZK_ERR_ARG;     // the hi/lo image must fit one CU's LDS
@@ -504,6 +572,7 @@ static int32_t embed_pool_x_impl(const void *boards_dev, int32_t boards_are_f32,
     a.msum = k->score_msum; a.sref = k->score_ref; a.z = z_out_dev; a.count = n_valid_dev; a.sched = sched_dev;
     a.wstats = (unsigned long long *)k->work_stats;
     a.n = n; a.R = rows; a.Cc = cols; a.T = rows * cols + 1; a.eps = k->ln_eps; a.wscale_inv = 1.0f / k->wt_scale;
+    a.wcH = k->wconst_h16_tok; a.pscale = k->pool_scale;
     if (src) a.src = *src;
     hipStream_t st = (hipStream_t)stream;
     const int nh = k->num_heads;

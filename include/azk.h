@@ -446,15 +446,20 @@ int32_t azk_nn_heads_finalize_sum(const float *partials_dev, int32_t nsplit, int
  * statistics / softmax / GELU(erf) / tanh in float32.  Tables as azk_embed_pool_consts, all float32, with
  *   wt_frag     fp16 [33 column tiles][kp/32][2: hi, lo][64 lanes][8]: element [ct][s][p][l][i] = the p-th fp16 term of
  *               wt_scale * wt_ext[col(ct, l)][32 s + 8 (l>>4) + i], col(ct, l) = 64 (ct>>2) + 4 (l&15) + (ct&3) for ct < 32, 512 + (l&15) for ct = 32
- *   z_all       f32 [8][4][64][4]: sum_t wconst[t][h] * xnconst[t][col] at [w][q][lane][j]: h = 4 (lane>>4) + j, col = 64 w + 4 (lane&15) + q
+ *   xnconst_tok fp16 [T+1][128][8]: the constant tokens' normalised rows x 16 as two fp16 terms, per 4 columns (hi0..hi3, lo0..lo3)
+ *   score_ref   per head the largest score of a constant token (their weights wconst are in (0, 1]); score bound <= 40 required
+ *   z_all       f32 [8][4][64][4]: pool_scale * sum_t wconst[t][h] * xnconst[t][col] (from the fp16 terms) at [g][q][lane][j]: h = 4 (lane>>4) + j, col = 64 g + 4 (lane&15) + q
  * kp <= 64 (the hi / lo image must fit one CU's LDS), tokens <= 256.  z_out float32 [n][H][512]. */
 typedef struct azk_embed_pool_x_consts {
     const void *wt_frag;
-    const float *cpos_tok, *score_tok, *wconst_tok, *xnconst_tok;
+    const float *cpos_tok, *score_tok, *wconst_tok;
+    const void *xnconst_tok;
     const float *z_all, *l_all, *score_msum, *score_ref;
     int32_t num_heads, ksize, kp, embed_dim;
     float ln_eps, wt_scale;
     uint64_t *work_stats;   /* optional device uint64 [2]: += boards evaluated, += 16-token tiles evaluated */
+    const uint32_t *wconst_h16_tok;   /* [T+1][16]: -wconst * 64 as two fp16 terms, hi | lo << 16 */
+    float pool_scale;                 /* 64 * 16: the unit of z_all and of the kernel's accumulators */
 } azk_embed_pool_x_consts;
 int32_t azk_nnx_embed_pool(const void *boards_dev, int32_t boards_are_f32, const azk_embed_pool_x_consts *consts,
                            float *z_out_f32_dev, int32_t n, int32_t channels, int32_t rows, int32_t cols,
