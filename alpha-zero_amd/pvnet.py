@@ -369,16 +369,16 @@ class PolicyValueNet:
                       x2=torch.empty((rows, D), **f32), st1=torch.empty((rows, D // 64, 2), **f32), st2=torch.empty((rows, D // 64, 2), **f32))
             self._tail_ws[key] = ws
         ws = {k_: (v[:n] if k_ != "rows" else v) for k_, v in ws.items()}
-        azk.nnx_gemm(z.view(n, H * D), e["WvX"], D // H, D, azk.TAIL_BF16, nbatch=H, a_batch_stride=D, out=ws["u"], count=cnt)
-        azk.nnx_gemm(ws["u"], e["WoX"], D, D, azk.TAIL_BF16, bias=e["bias1"], out=ws["x1"], stats_out=ws["st1"], count=cnt)
-        azk.nnx_gemm(ws["x1"], e["W0GX"], 4 * D, D, azk.TAIL_GELU, bias=e["b0G"], out=ws["hh"], a_stats=ws["st1"], count=cnt)
-        azk.nnx_gemm(ws["hh"], e["W3X"], D, 4 * D, azk.TAIL_RESID, bias=e["b3"], resid=ws["x1"], out=ws["x2"], stats_out=ws["st2"], count=cnt)
+        self._launch(azk.nnx_gemm, z.view(n, H * D), e["WvX"], D // H, D, azk.TAIL_BF16, nbatch=H, a_batch_stride=D, out=ws["u"], count=cnt)
+        self._launch(azk.nnx_gemm, ws["u"], e["WoX"], D, D, azk.TAIL_BF16, bias=e["bias1"], out=ws["x1"], stats_out=ws["st1"], count=cnt)
+        self._launch(azk.nnx_gemm, ws["x1"], e["W0GX"], 4 * D, D, azk.TAIL_GELU, bias=e["b0G"], out=ws["hh"], a_stats=ws["st1"], count=cnt)
+        self._launch(azk.nnx_gemm, ws["hh"], e["W3X"], D, 4 * D, azk.TAIL_RESID, bias=e["b3"], resid=ws["x1"], out=ws["x2"], stats_out=ws["st2"], count=cnt)
         if self.out_buffers is not None:
             lb, vb = self.out_buffers
         else:
             lb = torch.empty((n, A), dtype=torch.float32, device=dev)
             vb = torch.empty(n, dtype=torch.float32, device=dev)
-        azk.nnx_gemm(ws["x2"], e["WhGX"], 256, D, azk.TAIL_HEADS, bias=e["bhG"], a_stats=ws["st2"], logits=lb, values=vb, action_dim=A, count=cnt)
+        self._launch(azk.nnx_gemm, ws["x2"], e["WhGX"], 256, D, azk.TAIL_HEADS, bias=e["bhG"], a_stats=ws["st2"], logits=lb, values=vb, action_dim=A, count=cnt)
         return lb, (vb if self.out_buffers is not None else vb[:, None])
 
     def _prepare_folded(self):
@@ -601,16 +601,16 @@ class PolicyValueNet:
                       st2=torch.empty((rows, D // 64, 2), dtype=torch.float32, device=dev))
             self._tail_ws[key] = ws
         ws = {k_: (v[:n] if k_ != "rows" else v) for k_, v in ws.items()}
-        azk.nn_tail_gemm(z.view(n, H * D), f["WvHP"], D // H, D, azk.TAIL_BF16, nbatch=H, a_batch_stride=D, out=ws["u"], count=cnt)
-        azk.nn_tail_gemm(ws["u"], f["WoP"], D, D, azk.TAIL_BF16, bias=f["bias1_f"], out=ws["x1"], stats_out=ws["st1"], count=cnt)
-        azk.nn_tail_gemm(ws["x1"], f["W0GP"], 4 * D, D, azk.TAIL_GELU, bias=f["b0G_f"], out=ws["hh"], a_stats=ws["st1"], count=cnt)
-        azk.nn_tail_gemm(ws["hh"], f["W3P"], D, 4 * D, azk.TAIL_RESID, bias=f["b3_f"], resid=ws["x1"], out=ws["x2"], stats_out=ws["st2"], count=cnt)
+        self._launch(azk.nn_tail_gemm, z.view(n, H * D), f["WvHP"], D // H, D, azk.TAIL_BF16, nbatch=H, a_batch_stride=D, out=ws["u"], count=cnt)
+        self._launch(azk.nn_tail_gemm, ws["u"], f["WoP"], D, D, azk.TAIL_BF16, bias=f["bias1_f"], out=ws["x1"], stats_out=ws["st1"], count=cnt)
+        self._launch(azk.nn_tail_gemm, ws["x1"], f["W0GP"], 4 * D, D, azk.TAIL_GELU, bias=f["b0G_f"], out=ws["hh"], a_stats=ws["st1"], count=cnt)
+        self._launch(azk.nn_tail_gemm, ws["hh"], f["W3P"], D, 4 * D, azk.TAIL_RESID, bias=f["b3_f"], resid=ws["x1"], out=ws["x2"], stats_out=ws["st2"], count=cnt)
         if self.out_buffers is not None:
             lb, vb = self.out_buffers
         else:
             lb = torch.empty((n, A), dtype=torch.float32, device=dev)
             vb = torch.empty(n, dtype=torch.float32, device=dev)
-        azk.nn_tail_gemm(ws["x2"], f["WhGP"], f["bhG_f"].numel(), D, azk.TAIL_HEADS, bias=f["bhG_f"], a_stats=ws["st2"], logits=lb, values=vb,
+        self._launch(azk.nn_tail_gemm, ws["x2"], f["WhGP"], f["bhG_f"].numel(), D, azk.TAIL_HEADS, bias=f["bhG_f"], a_stats=ws["st2"], logits=lb, values=vb,
                          action_dim=A, count=cnt)
         return lb, (vb if self.out_buffers is not None else vb[:, None])
 
@@ -618,12 +618,25 @@ class PolicyValueNet:
         """depth-1 cls row after the pooled tokens zn [n, H, D]: composed projection, MLP, final norm, merged heads."""
         # kernel_timers = (k_embed_pool, k_tail) on the fused path, (k_embed, k_cls_pool, k_tail) on the two-kernel path
         kt = self.kernel_timers[-1] if self.kernel_timers is not None and len(self.kernel_timers) >= (2 if self.fused_embed_pool else 3) else None
-        if kt is None:
-            return self._tail_fast(z)
-        kt.start()                                   # HIP events around the whole tail (its launches back to back on this stream)
-        out = self._tail_fast(z)
-        kt.stop()
-        return out
+        self._tail_timer = kt                        # the hand-written chains bracket EACH launch with its own event pair (the host-side gap
+        try:                                         # between two eager launches is longer than these kernels: one pair around all five would time the host)
+            if kt is None or z.dtype == torch.float32 or (getattr(self, "chain_tail", False) and self.use_chain_tail):
+                return self._tail_fast(z)
+            kt.start()
+            out = self._tail_fast(z)
+            kt.stop()
+            return out
+        finally:
+            self._tail_timer = None
+
+    def _launch(self, fn, *args, **kw):
+        """One tail launch, bracketed by the tail timer's own event pair when a sampled step is being timed."""
+        kt = getattr(self, "_tail_timer", None)
+        if kt is not None:
+            kt.start()
+        fn(*args, **kw)
+        if kt is not None:
+            kt.stop()
 
     def _tail_fast(self, z):
         if z.dtype == torch.float32:

@@ -457,6 +457,8 @@ def main():
                                     "~9 KB per board (board in, z out): bound by VALU/MFMA issue and LDS, not HBM"})
         ch = kt.children.get("k_tail")                  # the cls-row tail (five k_tail_gemm launches, or the library GEMMs): MFMA-bound
         ms = ch.mean_ms() if ch else None
+        if ms and args.nn_path == "clsfold" and (exact or args.tail == "chain"):
+            ms *= 5                                     # the timer holds one event pair per launch of the five-launch chain: their sum per step
         if ms and args.nn_path == "clsfold":
             Hh, dh = cfg.num_heads, Dm // cfg.num_heads
             # value projection per head + output projection + MLP up + MLP down + merged heads, per row
@@ -468,8 +470,8 @@ def main():
                             "achieved": fl / (ms * 1e-3) / 1e12, "peak": tail_peak, "unit": "TFLOP/s",
                             "frac": fl / (ms * 1e-3) / 1e12 / tail_peak, "avg_launch_us": ms * 1e3,
                             "algorithmic_flops_per_launch": fl, "traffic": None, "event_samples": len(ch.pairs),
-                            "note": f"{per_row} flop per row x {rows:.0f} rows per step; avg_launch_us = the whole tail (all of its launches, HIP events "
-                                    "around them); the per-launch split is in the rocprofv3 summary under profiles/"})
+                            "note": f"{per_row} flop per row x {rows:.0f} rows per step; avg_launch_us = the SUM of the tail's launches per step (each "
+                                    "launch bracketed by its own HIP event pair); the per-launch split is in the rocprofv3 summary under profiles/"})
         dominant = max((k for k in kernels if not k["kernel"].startswith(("k_tail_gemm x5", "library tail", "k_gemm_x x5"))), key=lambda k: k["avg_launch_us"]) if kernels else None
         flops = {"cls": cfg.flops_cls(), "full": cfg.flops_full(), "clsfold": flops_clsfold(cfg)}[args.nn_path]
         # Boards the network really processed: eager stepping and the hand-written tail chain honour the live leaf count; only the
@@ -511,16 +513,30 @@ def main():
             "plies_in_window": plies_all, "counters_rank0": c, "roofline": dominant, "roofline_puct": roof, "kernel_rooflines": kernels,
         }
         try:        # what this evaluator does to the search results, measured on the reference's recorded positions (tools/measure_nn_parity.py)
-            par = json.load(open(os.path.join(ROOT, "profiles", "r02_nn_parity.json")))
+            par = json.load(open(os.path.join(ROOT, "profiles", "r03_nn_parity.json")))
+            fp32_line = None
+            try:    # the fp32-accurate evaluator's own bench line (same workload, same box family), so that the headline and the 1e-5 claim sit on one page
+                fl = json.loads(open(os.path.join(ROOT, "profiles", "r03_bench_fp32.json")).read().strip().splitlines()[-1])
+                fp32_line = {"games_per_sec": fl["value"], "sims_per_sec": fl["sims_per_sec"], "ms_per_step": fl["ms_per_step"],
+                             "command": "python bench.py --nn-dtype fp32", "source": "profiles/r03_bench_fp32.json"}
+            except Exception:
+                pass
+            exact_par = {"evaluator": "hand-written fp32-accurate kernels (csrc/azk_nnx.hip: fp16 hi/lo conv on the 0/1 board, f32 MFMA elsewhere)",
+                         "logits_vs_reference_seed0": par["kat_vs_reference_seed0"].get("fp32_clsfold"),
+                         "visit_policy_vs_fp32_full": par["search_vs_fp32_full"].get("fp32_clsfold"), "bench_line": fp32_line}
             if args.nn_dtype == "bf16":
                 out["parity"] = {"tree_and_rules": "bit-exact vs the oracle / the reference's golden vectors (tests/test_gpu_engine.py)",
                                  "evaluator_vs_reference_fp32": par["kat_vs_reference_seed0"].get(f"bf16_{args.nn_path}"),
                                  "visit_policy_vs_fp32_evaluator": par["search_vs_fp32_full"]["bf16_clsfold"],
-                                 "note": "north_star's 1e-5 bar on visit-count policies holds for the fp32 evaluator (delta = 0, --nn-dtype fp32 line); "
-                                         "the bf16 evaluator changes a few visits in a few positions (numbers above; tests/test_gpu_parity_nn.py)",
-                                 "source": "profiles/r02_nn_parity.json"}
+                                 "fp32_accurate_evaluator": exact_par,
+                                 "note": "north_star's 1e-5 bar on visit-count policies holds for the fp32-accurate evaluator (delta = 0 on all 92 recorded positions, "
+                                         "--nn-dtype fp32 line quoted above); the bf16 evaluator of this line changes a few visits in a few positions "
+                                         "(tests/test_gpu_parity_nn.py, tests/test_gpu_exact.py)",
+                                 "source": "profiles/r03_nn_parity.json"}
             else:
-                out["parity"] = {"visit_policy_vs_fp32_full": par["search_vs_fp32_full"]["fp32_cls"], "source": "profiles/r02_nn_parity.json"}
+                out["parity"] = {"tree_and_rules": "bit-exact vs the oracle / the reference's golden vectors (tests/test_gpu_engine.py)",
+                                 "fp32_accurate_evaluator" if exact else "torch_fp32_evaluator": exact_par if exact else par["search_vs_fp32_full"]["fp32_cls"],
+                                 "source": "profiles/r03_nn_parity.json"}
         except Exception:
             pass
         out["tree_launches_per_move"] = launches / runner.n_split / args.steps
