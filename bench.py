@@ -396,9 +396,9 @@ def main():
         roof = None
         traffic, traffic_src, pmc = None, None, {}
         try:        # HBM bytes per k_tree launch from the PMC passes committed under profiles/ (FETCH_SIZE + WRITE_SIZE)
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")))
             traffic = next(v["bytes_per_launch"] for k_, v in pmc.items() if k_.startswith("k_tree<true, true"))
-            traffic_src = "profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same workload)"
+            traffic_src = "profiles/r03_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same workload)"
         except Exception:
             pass
         if tree_ms:
