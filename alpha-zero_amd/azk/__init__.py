@@ -32,7 +32,7 @@ SYMBOLS = [
     "azk_nn_gemm_rows", "azk_nn_layernorm_sum", "azk_nn_heads_finalize_sum", "azk_nn_ln_heads",
     "azk_leaf_source_of", "azk_nn_embed_pool_leaves", "azk_nn_embed_pool_compact", "azk_nn_embed_pool_compact_leaves",
     "azk_nn_tail_gemm", "azk_begin_search_budget", "azk_search_unfinished",
-    "azk_nnx_embed_pool", "azk_nnx_embed_pool_leaves", "azk_nnx_gemm",
+    "azk_nnx_embed_pool", "azk_nnx_embed_pool_leaves", "azk_nnx_gemm", "azk_nnx_gemm_h",
     "azk_async_begin", "azk_async_step", "azk_async_drain", "azk_async_set_budget",
 ]
 
@@ -90,6 +90,16 @@ class GemmX(C.Structure):
                 ("a_stats", C.c_void_p), ("stats_out", C.c_void_p), ("out_f32", C.c_void_p), ("ldo", C.c_int32),
                 ("resid_f32", C.c_void_p), ("ldr", C.c_int32), ("logits_out", C.c_void_p), ("values_out", C.c_void_p),
                 ("action_dim", C.c_int32)]
+
+
+class GemmH(C.Structure):
+    """azk_gemm_h (include/azk.h): one link of the cls-row tail on fp16 (hi, lo) operand planes."""
+    _fields_ = [("a_hi", C.c_void_p), ("a_lo", C.c_void_p), ("a_f32", C.c_void_p), ("lda", C.c_int32), ("a_batch_stride", C.c_int32),
+                ("w_packed", C.c_void_p), ("m", C.c_int32), ("n_out", C.c_int32), ("k", C.c_int32), ("nbatch", C.c_int32),
+                ("n_valid", C.c_void_p), ("bias", C.c_void_p), ("col_sums", C.c_void_p), ("layernorm_a", C.c_int32), ("epilogue", C.c_int32),
+                ("ln_eps", C.c_float), ("a_scale", C.c_float), ("w_scale", C.c_float), ("a_stats", C.c_void_p), ("stats_out", C.c_void_p),
+                ("out_hi", C.c_void_p), ("out_lo", C.c_void_p), ("out_f32", C.c_void_p), ("ldo", C.c_int32), ("resid_f32", C.c_void_p),
+                ("ldr", C.c_int32), ("logits_out", C.c_void_p), ("values_out", C.c_void_p), ("action_dim", C.c_int32)]
 
 
 class AsyncConfig(C.Structure):
@@ -191,6 +201,7 @@ def lib():
     L.azk_nnx_embed_pool.argtypes = [vp, i32, C.POINTER(EmbedPoolXConsts), vp, i32, i32, i32, i32, vp, vp, vp]
     L.azk_nnx_embed_pool_leaves.argtypes = [C.POINTER(LeafSource), C.POINTER(EmbedPoolXConsts), vp, vp, vp]
     L.azk_nnx_gemm.argtypes = [C.POINTER(GemmX), vp]
+    L.azk_nnx_gemm_h.argtypes = [C.POINTER(GemmH), vp]
     L.azk_async_begin.argtypes = [vp, C.POINTER(AsyncConfig), vp]
     L.azk_async_step.argtypes = [vp, vp, vp, i32, vp]
     L.azk_async_set_budget.argtypes = [vp, i32, i32, vp]
@@ -1141,3 +1152,63 @@ def nnx_gemm(a, w_packed, n_out, k, epilogue=TAIL_BF16, nbatch=1, a_batch_stride
     rc = lib().azk_nnx_gemm(C.byref(d), _stream())
     if rc != 0:
         raise AzkError(f"azk_nnx_gemm failed ({rc})")
+
+
+GEMM_H_A_SCALE, GEMM_H_W_SCALE = 16.0, 256.0      # activations x 16, weights x 256 before the fp16 (hi, lo) split (azk_nnx_gemm_h)
+
+
+def pack_linear_weight_h(w):
+    """nn.Linear weight [n_out, k] (float64 / float32) -> (fp16 planes in azk_nnx_gemm_h's fragment order
+    [n_out/64][k/32][4][2][64][8], float32 col_sums [n_out padded] = sum_k of the RECONSTRUCTED weights)."""
+    torch = _torch()
+    n_out, k = w.shape
+    assert k % 32 == 0
+    npad = (n_out + 63) // 64 * 64
+    wp = torch.zeros(npad, k, dtype=torch.float64, device=w.device)
+    wp[:n_out] = w.double()
+    assert float(wp.abs().max()) * GEMM_H_W_SCALE < 60000.0
+    hi, lo = split_fp16(wp, GEMM_H_W_SCALE)
+    # [g, l15, c, s, l4, i] -> [g, s, c, plane, l4, l15, i]
+    f = lambda t: t.view(npad // 64, 16, 4, k // 32, 4, 8).permute(0, 3, 2, 4, 1, 5)
+    packed = torch.stack([f(hi), f(lo)], dim=3).contiguous()
+    csum = ((hi.double() + lo.double()) / GEMM_H_W_SCALE).sum(1).float().contiguous()
+    return packed, csum
+
+
+def nnx_gemm_h(a, w_packed, n_out, k, epilogue=TAIL_BF16, nbatch=1, a_batch_stride=0, bias=None, col_sums=None, out=None, out_f32=None,
+               resid=None, a_stats=None, stats_out=None, logits=None, values=None, action_dim=0, count=None, eps=1e-5):
+    """One link of the fp32-accurate tail on fp16 (hi, lo) planes (azk_nnx_gemm_h).  a: a float32 tensor [m, lda] (split on the fly)
+    or a (hi, lo) pair of fp16 tensors; out: a (hi, lo) pair of fp16 tensors [m, nbatch * n_out] and / or out_f32."""
+    torch = _torch()
+    d = GemmH()
+    if isinstance(a, (tuple, list)):
+        ah, al = a
+        assert ah.dtype == torch.float16 and al.dtype == torch.float16 and ah.stride(1) == 1 and ah.stride(0) == al.stride(0)
+        d.a_hi, d.a_lo, d.lda, m = ah.data_ptr(), al.data_ptr(), ah.stride(0), ah.shape[0]
+    else:
+        assert a.dtype == torch.float32 and a.stride(1) == 1
+        d.a_f32, d.lda, m = a.data_ptr(), a.stride(0), a.shape[0]
+    d.a_batch_stride, d.w_packed = int(a_batch_stride), w_packed.data_ptr()
+    d.m, d.n_out, d.k, d.nbatch = m, int(n_out), int(k), int(nbatch)
+    d.n_valid = count.data_ptr() if count is not None else None
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.col_sums = col_sums.data_ptr() if col_sums is not None else None
+    d.layernorm_a, d.epilogue, d.ln_eps = (1 if a_stats is not None else 0), int(epilogue), float(eps)
+    d.a_scale, d.w_scale = GEMM_H_A_SCALE, GEMM_H_W_SCALE
+    d.a_stats = a_stats.data_ptr() if a_stats is not None else None
+    d.stats_out = stats_out.data_ptr() if stats_out is not None else None
+    if out is not None:
+        oh, ol = out
+        assert oh.dtype == torch.float16 and ol.dtype == torch.float16 and oh.stride(1) == 1 and oh.stride(0) == ol.stride(0)
+        d.out_hi, d.out_lo, d.ldo = oh.data_ptr(), ol.data_ptr(), oh.stride(0)
+    if out_f32 is not None:
+        assert out_f32.dtype == torch.float32 and out_f32.stride(1) == 1 and (out is None or out_f32.stride(0) == out[0].stride(0))
+        d.out_f32, d.ldo = out_f32.data_ptr(), out_f32.stride(0)
+    if resid is not None:
+        assert resid.dtype == torch.float32 and resid.stride(1) == 1
+        d.resid_f32, d.ldr = resid.data_ptr(), resid.stride(0)
+    if logits is not None:
+        d.logits_out, d.values_out, d.action_dim = logits.data_ptr(), values.data_ptr(), int(action_dim)
+    rc = lib().azk_nnx_gemm_h(C.byref(d), _stream())
+    if rc != 0:
+        raise AzkError(f"azk_nnx_gemm_h failed ({rc})")

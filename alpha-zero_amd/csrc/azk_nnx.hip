@@ -811,3 +811,261 @@ extern "C" int32_t azk_nnx_gemm(const azk_gemm_x *t, void *stream) {
     if (t->epilogue == X_EPI_RESID) return launch_gemm_x<X_EPI_RESID, 0, 4, 128>(a, st);
     return launch_gemm_x<X_EPI_HEADS, 0, 4, 128>(a, st);
 }
+
+// =====================================================================================================
+// k_gemm_h: the same links on the fp16 matrix pipe with every operand carried as TWO fp16 terms (x S = hi + lo: 22 significant
+// bits, the products hi*hi + hi*lo + lo*hi exact in the float32 accumulator; the dropped lo*lo term is 2^-22 relative).
+//   v_mfma_f32_16x16x4_f32 runs at the float32 VECTOR rate: the two wide links of the tail are 32.8 k matrix-pipe cycles per wave
+//   on it (31 us each at the clock these loops hold).  Three v_mfma_f32_16x16x32_f16 per 32-wide k-step instead of eight f32
+//   instructions of twice the length is 5.3x less pipe time at the same operand bytes (4 B per element either way).
+//   Activations travel between the links as (hi, lo) planes written by the PRODUCING epilogue (four VALU per element, once),
+//   scaled by 16; the first link reads the float32 z of k_embed_pool_x and splits on the fly (each element is read by one wave only).
+//   Weights: (hi, lo) planes of w x 256 in fragment order Wp[N/64][K/32][4][2][64 lanes][8].
+//   LayerNorm cannot be applied to split operands on the fly, so it moves into the epilogue: with the row's mean and rstd (from the
+//   producer's partial sums, as before) LN(x) W'^T = rstd (x W'^T - mean csum), csum[n] = sum_k W'[n][k] precomputed.
+// =====================================================================================================
+namespace {
+
+struct GemmHArgs {
+    const _Float16 *Ahi, *Alo; const float *Af32; int lda, a_batch;
+    const uint4 *Wp; long long w_batch;          // uint4 elements between batches
+    int M, N, nbatch;
+    const int *count;
+    const float *bias, *csum;                    // [nbatch * N]; csum: LayerNorm mode only
+    float inv_scale, a_scale;                    // 1 / (16 * 256); 16
+    _Float16 *ohi, *olo; float *of32; int ldo;   // output planes (x a_scale) and / or float32
+    const float *resid; int ldr;
+    float ln_eps;
+    const float *stats_in; float *stats_out;
+    float *logits, *values; int action_dim;
+};
+
+// nn.GELU (erf form), erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7: 3e-7 on a hidden activation, below this path's 22-bit
+// operands) - a dozen instructions; erff costs fifty, and the wide link's epilogue runs it on 32 values per lane
+__device__ __forceinline__ float gelu_as(float x) {
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = 1.0f / (1.0f + 0.3275911f * z);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float erf_abs = 1.0f - poly * __expf(-z * z);
+    return 0.5f * x * (1.0f + copysignf(erf_abs, x));
+}
+
+template <int EPI, int LNA, int AIN, int NWK, int KW>      // AIN 1: float32 A, split on the fly
+__global__ __launch_bounds__(256, 1) void k_gemm_h(GemmHArgs a) {
+    constexpr int RT = 2, K = KW * NWK, S32 = K / 32, NCH = KW / 32;
+    constexpr int RING = NCH >= 4 ? 4 : NCH, AHEAD = RING - 1;        // chunks of loads in flight ahead of the MFMAs
+    __shared__ f32x4 kred[NWK > 1 ? (NWK - 1) * RT * 4 * 64 : 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, l4 = lane >> 4;
+    // (every kernel argument is wanted in SGPRs HERE: left alone, the compiler fetches the count pointer first, waits for the count, and
+    //  only then goes back to the argument segment for the rest - one more dependent scalar round trip before the first load)
+    asm volatile("" :: "s"(a.Ahi), "s"(a.Alo), "s"(a.Af32), "s"(a.Wp), "s"(a.bias), "s"(a.csum), "s"(a.ohi), "s"(a.olo), "s"(a.of32), "s"(a.resid),
+                 "s"(a.stats_in), "s"(a.stats_out), "s"(a.logits), "s"(a.values), "s"(a.lda), "s"(a.ldo), "s"(a.ldr), "s"(a.N), "s"(a.nbatch), "s"(a.M),
+                 "s"(a.a_batch), "s"(a.w_batch), "s"(a.inv_scale), "s"(a.a_scale), "s"(a.ln_eps), "s"(a.action_dim));
+    const int nvalid = a.count ? min(a.M, *a.count) : a.M;
+    const int wk = NWK > 1 ? wave : 0;
+    const int wr = NWK > 1 ? 0 : (wave >> 1), wc = NWK > 1 ? 0 : (wave & 1);
+    constexpr int WROWS = NWK > 1 ? 16 * RT : 32 * RT, WCOLS = NWK > 1 ? 64 : 128;
+    const int rtiles = (nvalid + WROWS - 1) / WROWS, ctiles = a.N / WCOLS;
+    const int nitems = rtiles * ctiles * a.nbatch;
+    union HF { uint4 u; f16x8 v; };
+    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+        if (NWK > 1 && item != (int)blockIdx.x) __syncthreads();
+        const int ct = item % ctiles, r2 = item / ctiles, rt = r2 % rtiles, b = r2 / rtiles;
+        const int row0 = rt * WROWS + wr * 16 * RT, g = ct * (WCOLS / 64) + wc;
+        size_t aoff[RT];
+#pragma unroll
+        for (int i = 0; i < RT; i++) aoff[i] = (size_t)min(row0 + 16 * i + l15, a.M - 1) * a.lda + (size_t)b * a.a_batch + KW * wk + 8 * l4;
+        const uint4 *bp = a.Wp + (size_t)b * a.w_batch + ((size_t)g * S32 + (size_t)NCH * wk) * 8 * 64 + lane;
+        f32x4 acc[RT][4];
+#pragma unroll
+        for (int i = 0; i < RT; i++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) acc[i][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        HF ah[RING][RT], al[RING][RT], bw[RING][4][2];
+        f32x4 af[AIN == 1 ? RING : 1][RT][2];
+        auto fetch = [&](int ch) {
+            const int u = ch % RING;
+#pragma unroll
+            for (int i = 0; i < RT; i++) {
+                if (AIN == 1) { af[u][i][0] = *(const f32x4 *)(a.Af32 + aoff[i] + 32 * ch); af[u][i][1] = *(const f32x4 *)(a.Af32 + aoff[i] + 32 * ch + 4); }
+                else { ah[u][i].u = *(const uint4 *)(a.Ahi + aoff[i] + 32 * ch); al[u][i].u = *(const uint4 *)(a.Alo + aoff[i] + 32 * ch); }
+            }
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+#pragma unroll
+                for (int p = 0; p < 2; p++) bw[u][c][p].u = bp[((ch * 4 + c) * 2 + p) * 64];
+        };
+        // every operand of the epilogue is requested HERE, in front of the k loop (behind it each of them would be a memory round trip
+        // of its own): bias, column sums, the residual rows, and the LayerNorm partial sums of this wave's 32 rows - lane (row lane&15,
+        // quarter lane>>4) takes 16 of the row's 64 bytes, the row's mean / rstd then sit in the lanes with lane&15 = row
+        const int col0 = b * a.N + 64 * g + 4 * l15;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f}, cs = {0.f, 0.f, 0.f, 0.f};
+        if (a.bias) bv = *(const f32x4 *)(a.bias + col0);
+        if (LNA) cs = *(const f32x4 *)(a.csum + col0);
+        f32x4 st[LNA ? RT : 1];
+        if (LNA) {
+#pragma unroll
+            for (int i = 0; i < RT; i++) st[i] = *((const f32x4 *)(a.stats_in + (size_t)min(row0 + 16 * i + l15, a.M - 1) * 16) + l4);
+        }
+        f32x4 rr[EPI == X_EPI_RESID ? RT : 1][4];
+        if (EPI == X_EPI_RESID && (NWK == 1 || wave == 0)) {
+#pragma unroll
+            for (int i = 0; i < RT; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) rr[i][j] = *(const f32x4 *)(a.resid + (size_t)min(row0 + 16 * i + 4 * l4 + j, a.M - 1) * a.ldr + col0);
+        }
+#pragma unroll
+        for (int ch = 0; ch < AHEAD && ch < NCH; ch++) fetch(ch);
+#pragma unroll
+        for (int ch = 0; ch < NCH; ch++) {
+            const int u = ch % RING;
+            if (ch + AHEAD < NCH) fetch(ch + AHEAD);
+            __builtin_amdgcn_sched_barrier(0);                // (the loads AHEAD chunks ahead are issued before this chunk's MFMAs)
+            if (AIN == 1) {
+#pragma unroll
+                for (int i = 0; i < RT; i++)
+#pragma unroll
+                    for (int e = 0; e < 8; e++) {
+                        const float x = af[u][i][e >> 2][e & 3] * a.a_scale;
+                        const _Float16 h = (_Float16)x;
+                        ah[u][i].v[e] = h;
+                        al[u][i].v[e] = (_Float16)(x - (float)h);
+                    }
+            }
+            // term by term over the eight accumulators: eight independent MFMAs between two that touch the same accumulator
+#pragma unroll
+            for (int term = 0; term < 3; term++)
+#pragma unroll
+                for (int i = 0; i < RT; i++)
+#pragma unroll
+                    for (int c = 0; c < 4; c++)
+                        acc[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(term == 2 ? al[u][i].v : ah[u][i].v, bw[u][c][term == 1 ? 1 : 0].v, acc[i][c], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (row0 >= nvalid) continue;
+        if (NWK > 1) {
+            if (wave > 0) {
+#pragma unroll
+                for (int i = 0; i < RT; i++)
+#pragma unroll
+                    for (int c = 0; c < 4; c++) kred[((wave - 1) * RT * 4 + i * 4 + c) * 64 + lane] = acc[i][c];
+            }
+            __syncthreads();
+            if (wave > 0) continue;
+#pragma unroll
+            for (int w = 1; w < NWK; w++)
+#pragma unroll
+                for (int i = 0; i < RT; i++)
+#pragma unroll
+                    for (int c = 0; c < 4; c++) acc[i][c] += kred[((w - 1) * RT * 4 + i * 4 + c) * 64 + lane];
+        }
+        // LayerNorm statistics: the groups are added in a fixed order (deterministic); lane (lane&15 = row) ends up with the row's mean
+        // and rstd, the epilogue's rows 16 i + 4 (lane>>4) + j fetch them from lane 4 (lane>>4) + j
+        float rstd[RT][4], mshift[RT][4];
+        if (LNA) {
+#pragma unroll
+            for (int i = 0; i < RT; i++) {
+                float s1 = st[i][0] + st[i][2], s2 = st[i][1] + st[i][3];
+                s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+                s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+                const float mean = s1 * (1.0f / 512.0f);
+                const float rs = 1.0f / sqrtf(fmaxf(__builtin_fmaf(-mean, mean, s2 * (1.0f / 512.0f)), 0.f) + a.ln_eps);
+#pragma unroll
+                for (int j = 0; j < 4; j++) { rstd[i][j] = __shfl(rs, 4 * l4 + j); mshift[i][j] = __shfl(mean, 4 * l4 + j); }
+            }
+        }
+        const int ngr = a.nbatch * (a.N >> 6), gr = b * (a.N >> 6) + g;
+#pragma unroll
+        for (int i = 0; i < RT; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int row = row0 + 16 * i + 4 * l4 + j;
+                f32x4 v = {acc[i][0][j], acc[i][1][j], acc[i][2][j], acc[i][3][j]};
+                v = v * a.inv_scale;
+                if (LNA) v = (v - cs * mshift[i][j]) * rstd[i][j];
+                v += bv;
+                if (EPI == X_EPI_HEADS) {
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        const int col = col0 + c;
+                        if (row < nvalid && col < a.action_dim) a.logits[(size_t)row * a.action_dim + col] = v[c];
+                        if (row < nvalid && col == a.action_dim) a.values[row] = tanhf(v[c]);
+                    }
+                    continue;
+                }
+                if (EPI == X_EPI_GELU) {
+#pragma unroll
+                    for (int c = 0; c < 4; c++) v[c] = gelu_as(v[c]);
+                }
+                if (EPI == X_EPI_RESID) v += rr[i][j];
+                if (row < nvalid) {
+                    if (a.of32) *(f32x4 *)(a.of32 + (size_t)row * a.ldo + col0) = v;
+                    if (a.ohi) {
+                        union { _Float16 h[4]; uint2 u; } ph, pl;
+#pragma unroll
+                        for (int c = 0; c < 4; c++) { const float x = v[c] * a.a_scale; ph.h[c] = (_Float16)x; pl.h[c] = (_Float16)(x - (float)ph.h[c]); }
+                        *(uint2 *)(a.ohi + (size_t)row * a.ldo + col0) = ph.u;
+                        *(uint2 *)(a.olo + (size_t)row * a.ldo + col0) = pl.u;
+                    }
+                }
+                if (a.stats_out) {
+                    const f32x2 ps = {row16_sum((v[0] + v[1]) + (v[2] + v[3])), row16_sum((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]))};
+                    if (l15 == 0 && row < nvalid) *(f32x2 *)(a.stats_out + ((size_t)row * ngr + gr) * 2) = ps;
+                }
+            }
+    }
+}
+
+template <int EPI, int LNA, int AIN, int NWK, int KW>
+int launch_gemm_h(const GemmHArgs &a, hipStream_t st) {
+    constexpr int WROWS = NWK > 1 ? 32 : 64, WCOLS = NWK > 1 ? 64 : 128;
+    const long long items = (long long)((a.M + WROWS - 1) / WROWS) * (a.N / WCOLS) * a.nbatch;
+    const unsigned blocks = (unsigned)(items < 16384 ? items : 16384);
+    k_gemm_h<EPI, LNA, AIN, NWK, KW><<<blocks, 256, 0, st>>>(a);
+    return hipGetLastError() == hipSuccess ? AZK_OK : AZK_ERR_HIP;
+}
+}  // namespace
+
+extern "C" int32_t azk_nnx_gemm_h(const azk_gemm_h *t, void *stream) {
+    if (!t || !t->w_packed || t->m < 0 || t->n_out < 64 || (t->n_out & 63) || t->nbatch < 1) return AZK_ERR_ARG;
+    if ((t->k != 512 && t->k != 2048) || t->lda < t->k || (t->lda & 7) || (t->a_batch_stride & 7)) return AZK_ERR_ARG;
+    const bool af32 = t->a_f32 != nullptr;
+    if (!af32 && (!t->a_hi || !t->a_lo)) return AZK_ERR_ARG;
+    if (t->epilogue < 0 || t->epilogue > 3 || (t->layernorm_a && (t->k != 512 || !t->a_stats || !t->col_sums))) return AZK_ERR_ARG;
+    if (t->epilogue == X_EPI_HEADS ? (!t->logits_out || !t->values_out || t->action_dim + 1 > t->n_out * t->nbatch)
+                                   : ((!t->out_f32 && !(t->out_hi && t->out_lo)) || t->ldo < t->n_out * t->nbatch || (t->ldo & 3))) return AZK_ERR_ARG;
+    if ((t->out_hi != nullptr) != (t->out_lo != nullptr)) return AZK_ERR_ARG;
+    if (t->epilogue == X_EPI_RESID && (!t->resid_f32 || (t->ldr & 3))) return AZK_ERR_ARG;
+    if (!(t->a_scale > 0.f) || !(t->w_scale > 0.f)) return AZK_ERR_ARG;
+    if (t->m == 0) return AZK_OK;
+    GemmHArgs a;
+    memset(&a, 0, sizeof a);
+    a.Ahi = (const _Float16 *)t->a_hi; a.Alo = (const _Float16 *)t->a_lo; a.Af32 = t->a_f32; a.lda = t->lda; a.a_batch = t->a_batch_stride;
+    a.Wp = (const uint4 *)t->w_packed; a.w_batch = (long long)(t->n_out / 64) * (t->k / 32) * 8 * 64;
+    a.M = t->m; a.N = t->n_out; a.nbatch = t->nbatch; a.count = t->n_valid; a.bias = t->bias; a.csum = t->col_sums;
+    a.inv_scale = 1.0f / (t->a_scale * t->w_scale); a.a_scale = t->a_scale;
+    a.ohi = (_Float16 *)t->out_hi; a.olo = (_Float16 *)t->out_lo; a.of32 = t->out_f32; a.ldo = t->ldo; a.resid = t->resid_f32; a.ldr = t->ldr;
+    a.ln_eps = t->ln_eps; a.stats_in = t->a_stats; a.stats_out = t->stats_out; a.logits = t->logits_out; a.values = t->values_out; a.action_dim = t->action_dim;
+    hipStream_t st = (hipStream_t)stream;
+    const int ln = t->layernorm_a ? 1 : 0;
+    if (t->k == 2048) {
+        if (ln || af32) return AZK_ERR_ARG;
+        if (t->epilogue == X_EPI_RESID) return launch_gemm_h<X_EPI_RESID, 0, 0, 4, 512>(a, st);
+        if (t->epilogue == X_EPI_PLAIN) return launch_gemm_h<X_EPI_PLAIN, 0, 0, 4, 512>(a, st);
+        return AZK_ERR_ARG;
+    }
+    const bool wide = t->n_out % 128 == 0 && t->n_out >= 1024;
+    if (af32) {                                                        // the first link: float32 z, split on the fly
+        if (ln || t->epilogue != X_EPI_PLAIN) return AZK_ERR_ARG;
+        return launch_gemm_h<X_EPI_PLAIN, 0, 1, 4, 128>(a, st);
+    }
+    if (ln) {
+        if (t->epilogue == X_EPI_GELU) return wide ? launch_gemm_h<X_EPI_GELU, 1, 0, 1, 512>(a, st) : launch_gemm_h<X_EPI_GELU, 1, 0, 4, 128>(a, st);
+        if (t->epilogue == X_EPI_HEADS) return launch_gemm_h<X_EPI_HEADS, 1, 0, 4, 128>(a, st);
+        return AZK_ERR_ARG;
+    }
+    if (t->epilogue == X_EPI_PLAIN) return launch_gemm_h<X_EPI_PLAIN, 0, 0, 4, 128>(a, st);
+    if (t->epilogue == X_EPI_GELU) return wide ? launch_gemm_h<X_EPI_GELU, 0, 0, 1, 512>(a, st) : launch_gemm_h<X_EPI_GELU, 0, 0, 4, 128>(a, st);
+    if (t->epilogue == X_EPI_RESID) return launch_gemm_h<X_EPI_RESID, 0, 0, 4, 128>(a, st);
+    return launch_gemm_h<X_EPI_HEADS, 0, 0, 4, 128>(a, st);
+}

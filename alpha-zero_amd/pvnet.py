@@ -302,6 +302,12 @@ class PolicyValueNet:
             e[k_ + "X"] = azk.pack_linear_weight_x(r[k_])
         for k_ in ("bias1", "b0G", "b3", "bhG"):
             e[k_] = r[k_]
+        # the same weights as fp16 (hi, lo) planes for the fp16-pipe tail (azk_nnx_gemm_h) + the column sums its LayerNorm epilogue needs
+        wvh = [azk.pack_linear_weight_h(r["Wvn"][h]) for h in range(H)]
+        e["WvH"] = torch.cat([w_.reshape(-1) for w_, _ in wvh])
+        for k_ in ("Wo", "W0G", "W3", "WhG"):
+            e[k_ + "H"], e[k_ + "H_csum"] = azk.pack_linear_weight_h(r[k_])
+        self.exact_tail = "h16"                                # "h16": fp16 (hi, lo) planes on the fp16 matrix pipe; "f32": v_mfma_f32_16x16x4_f32
         self._exact = e
         self.fused_embed_pool = True                          # the step graph may hand the engine's pending leaves straight to the kernel
 
@@ -351,10 +357,46 @@ class PolicyValueNet:
                                    timers=self.kernel_timers)
         return self.tail_fast(z)
 
+    def tail_exact_h(self, z):
+        """The fp32-accurate cls-row tail on the fp16 matrix pipe (csrc/azk_nnx.hip k_gemm_h): every operand as two fp16 terms (22
+        bits), activations handed from link to link as (hi, lo) planes, LayerNorm in the consuming epilogue; five launches, each
+        honouring the device-side live count (nn.py:54-60, 78-83 for the row the heads read)."""
+        import azk
+        cfg, e = self.cfg, self._exact
+        n, A, D, H = z.shape[0], cfg.action_dim, cfg.embed_dim, cfg.num_heads
+        dev, cnt = z.device, self.live_count
+        key = ("h", id(self.leaf_source) if self.leaf_source is not None else None)
+        ws = self._tail_ws.get(key)
+        if ws is None or ws["rows"] < n:
+            rows = n if ws is None else max(n, 2 * ws["rows"])
+            if ws is not None:
+                self._tail_ws_retired.append(ws)                 # never freed: captured graphs may hold these addresses
+            f16, f32 = dict(dtype=torch.float16, device=dev), dict(dtype=torch.float32, device=dev)
+            ws = dict(rows=rows, u=torch.empty((2, rows, D), **f16), x1=torch.empty((2, rows, D), **f16), x1f=torch.empty((rows, D), **f32),
+                      hh=torch.empty((2, rows, 4 * D), **f16), x2=torch.empty((2, rows, D), **f16),
+                      st1=torch.empty((rows, D // 64, 2), **f32), st2=torch.empty((rows, D // 64, 2), **f32))
+            self._tail_ws[key] = ws
+        pl = lambda k_: (ws[k_][0, :n], ws[k_][1, :n])
+        G = azk.nnx_gemm_h
+        self._launch(G, z.view(n, H * D), e["WvH"], D // H, D, azk.TAIL_BF16, nbatch=H, a_batch_stride=D, out=pl("u"), count=cnt)
+        self._launch(G, pl("u"), e["WoH"], D, D, azk.TAIL_BF16, bias=e["bias1"], out=pl("x1"), out_f32=ws["x1f"][:n], stats_out=ws["st1"][:n], count=cnt)
+        self._launch(G, pl("x1"), e["W0GH"], 4 * D, D, azk.TAIL_GELU, bias=e["b0G"], col_sums=e["W0GH_csum"], out=pl("hh"), a_stats=ws["st1"][:n], count=cnt)
+        self._launch(G, pl("hh"), e["W3H"], D, 4 * D, azk.TAIL_RESID, bias=e["b3"], resid=ws["x1f"][:n], out=pl("x2"), stats_out=ws["st2"][:n], count=cnt)
+        if self.out_buffers is not None:
+            lb, vb = self.out_buffers
+        else:
+            lb = torch.empty((n, A), dtype=torch.float32, device=dev)
+            vb = torch.empty(n, dtype=torch.float32, device=dev)
+        self._launch(G, pl("x2"), e["WhGH"], 256, D, azk.TAIL_HEADS, bias=e["bhG"], col_sums=e["WhGH_csum"], a_stats=ws["st2"][:n], logits=lb, values=vb,
+                     action_dim=A, count=cnt)
+        return lb, (vb if self.out_buffers is not None else vb[:, None])
+
     def tail_exact(self, z):
         """The cls-row tail as five float32 launches (csrc/azk_nnx.hip k_gemm_x), each honouring the device-side live count
         (nn.py:54-60, 78-83 for the row the heads read)."""
         import azk
+        if getattr(self, "exact_tail", "f32") == "h16":
+            return self.tail_exact_h(z)
         cfg, e = self.cfg, self._exact
         n, A, D, H = z.shape[0], cfg.action_dim, cfg.embed_dim, cfg.num_heads
         dev, cnt = z.device, self.live_count

@@ -465,14 +465,18 @@ def main():
             per_row = 2 * Hh * dh * Dm + 2 * Dm * Dm + 2 * 2 * Dm * 4 * Dm + 2 * Dm * (cfg.action_dim + 1)
             rows = live if (args.tail == "chain" or exact) else args.games * runner.leaves_per_step
             fl = per_row * rows
-            tail_peak = MFMA_F32_PEAK_TFLOPS if exact else MFMA_BF16_PEAK_TFLOPS
-            kernels.append({"kernel": "k_gemm_x x5 (cls-row tail, f32 MFMA)" if exact else ("k_tail_gemm x5 (cls-row tail)" if args.tail == "chain" else "library tail"), "bound": "mfma",
+            h16 = exact and getattr(net, "exact_tail", "f32") == "h16"
+            # the fp32-accurate tail: on fp16 (hi, lo) operand planes every product is three fp16 MFMAs (peak = a third of the fp16 rate),
+            # on the float32-input MFMA it runs at the float32 vector rate
+            tail_peak = (MFMA_BF16_PEAK_TFLOPS / 3 if h16 else MFMA_F32_PEAK_TFLOPS) if exact else MFMA_BF16_PEAK_TFLOPS
+            kernels.append({"kernel": ("k_gemm_h x5 (cls-row tail, fp16 hi/lo planes)" if h16 else "k_gemm_x x5 (cls-row tail, f32 MFMA)") if exact
+                            else ("k_tail_gemm x5 (cls-row tail)" if args.tail == "chain" else "library tail"), "bound": "mfma",
                             "achieved": fl / (ms * 1e-3) / 1e12, "peak": tail_peak, "unit": "TFLOP/s",
                             "frac": fl / (ms * 1e-3) / 1e12 / tail_peak, "avg_launch_us": ms * 1e3,
                             "algorithmic_flops_per_launch": fl, "traffic": None, "event_samples": len(ch.pairs),
                             "note": f"{per_row} flop per row x {rows:.0f} rows per step; avg_launch_us = the SUM of the tail's launches per step (each "
                                     "launch bracketed by its own HIP event pair); the per-launch split is in the rocprofv3 summary under profiles/"})
-        dominant = max((k for k in kernels if not k["kernel"].startswith(("k_tail_gemm x5", "library tail", "k_gemm_x x5"))), key=lambda k: k["avg_launch_us"]) if kernels else None
+        dominant = max((k for k in kernels if not k["kernel"].startswith(("k_tail_gemm x5", "library tail", "k_gemm_x x5", "k_gemm_h x5"))), key=lambda k: k["avg_launch_us"]) if kernels else None
         flops = {"cls": cfg.flops_cls(), "full": cfg.flops_full(), "clsfold": flops_clsfold(cfg)}[args.nn_path]
         # Boards the network really processed: eager stepping and the hand-written tail chain honour the live leaf count; only the
         # library tail (--tail library) runs the whole fixed-size leaf buffer every step.

@@ -486,6 +486,31 @@ typedef struct azk_gemm_x {
 } azk_gemm_x;
 int32_t azk_nnx_gemm(const azk_gemm_x *desc, void *stream);
 
+/* azk_nnx_gemm_h - the same link with every operand as TWO fp16 terms (x scale = hi + lo, 22 significant bits; products hi*hi + hi*lo +
+ * lo*hi exact in the float32 accumulator) on v_mfma_f32_16x16x32_f16: a fifth of the matrix-pipe time of the float32-input MFMA.
+ *   A: either (a_hi, a_lo) fp16 planes [m][lda] holding a * a_scale (written by the producing call's out_hi / out_lo), or a_f32
+ *      float32 [m][lda] split on the fly (first link only: k = 512, epilogue 0);
+ *   w_packed: nbatch weights [n_out][k] x w_scale as fp16 (hi, lo) in fragment order Wp[n_out/64][k/32][4][2][64 lanes][8]:
+ *      element [g][s][c][p][lane][i] = term p of W[64 g + 4 (lane&15) + c][32 s + 8 (lane>>4) + i];
+ *   layernorm_a: LayerNorm moves into the epilogue - out = rstd (acc - mean col_sums[n]) + bias, col_sums[n] = sum_k W[n][k] (of the
+ *      reconstructed terms), mean / rstd from a_stats as in azk_nnx_gemm;
+ *   outputs: out_f32 and / or (out_hi, out_lo) planes (x a_scale) [m][ldo]; stats_out / heads as azk_nnx_gemm. */
+typedef struct azk_gemm_h {
+    const void *a_hi, *a_lo; const float *a_f32; int32_t lda, a_batch_stride;
+    const void *w_packed;
+    int32_t m, n_out, k, nbatch;
+    const int32_t *n_valid;
+    const float *bias, *col_sums;
+    int32_t layernorm_a, epilogue;
+    float ln_eps, a_scale, w_scale;
+    const float *a_stats;
+    float *stats_out;
+    void *out_hi, *out_lo; float *out_f32; int32_t ldo;
+    const float *resid_f32; int32_t ldr;
+    float *logits_out, *values_out; int32_t action_dim;
+} azk_gemm_h;
+int32_t azk_nnx_gemm_h(const azk_gemm_h *desc, void *stream);
+
 /* ---- vanilla mode: MCTS.mcts(model=None, ...) (mcts.py:57-59), MCTS.simulate (mcts.py:62-79), UCB1 of
  * utils.py:29-44 mode 'normal'.  A search is azk_begin_search(e, NULL) followed by azk_vanilla_search calls summing to
  * n simulations (each launch runs its simulations - select, expand, random rollout, backup - entirely on the device);

@@ -76,6 +76,56 @@ def test_gemm_x_against_float64():
     assert (u.double() - ru).abs().max().item() < 2e-5
 
 
+def test_gemm_h_against_float64():
+    """azk_nnx_gemm_h (every operand as two fp16 terms on v_mfma_f32_16x16x32_f16): the same chain of links as above - float32 A split
+    on the fly, (hi, lo) planes from link to link, LayerNorm in the consuming epilogue (rstd (acc - mean col_sums) + bias), K = 2048
+    with residual, heads - against float64.  Budget: operands carried to 22 bits (2.4e-7 relative per term), float32 accumulation:
+    measured ~2e-6 on outputs of magnitude ~1, asserted at 3e-5; rows past the device-side count untouched."""
+    import azk
+    g = torch.Generator("cuda").manual_seed(4)
+    rn = lambda *s: torch.randn(*s, device="cuda", generator=g)
+    m = 300
+    cnt = torch.tensor([257], dtype=torch.int32, device="cuda")
+    planes = lambda c: (torch.full((m, c), 7.0, device="cuda", dtype=torch.float16), torch.full((m, c), 7.0, device="cuda", dtype=torch.float16))
+    val = lambda p: (p[0].double() + p[1].double()) / azk.GEMM_H_A_SCALE
+    # first link: float32 A, batched block-diagonal form
+    z, wv = rn(m, 8 * 512), rn(8, 64, 512) * 0.05
+    u = planes(512)
+    azk.nnx_gemm_h(z, torch.cat([azk.pack_linear_weight_h(wv[h])[0].reshape(-1) for h in range(8)]), 64, 512, azk.TAIL_BF16, nbatch=8, a_batch_stride=512, out=u, count=cnt)
+    ru = torch.einsum("nhd,hed->nhe", z.view(m, 8, 512).double(), wv.double()).reshape(m, 512)
+    assert (val(u)[:257] - ru[:257]).abs().max().item() < 3e-5 and bool((u[0][257:] == 7.0).all())
+    # planes in, planes + float32 + statistics out
+    w, b = rn(512, 512) * 0.05, rn(512)
+    wp, _ = azk.pack_linear_weight_h(w)
+    x1, x1f, st = planes(512), torch.full((m, 512), 7.0, device="cuda"), torch.zeros(m, 8, 2, device="cuda")
+    azk.nnx_gemm_h(u, wp, 512, 512, azk.TAIL_BF16, bias=b, out=x1, out_f32=x1f, stats_out=st, count=cnt)
+    r1 = ru[:257] @ w.double().t() + b.double()
+    assert (x1f[:257].double() - r1).abs().max().item() < 3e-5 and (val(x1)[:257] - r1).abs().max().item() < 3e-5 and bool((x1f[257:] == 7.0).all())
+    # LayerNorm in the epilogue + GELU, wide N
+    w0, b0 = rn(2048, 512) * 0.05, rn(2048)
+    w0p, cs0 = azk.pack_linear_weight_h(w0)
+    hh = planes(2048)
+    azk.nnx_gemm_h(x1, w0p, 2048, 512, azk.TAIL_GELU, bias=b0, col_sums=cs0, out=hh, a_stats=st, count=cnt)
+    ln = (r1 - r1.mean(1, keepdim=True)) / torch.sqrt(r1.var(1, unbiased=False, keepdim=True) + 1e-5)
+    rh = torch.nn.functional.gelu(ln @ w0.double().t() + b0.double())
+    assert (val(hh)[:257] - rh).abs().max().item() < 3e-5
+    # K = 2048 + residual + statistics
+    w3, b3 = rn(512, 2048) * 0.02, rn(512)
+    x2, st2 = planes(512), torch.zeros(m, 8, 2, device="cuda")
+    azk.nnx_gemm_h(hh, azk.pack_linear_weight_h(w3)[0], 512, 2048, azk.TAIL_RESID, bias=b3, resid=x1f, out=x2, stats_out=st2, count=cnt)
+    r2 = r1 + rh @ w3.double().t() + b3.double()
+    assert (val(x2)[:257] - r2).abs().max().item() < 5e-5
+    # heads
+    wh, bh = rn(256, 512) * 0.05, rn(256)
+    whp, csh = azk.pack_linear_weight_h(wh)
+    lg, vl = torch.full((m, 225), 7.0, device="cuda"), torch.full((m,), 7.0, device="cuda")
+    azk.nnx_gemm_h(x2, whp, 256, 512, azk.TAIL_HEADS, bias=bh, col_sums=csh, a_stats=st2, logits=lg, values=vl, action_dim=225, count=cnt)
+    ln2 = (r2 - r2.mean(1, keepdim=True)) / torch.sqrt(r2.var(1, unbiased=False, keepdim=True) + 1e-5)
+    ro = ln2 @ wh.double().t() + bh.double()
+    assert (lg[:257].double() - ro[:, :225]).abs().max().item() < 5e-5 and (vl[:257].double() - torch.tanh(ro[:, 225])).abs().max().item() < 1e-5
+    assert bool((lg[257:] == 7.0).all()) and bool((vl[257:] == 7.0).all())
+
+
 def test_embed_pool_x_against_float64():
     """k_embed_pool_x: z [n, H, 512] against the float64 evaluation of the same tables.  Budget: conv weights carried as two fp16
     terms (2.4e-7 relative), float32 statistics / exp / pooling: measured ~3e-7; asserted at 3e-6 on |z| <= ~1.  Empty boards
@@ -99,11 +149,14 @@ def test_embed_pool_x_against_float64():
     assert int(net._sched_for(None)[0]) == 0              # the board queue is left zero
 
 
-def test_exact_evaluator_against_reference_known_answers():
+@pytest.mark.parametrize("tail", ["h16", "f32"])
+def test_exact_evaluator_against_reference_known_answers(tail):
     """The whole fp32-accurate evaluator against the reference's seed-0 outputs (nn_small.npz full_*): north_star's float32 bar,
-    logits 1e-5 / value 1e-6 (measured ~1e-6 / 1e-7) - the tolerance the torch float32 paths are held to."""
+    logits 1e-5 / value 1e-6 (measured ~1e-6 / 1e-7) - the tolerance the torch float32 paths are held to.  Both tails: fp16 (hi, lo)
+    planes on the fp16 matrix pipe (the default) and the float32-input MFMA."""
     z = load_golden("nn_small.npz")
     net = PolicyValueNet(CFG, seed=0, device="cuda", dtype=torch.float32, path="clsfold")
+    net.exact_tail = tail
     logits, v = net(torch.from_numpy(z["full_x"]).cuda())
     np.testing.assert_allclose(logits.cpu().numpy(), z["full_logits"], rtol=0, atol=1e-5)
     np.testing.assert_allclose(v.cpu().numpy().reshape(-1), z["full_value"].reshape(-1), rtol=0, atol=1e-6)
@@ -126,11 +179,14 @@ def test_search_policies_identical_under_the_exact_evaluator():
     assert len(positions) == 92
     noise = torch.from_numpy(np.random.RandomState(7).dirichlet([0.03] * 225, size=len(positions))).cuda()
     ref_pi, ref_q = search_pis(PolicyValueNet(CFG, seed=0, device="cuda", dtype=torch.float32, path="full"), "float32", positions, 800, noise)
-    pi, q = search_pis(PolicyValueNet(CFG, seed=0, device="cuda", dtype=torch.float32, path="clsfold"), "float32", positions, 800, noise)
-    d = np.abs(pi - ref_pi)
-    print(f"exact clsfold vs fp32 full: {(d.max(1) == 0).sum()}/{len(positions)} identical, max |dpi| {d.max():.2e}, max |dq| {np.abs(q - ref_q).max():.2e}")
-    assert d.max() <= 1e-5
-    assert np.abs(q - ref_q).max() < 1e-5
+    for tail in ("h16", "f32"):
+        net = PolicyValueNet(CFG, seed=0, device="cuda", dtype=torch.float32, path="clsfold")
+        net.exact_tail = tail
+        pi, q = search_pis(net, "float32", positions, 800, noise)
+        d = np.abs(pi - ref_pi)
+        print(f"exact clsfold ({tail} tail) vs fp32 full: {(d.max(1) == 0).sum()}/{len(positions)} identical, max |dpi| {d.max():.2e}, max |dq| {np.abs(q - ref_q).max():.2e}")
+        assert d.max() <= 1e-5, tail
+        assert np.abs(q - ref_q).max() < 1e-5, tail
 
 
 def test_runner_exact_evaluator_graph_stepping():
