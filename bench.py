@@ -81,9 +81,23 @@ def cpu_port_sample(n_sims, budget_s, threads):
         l = logits[0].numpy()
         return np.exp(l) / np.sum(np.exp(l)), float(v[0, 0])
     t0 = time.time()
+    # two half-samples, so that the searches timed are not all early-game ones (few children, almost no terminal leaves): a game
+    # from the empty board, and one continued from ply 12 of a recorded 15x15 game of the reference (tests/golden/games.npz)
     out = ao.self_play(game, ev, n_sims, noise_fn=lambda mc: rng.dirichlet([0.03] * 225),
-                       uniform_fn=lambda mc: rng.random_sample(), cache=cache, counters=cnt, time_budget=budget_s)
-    return cnt.mcts_count, cnt.evals, cnt.matched, len(out["cells"]), time.time() - t0
+                       uniform_fn=lambda mc: rng.random_sample(), cache=cache, counters=cnt, time_budget=budget_s * 0.5)
+    moves = len(out["cells"])
+    try:
+        from conftest import golden_meta, load_golden
+        zg = load_golden("games.npz")
+        m15 = next(m for m in golden_meta(zg) if m["size"] == 15 and len(zg[f"g{m['game']}_board_cells"]) > 14)
+        cells = zg[f"g{m15['game']}_board_cells"][12].reshape(15, 15)
+        board = np.stack([(cells == 1), (cells == 2)]).astype(np.float32)
+        out2 = ao.self_play(game, ev, n_sims, noise_fn=lambda mc: rng.dirichlet([0.03] * 225), uniform_fn=lambda mc: rng.random_sample(),
+                            cache=cache, counters=cnt, time_budget=budget_s * 0.5, start=(board, 0, 12))
+        moves += len(out2["cells"])
+    except StopIteration:
+        pass
+    return cnt.mcts_count, cnt.evals, cnt.matched, moves, time.time() - t0
 
 
 def cpu_baseline(n_sims, budget_s, mean_plies):
@@ -100,7 +114,7 @@ def cpu_baseline(n_sims, budget_s, mean_plies):
     games_per_s = sims_per_s / (n_sims * mean_plies)
     out = {"value": games_per_s, "unit": "games/s", "cores": threads, "kind": "port",
            "sims_per_sec": sims_per_s, "host_cpus": os.cpu_count(),
-           "sample": f"first {moves} moves of one Gomoku 15x15 game, {n_sims} sims/move: {sims} sims "
+           "sample": f"{moves} searches of Gomoku 15x15 at {n_sims} sims/move - half of the time from the empty board, half continued from ply 12 of a recorded game: {sims} sims "
                      f"({evals} net evals, {hits} cache hits) in {dt:.1f} s; games/s = sims/s / ({n_sims} x {mean_plies:.1f} plies)",
            "reference_python": REFERENCE_PYTHON}
     # leg 2: independent single-threaded processes, one per core of the CPU share; children never touch the GPU

@@ -309,13 +309,16 @@ def mcts_vl(game, tree, board, n_sims, K, evaluator, noise=None, cache=None, cou
 
 
 def self_play(game, evaluator, n_sims, noise_fn=None, uniform_fn=None, cache=None, randint=None,
-              counters=None, max_moves=None, time_budget=None, evaluator2=None, n_sims2=None, sample_until=None):
+              counters=None, max_moves=None, time_budget=None, evaluator2=None, n_sims2=None, sample_until=None, start=None):
     """<Game>.self_play.  noise_fn(move_idx)->f64[A] supplies np.random.dirichlet's draw,
     uniform_fn(move_idx)->float the uniform consumed by np.random.choice.  Returns a dict with
-    boards (raw, not canonical), cells played, pis, qs, winner."""
+    boards (raw, not canonical), cells played, pis, qs, winner.  start = (board, player to move, plies played): continue a game
+    from that position instead of Game() (bench.py's CPU-baseline sample of mid-game searches)."""
     board = game.new_board()
     tree = OracleTree(game)
     player, mc = 0, 0
+    if start is not None:
+        board, player, mc = np.ascontiguousarray(start[0], np.float32).copy(), int(start[1]), int(start[2])
     boards, cells, pis, qs = [], [], [], []
     import time as _time
     t_start = _time.time()
