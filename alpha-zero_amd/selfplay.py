@@ -366,7 +366,9 @@ class SelfPlayRunner:
                     else:
                         g.replay()
         if not self.budget_stepping:
-            s, U, next_sample = done, self.steps_per_graph, done
+            # (the sampling phase carries over from move to move: with a stride that does not divide n_sims the sampled simulations
+            #  drift through the search - leaf counts differ between its early and late simulations - instead of hitting the same few)
+            s, U, next_sample = done, self.steps_per_graph, max(done, getattr(self, "_sample_phase", 0))
             while s < self.n_sims:
                 if kt is not None and kt.enabled and s >= next_sample and len(kt.pairs) < kt.max:
                     replay(s, timed=True)
@@ -379,6 +381,8 @@ class SelfPlayRunner:
                     replay(s, timed=False)
                     s += 1
             self.launches += self.n_sims
+            if kt is not None:
+                self._sample_phase = max(0, next_sample - self.n_sims)
         else:
             # no game can finish before its budget's worth of cache misses: a first stretch without looking, then a look (one
             # 4-byte read-back) every few launches

@@ -210,7 +210,7 @@ def main():
     ap.add_argument("--cache", default="shared", choices=["shared", "per-game"],
                     help="eval cache: one table shared by every game of the GPU (the reference's MCTS.cache is process-global, mcts.py:7) or one "
                          "table per game; same memory, same results, different hit rate")
-    ap.add_argument("--timer-stride", type=int, default=64,
+    ap.add_argument("--timer-stride", type=int, default=176,
                     help="every n-th simulation step runs eagerly with HIP events around k_tree and the embedding kernel (the roofline's live durations)")
     ap.add_argument("--steps-per-graph", type=int, default=32,
                     help="simulation steps captured in one hipGraph (consecutive graph launches leave an ~8 us bubble; 1 = one step per launch)")
