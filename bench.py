@@ -445,7 +445,8 @@ def main():
             fl = per_board * live
             ep_traffic = None
             try:
-                ep_traffic = next(v["bytes_per_launch"] for k_, v in pmc.items() if k_.startswith("k_embed_pool"))
+                # the counters were collected on the bf16 build's kernel: no figure for k_embed_pool_x unless the file holds one
+                ep_traffic = next(v["bytes_per_launch"] for k_, v in pmc.items() if k_.startswith("k_embed_pool_x" if exact else "k_embed_pool_c"))
             except Exception:
                 pass
             compact = exact or (getattr(net, "_compact", None) is not None and getattr(net, "use_compact", False))
@@ -539,7 +540,7 @@ def main():
                              "command": "python bench.py --nn-dtype fp32", "source": "profiles/r03_bench_fp32.json"}
             except Exception:
                 pass
-            exact_par = {"evaluator": "hand-written fp32-accurate kernels (csrc/azk_nnx.hip: fp16 hi/lo conv on the 0/1 board, f32 MFMA elsewhere)",
+            exact_par = {"evaluator": "hand-written fp32-accurate kernels (csrc/azk_nnx.hip: fp16 hi/lo conv on the 0/1 board, f32-input MFMA for the stone-touched pooling, fp16 hi/lo planes for the constant-token pooling and the cls-row tail)",
                          "logits_vs_reference_seed0": par["kat_vs_reference_seed0"].get("fp32_clsfold"),
                          "visit_policy_vs_fp32_full": par["search_vs_fp32_full"].get("fp32_clsfold"), "bench_line": fp32_line}
             if args.nn_dtype == "bf16":
