@@ -145,6 +145,38 @@ class _Half:
         self.uni = None
 
 
+def concurrent_streams(torch, device, n, spin_cycles=600_000):
+    """n HIP streams whose kernels really run side by side.  HIP hands its streams out over a few hardware queues (four per priority by
+    default) and two streams on one queue serialize - measured on this pool: of six fresh streams three pairs shared a queue, and the
+    two streams the game groups used to get were such a pair (rocprofv3 kernel trace: same Queue_Id, 0.1 % of the time with two kernels
+    in flight).  So candidates are probed pairwise with a one-thread spin kernel: two spins that take the time of one overlap."""
+    import time
+    cand = [torch.cuda.Stream(device=device) for _ in range(8)] + [torch.cuda.Stream(device=device, priority=-1) for _ in range(2)]
+    for st in cand:                                  # queues are created at first use
+        with torch.cuda.stream(st):
+            torch.cuda._sleep(1000)
+    torch.cuda.synchronize(device)
+
+    def spins(a, b):
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for st in (a, b):
+            with torch.cuda.stream(st):
+                torch.cuda._sleep(spin_cycles)
+        torch.cuda.synchronize(device)
+        return time.perf_counter() - t0
+    serial = min(spins(cand[0], cand[0]) for _ in range(2))
+    chosen = [cand[0]]
+    for st in cand[1:]:
+        if len(chosen) == n:
+            break
+        if all(min(spins(st, c) for _ in range(2)) < 0.75 * serial for c in chosen):
+            chosen.append(st)
+    if len(chosen) < n:
+        raise RuntimeError(f"only {len(chosen)} of {n} streams found that run concurrently on this device")
+    return chosen
+
+
 class SelfPlayRunner:
     """Continuous self-play: G slots advance one move per `play_move()`; a slot whose game ends restarts
     from an empty board in the same call (azk_recycle_finished), so every move does G searches.
@@ -188,7 +220,7 @@ class SelfPlayRunner:
         self.sample_until = SAMPLE_UNTIL[game]
         self.kernel_timer = kernel_timer
         self.leaf_source_ok = True              # let a fused evaluator read the pending leaves straight from the engine (no azk_step_gather)
-        self.streams = [torch.cuda.Stream(device=self.eng.device) for _ in range(self.n_split)] if self.n_split > 1 else []
+        self.streams = concurrent_streams(torch, self.eng.device, self.n_split) if self.n_split > 1 else []
         self.move_idx = 0
         self.plies_played = 0
         for h in self.halves:

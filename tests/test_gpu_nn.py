@@ -551,6 +551,33 @@ def test_runner_steps_per_graph_plays_the_same_moves():
                 assert np.array_equal(cha, chb) and pa.tobytes() == pb.tobytes(), (sims, per_graph, graph)
 
 
+def test_runner_game_groups_on_concurrent_streams_play_the_same_moves():
+    """`n_split` game groups, each with its own captured graphs on its own stream, chosen so that the streams really run side by side
+    (selfplay.concurrent_streams: distinct hardware queues).  The groups share ONE evaluator; its per-engine workspaces, schedules
+    and graph-private intermediates must keep the concurrent forwards apart: the same pi bytes and moves as one group."""
+    from selfplay import SelfPlayRunner, concurrent_streams
+    sts = concurrent_streams(torch, torch.device("cuda:0"), 2)
+    assert len(sts) == 2 and sts[0].cuda_stream != sts[1].cuda_stream
+    cfg = NetConfig(15, 15, 2, 225, 5, 512, 8, 1)
+    net = PolicyValueNet(cfg, seed=6, device="cuda", dtype=torch.bfloat16, path="clsfold")
+
+    def play(n_split):
+        rec = {}
+        def on(mv, base, pi, q, ch, w, d):
+            rec[(mv, base)] = (pi.numpy().copy(), ch.numpy().copy())
+        r = SelfPlayRunner("gomoku", net, 256, 64, size=15, seed=13, leaf_dtype="bfloat16", recycle=True, use_graph=True, cache_entries=256,
+                           cache_shared=True, steps_per_graph=8, n_split=n_split, on_records=on)
+        for _ in range(4):
+            r.play_move()
+        r.check_error()
+        per = 256 // n_split
+        return [(np.concatenate([rec[(mv, g * per)][0] for g in range(n_split)]), np.concatenate([rec[(mv, g * per)][1] for g in range(n_split)]))
+                for mv in range(4)]
+    one, two = play(1), play(2)
+    for (pa, ca), (pb, cb) in zip(one, two):
+        assert np.array_equal(ca, cb) and pa.tobytes() == pb.tobytes()
+
+
 def test_runner_real_network_eval_cache_is_transparent():
     """The eval cache under the REAL bf16 network: 256 games, continuous self-play on the graph runner, the
     cache off / one table per game / ONE table shared by every game (multi-writer: claim word, copy, re-read) must give the same
