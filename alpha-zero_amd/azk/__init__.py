@@ -5,6 +5,7 @@ behind the C ABI.  There is NO CPU fallback: if libazk.so is missing or no GPU i
 functions here raise.  PyTorch is used for device memory and streams only.
 """
 import ctypes as C
+import math
 import os
 import subprocess
 
@@ -14,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(os.path.dirname(_HERE), "csrc")
 LIB_PATH = os.path.join(_HERE, "libazk.so")
 
-ABI_VERSION = 2           # include/azk.h AZK_ABI_VERSION the structure layouts below were written for
+ABI_VERSION = 3           # include/azk.h AZK_ABI_VERSION the structure layouts below were written for
 GAME_ID = {"tictactoe": 0, "connect4": 1, "gomoku": 2}
 LEAF_F32, LEAF_BF16 = 0, 1
 EMBED_POOL_COMPACT_MAX_SLOTS = 65279       # AZK_EMBED_POOL_COMPACT_MAX_SLOTS (include/azk.h)
@@ -31,6 +32,7 @@ SYMBOLS = [
     "azk_vanilla_set_rng", "azk_vanilla_get_rng", "azk_vanilla_search", "azk_nn_embed_pool",
     "azk_nn_gemm_rows", "azk_nn_layernorm_sum", "azk_nn_heads_finalize_sum", "azk_nn_ln_heads",
     "azk_leaf_source_of", "azk_nn_embed_pool_leaves", "azk_nn_embed_pool_compact", "azk_nn_embed_pool_compact_leaves",
+    "azk_nn_embed_fold", "azk_nn_embed_fold_leaves",
     "azk_nn_tail_gemm", "azk_begin_search_budget", "azk_search_unfinished",
     "azk_nnx_embed_pool", "azk_nnx_embed_pool_leaves", "azk_nnx_gemm", "azk_nnx_gemm_h",
     "azk_async_begin", "azk_async_step", "azk_async_drain", "azk_async_set_budget",
@@ -61,6 +63,14 @@ class EmbedPoolConsts(C.Structure):
                 ("xnconst_tok", C.c_void_p), ("z_all", C.c_void_p), ("l_all", C.c_void_p), ("score_msum", C.c_void_p),
                 ("score_ref", C.c_void_p), ("num_heads", C.c_int32), ("ksize", C.c_int32), ("kp", C.c_int32),
                 ("embed_dim", C.c_int32), ("ln_eps", C.c_float), ("work_stats", C.c_void_p)]
+
+
+class EmbedFoldConsts(C.Structure):
+    """azk_embed_fold_consts (include/azk.h): tables of the patch-pooling embedding kernel."""
+    _fields_ = [("g_frag", C.c_void_p), ("e_frag", C.c_void_p), ("u2_tok", C.c_void_p), ("score_tok", C.c_void_p),
+                ("wconst_tok", C.c_void_p), ("l_all", C.c_void_p), ("score_ref", C.c_void_p), ("inv_scales", C.c_void_p),
+                ("num_heads", C.c_int32), ("ksize", C.c_int32), ("embed_dim", C.c_int32), ("ln_eps", C.c_float),
+                ("work_stats", C.c_void_p)]
 
 
 class TailGemm(C.Structure):
@@ -195,6 +205,8 @@ def lib():
     L.azk_nn_embed_pool_leaves.argtypes = [C.POINTER(LeafSource), vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, C.c_float, vp]
     L.azk_nn_embed_pool_compact.argtypes = [vp, i32, C.POINTER(EmbedPoolConsts), vp, i32, i32, i32, i32, vp, vp, vp]
     L.azk_nn_embed_pool_compact_leaves.argtypes = [C.POINTER(LeafSource), C.POINTER(EmbedPoolConsts), vp, vp, vp]
+    L.azk_nn_embed_fold.argtypes = [vp, i32, C.POINTER(EmbedFoldConsts), vp, i32, i32, i32, i32, vp, vp, vp]
+    L.azk_nn_embed_fold_leaves.argtypes = [C.POINTER(LeafSource), C.POINTER(EmbedFoldConsts), vp, vp, vp]
     L.azk_begin_search_budget.argtypes = [vp, vp, i32, i32, vp]
     L.azk_search_unfinished.argtypes = [vp, vp, vp]
     L.azk_nn_tail_gemm.argtypes = [C.POINTER(TailGemm), vp]
@@ -805,6 +817,112 @@ def nn_embed_pool_compact_leaves(src, tables, sched, timers=None):
     if rc != 0:
         raise AzkError(f"azk_nn_embed_pool_compact_leaves failed ({rc})")
     return z
+
+
+EMBED_FOLD_ROW = 384        # include/azk.h AZK_EMBED_FOLD_ROW
+
+
+class EmbedFoldTables:
+    """Tables of azk_nn_embed_fold and the weight of the batched GEMM that follows it, from PolicyValueNet.fold_u's float64 operands
+    (r: G [64, 64], ext [64, 16], U2 [T, 64], nt [T], sct [T, H], Dtab [T, 512], M [512, 64], rstdc [T], ref [H], wc [T, H], uall [512],
+    lall [H]); kept alive with the ctypes descriptor.  `weight`: H blocks of [64][EMBED_FOLD_ROW] in azk_nn_tail_gemm's packing."""
+
+    def __init__(self, r, num_heads, ksize, embed_dim, device, eps=1e-5):
+        torch = _torch()
+        assert embed_dim == 512 and embed_dim // num_heads == 64
+        H, D = num_heads, embed_dim
+        dev = torch.device(device)
+        T = r["U2"].shape[0]
+        assert T + 3 <= 256 and r["G"].shape == (64, 64)
+        # power-of-two scales that put the largest entry's hi term near 2^10: hi and lo both normal fp16 for entries down to ~1e-7 of it
+        sc = lambda t: 2.0 ** (10 - math.ceil(math.log2(max(float(t.abs().max()), 1e-30))))
+        gs, es = sc(r["G"]), sc(r["ext"])
+
+        def frags(mat, scale, ncol):                    # mat [64 k, 16 ncol columns] -> [2 (hi, lo)][ncol][2 k-steps][64 lanes][8]
+            hi, lo = split_fp16(mat.to(dev), scale)
+            l = torch.arange(64, device=dev)
+            col = 16 * torch.arange(ncol, device=dev)[:, None] + (l & 15)[None, :]                                      # [ncol, 64]
+            kidx = 32 * torch.arange(2, device=dev)[:, None, None] + 8 * (l >> 4)[None, :, None] + torch.arange(8, device=dev)[None, None, :]   # [2, 64, 8]
+            pick = lambda m_: m_[kidx[None], col[:, None, :, None]]                                                     # [ncol, 2, 64, 8]
+            return torch.stack([pick(hi), pick(lo)]).contiguous()
+        t = {}
+        t["g_frag"] = frags(r["G"], gs, 4)              # element [term][q][s][l][i] = G[32 s + 8 (l>>4) + i][16 q + (l&15)] (G is symmetric)
+        t["e_frag"] = frags(r["ext"], es, 1)
+        f32 = lambda x: x.to(dev, torch.float32).contiguous()
+        u2 = torch.zeros(T + 1, 64, dtype=torch.float64, device=dev)
+        u2[:T] = r["U2"].to(dev)
+        t["u2_tok"] = f32(u2)
+        st = torch.zeros(T + 1, 16, dtype=torch.float64, device=dev)
+        st[:T, :H], st[:T, 15] = r["sct"].to(dev), r["nt"].to(dev)
+        st[T, :H], st[T, 15] = -1e30, float(D)
+        t["score_tok"] = f32(st)
+        wct = torch.zeros(T + 1, 16, dtype=torch.float64, device=dev)
+        wct[:T, :H], wct[:T, 15] = r["wc"].to(dev), r["rstdc"].to(dev)
+        wct[T, 15] = 1.0
+        t["wconst_tok"] = f32(wct)
+        la = torch.zeros(16, dtype=torch.float64, device=dev)
+        la[:H] = r["lall"].to(dev)
+        t["l_all"] = f32(la)
+        ref = torch.full((16,), 1e30, dtype=torch.float64, device=dev)
+        ref[:H] = r["ref"].to(dev)
+        t["score_ref"] = f32(ref)
+        t["inv_scales"] = torch.tensor([1.0 / gs, 1.0 / es], dtype=torch.float32, device=dev)
+        self.t = t
+        # the GEMM weight: per head [64 outputs][EMBED_FOLD_ROW]: D_t (t < T), U_all as bf16 hi at T and T + 1, its remainder at T + 2,
+        # M_h at [256, 320)
+        W = torch.zeros(H, 64, EMBED_FOLD_ROW, dtype=torch.float64, device=dev)
+        W[:, :, :T] = r["Dtab"].to(dev).view(T, H, 64).permute(1, 2, 0)
+        ua = r["uall"].to(dev).view(H, 64)
+        ua_hi = ua.to(torch.bfloat16).double()
+        W[:, :, T], W[:, :, T + 1], W[:, :, T + 2] = ua_hi, ua_hi, ua - ua_hi
+        W[:, :, 256:320] = r["M"].to(dev).view(H, 64, 64)
+        self.weight_f64 = W
+        t["weight"] = torch.cat([pack_linear_weight(W[h].float()).reshape(-1) for h in range(H)])      # (in .t: promoted in place with the tables)
+        self.weight = t["weight"]
+        self.tokens, self.num_heads, self.embed_dim = T, H, D
+        self.c = EmbedFoldConsts(*[t[k].data_ptr() for k in ("g_frag", "e_frag", "u2_tok", "score_tok", "wconst_tok", "l_all", "score_ref",
+                                                             "inv_scales")], H, ksize, D, float(eps), None)
+        self.work_stats = None
+
+    def enable_work_stats(self):
+        if self.work_stats is None:
+            self.work_stats = _torch().zeros(2, dtype=_torch().int64, device=self.t["u2_tok"].device)
+            self.c.work_stats = self.work_stats.data_ptr()
+        return self.work_stats
+
+
+def nn_embed_fold(boards, tables, rows, cols, sched, count=None, timers=None):
+    """azk_nn_embed_fold: boards [n, C, R, Cc] bf16 / f32 -> bf16 [n, H, EMBED_FOLD_ROW] (token weights / L, 1 / L, pooled patch / L)."""
+    torch = _torch()
+    assert boards.is_cuda and boards.is_contiguous() and boards.dtype in (torch.bfloat16, torch.float32)
+    assert rows * cols + 1 == tables.tokens and sched.dtype == torch.int32 and sched.numel() >= 2
+    n, Cc = boards.shape[0], boards.shape[1]
+    out = torch.empty((n, tables.num_heads, EMBED_FOLD_ROW), dtype=torch.bfloat16, device=boards.device)
+    args = (_p(boards), 1 if boards.dtype == torch.float32 else 0, C.byref(tables.c), _p(out), n, Cc, rows, cols, _p(count), _p(sched), _stream())
+    if timers is not None:
+        timers[0].start()
+    rc = lib().azk_nn_embed_fold(*args)
+    if timers is not None:
+        timers[0].stop()
+    if rc != 0:
+        raise AzkError(f"azk_nn_embed_fold failed ({rc})")
+    return out
+
+
+def nn_embed_fold_leaves(src, tables, sched, timers=None):
+    """azk_nn_embed_fold over an engine's pending leaves (LeafSource): bf16 [G, H, EMBED_FOLD_ROW], rows [0, n_leaf) valid."""
+    torch = _torch()
+    assert src.rows * src.cols + 1 == tables.tokens and sched.dtype == torch.int32 and sched.numel() >= 2
+    out = torch.empty((src.n_games, tables.num_heads, EMBED_FOLD_ROW), dtype=torch.bfloat16, device=sched.device)
+    args = (C.byref(src), C.byref(tables.c), _p(out), _p(sched), _stream())
+    if timers is not None:
+        timers[0].start()
+    rc = lib().azk_nn_embed_fold_leaves(*args)
+    if timers is not None:
+        timers[0].stop()
+    if rc != 0:
+        raise AzkError(f"azk_nn_embed_fold_leaves failed ({rc})")
+    return out
 
 
 TAIL_BF16, TAIL_GELU, TAIL_RESID, TAIL_HEADS = 0, 1, 2, 3

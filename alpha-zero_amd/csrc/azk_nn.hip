@@ -1701,6 +1701,477 @@ extern "C" int32_t azk_nn_embed_pool_compact_leaves(const azk_leaf_source *src, 
 }
 
 // =====================================================================================================
+// k_embed_fold: embedding + cls pooling without the token rows (include/azk.h azk_nn_embed_fold; pvnet.PolicyValueNet.fold_u).
+//   x_t = Wc p_t + cpos_t with p_t the token's 0/1 patch, so LayerNorm1's variance is a quadratic form of <= 64 bits, the cls scores
+//   are linear in them, and the value-projected pooled row u_h = (1/L_h) sum_t a_t[h] (M_h p_t + D_t[h]) is linear in x_t: what a
+//   board contributes is, per head, one weight per token, 1/L, and the pooled patch sum_t a_t p_t / L - 384 bf16 per head, which the
+//   tail's first GEMM multiplies with [D_t; U_all; M_h].  No conv, no D-wide normalisation, no gather of D-wide rows.
+//   Board queue, leaf ranks, board bits, patch bits and the compaction of the stone-touched ("dirty") tokens are k_embed_pool_c's.
+//   Tile loop: a WAVE owns 16-token tiles (tile = wave, wave + 4, ...), nothing between the waves until the board's sums meet:
+//     Y = P G (16 x 64, fp16 hi + lo terms: exact products with the 0/1 patch), E = P S (scores), both v_mfma_f32_16x16x32_f16;
+//     var_t = (sum_k p_tk (Y_tk + u2_tk) + n_t) / D from the accumulator layout (DPP row sum); w = exp(rstd (E + sc) - ref);
+//     a = w rstd; b = a - aconst to LDS; pooled patch: Pw[h][k] += a_t[h] p_tk on v_mfma_f32_16x16x32_bf16 with k-slots 0..3 of a
+//     lane group = its four tokens' a as bf16 hi, slots 4..7 = the bf16 remainder (B: the patch bits twice).
+//   Board end: L and Pw of the four waves meet in LDS, every thread scales ITS token's eight weights by 1 / L into the output image
+//   (LDS, bf16), the pooled patch and the three 1/L slots follow, the image leaves with 16-byte stores.
+// =====================================================================================================
+namespace {
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+
+struct EmbedFoldArgs {
+    const void *boards;
+    int boards_f32;
+    const uint4 *gfrag;            // [2 (hi, lo)][4][2][64]
+    const uint4 *efrag;            // [2][2][64]
+    const float *u2T, *scoreT, *wcT, *lall, *sref, *inv_scales;
+    unsigned short *out;           // [n][NH][FOLD_ROW] bf16
+    const int *count;
+    int *sched;
+    unsigned long long *wstats;
+    int n, R, Cc, T;
+    float eps;
+    azk_leaf_source src;
+};
+
+__device__ __forceinline__ unsigned bf16_rne(float v) {
+    const unsigned u = __float_as_uint(v);
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+
+constexpr int FOLD_ROW = AZK_EMBED_FOLD_ROW;
+
+template <int NC, int KSZ, int NH, bool SRC>
+__global__ __launch_bounds__(256, 2) void k_embed_fold(EmbedFoldArgs a) {
+    static_assert(NC * KSZ * KSZ <= 64, "the patch is one 64-bit word");
+    constexpr int D = 512;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint4 *alut = (uint4 *)smem;                                  // [256] A fragment (fp16 0 / 1) of 8 patch bits
+    const int Tp16 = ((a.T + 15) >> 4) << 4;
+    uint2 *pbits = (uint2 *)(alut + 256);                         // [Tp16] patch bits of the compacted dirty tokens
+    int *dlist = (int *)(pbits + Tp16);                           // [Tp16] their token indices (null token = T past the end)
+    int *scan = dlist + Tp16;                                     // [4] SRC wave totals, [4] dirty counts per wave, [8] next board, [9] game, [16..31] class totals
+    float *lred = (float *)(scan + 32);                           // [4 waves][8 heads]
+    float *bw = lred + 32;                                        // [Tp16][8]  a - aconst per dirty token and head
+    float *pwred = bw + Tp16 * 8;                                 // [4 waves][8 heads][64]
+    unsigned short *orow = (unsigned short *)(pwred + 4 * 8 * 64);// [NH][FOLD_ROW] the board's output image
+    uint4 *rankv = (uint4 *)(orow + 8 * FOLD_ROW);                // SRC: [256 threads] ranks of the thread's first eight games, 16 bits each
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    int nvalid, my_lo = 0, my_per = 0;
+    unsigned long long cb_lo = 0ull, cb_hi = 0ull;
+    unsigned long long myflags = 0ull;
+    if (SRC) {
+        my_per = ((((a.src.n_games + 255) >> 8) + 7) >> 3) << 3;
+        my_lo = tid * my_per;
+        if (my_lo < a.src.flag_bytes) myflags = *(const unsigned long long *)(a.src.leaf_flag + my_lo);
+    }
+    // the quadratic form's and the score columns' B fragments live in registers for the whole launch (80 VGPRs; 20 KB per wave, once)
+    uint4 gh[4][2], gl[4][2], eh[2], el[2];
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; s2++) { gh[q][s2] = a.gfrag[((0 * 4 + q) * 2 + s2) * 64 + lane]; gl[q][s2] = a.gfrag[((1 * 4 + q) * 2 + s2) * 64 + lane]; }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; s2++) { eh[s2] = a.efrag[(0 * 2 + s2) * 64 + lane]; el[s2] = a.efrag[(1 * 2 + s2) * 64 + lane]; }
+    if (SRC) {
+        // leaf flags -> ranks (class descending, game ascending), as k_embed_pool_c
+        unsigned long long c_lo = 0ull, c_hi = 0ull;
+        for (int w = 0; w < my_per; w += 8)
+            if (my_lo + w < a.src.flag_bytes) {
+                const unsigned long long f = w == 0 ? myflags : *(const unsigned long long *)(a.src.leaf_flag + my_lo + w);
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const unsigned c = (unsigned)((f >> (8 * q)) & 0xffull);
+                    if (c) { if (c <= 4) c_lo += 1ull << (16 * (c - 1)); else c_hi += 1ull << (16 * (c - 5)); }
+                }
+            }
+        unsigned long long i_lo = c_lo, i_hi = c_hi;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned long long v_lo = __shfl_up(i_lo, off), v_hi = __shfl_up(i_hi, off);
+            if (lane >= off) { i_lo += v_lo; i_hi += v_hi; }
+        }
+        unsigned long long *wtot = (unsigned long long *)(scan + 16);           // [4 waves][2]
+        if (lane == 63) { wtot[2 * wave] = i_lo; wtot[2 * wave + 1] = i_hi; }
+        __syncthreads();
+        unsigned long long b_lo = 0ull, b_hi = 0ull, t_lo = 0ull, t_hi = 0ull;
+        for (int w = 0; w < 4; w++) {
+            if (w < wave) { b_lo += wtot[2 * w]; b_hi += wtot[2 * w + 1]; }
+            t_lo += wtot[2 * w]; t_hi += wtot[2 * w + 1];
+        }
+        const unsigned long long e_lo = b_lo + i_lo - c_lo, e_hi = b_hi + i_hi - c_hi;
+        unsigned start = 0;
+#pragma unroll
+        for (int c = 7; c >= 0; c--) {
+            const unsigned tot = (unsigned)(((c < 4 ? t_lo : t_hi) >> (16 * (c & 3))) & 0xffffull);
+            const unsigned long long cb = (unsigned long long)(start + (unsigned)(((c < 4 ? e_lo : e_hi) >> (16 * (c & 3))) & 0xffffull)) << (16 * (c & 3));
+            if (c < 4) cb_lo |= cb; else cb_hi |= cb;
+            start += tot;
+        }
+        nvalid = (int)start;
+        unsigned run = 0;
+        unsigned myrank[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const unsigned c = (unsigned)((myflags >> (8 * q)) & 0xffull);
+            unsigned r = 0xffffu;
+            if (c) {
+                const unsigned bsel = (unsigned)(((c <= 4 ? cb_lo : cb_hi) >> (16 * ((c - 1) & 3))) & 0xffffull);
+                r = bsel + ((run >> (4 * (c - 1))) & 0xfu);
+                run += 1u << (4 * (c - 1));
+            }
+            myrank[q >> 1] = (q & 1) ? ((myrank[q >> 1] & 0x0000ffffu) | (r << 16)) : ((myrank[q >> 1] & 0xffff0000u) | r);
+        }
+        rankv[tid] = make_uint4(myrank[0], myrank[1], myrank[2], myrank[3]);
+        if (blockIdx.x == 0 && tid == 0) { *a.src.n_leaf = nvalid; if (a.src.cache_stamp) *a.src.cache_stamp += 1u; }
+    } else {
+        nvalid = a.count ? min(a.n, *a.count) : a.n;
+    }
+    int board = blockIdx.x;
+    int ws_boards = 0, ws_tiles = 0;
+    if (board < nvalid) {
+    {
+        unsigned r[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) r[i] = (((tid >> (2 * i)) & 1) ? 0x3C00u : 0u) | (((tid >> (2 * i + 1)) & 1) ? 0x3C000000u : 0u);
+        alut[tid] = make_uint4(r[0], r[1], r[2], r[3]);
+    }
+    constexpr int ksz = KSZ, kk = KSZ * KSZ, pad = KSZ / 2;
+    const int RC = a.R * a.Cc, T = a.T, ncell = NC * RC;
+    const float sref = a.sref[l15];
+    const float invD = 1.0f / (float)D, ginv = a.inv_scales[0], einv = a.inv_scales[1];
+    int nxt = 0;
+    __syncthreads();
+
+    while (board < nvalid) {
+        int tv = tid;
+        asm volatile("" : "+v"(tv));
+        const int lane_b = tv & 63;
+        const int tj = tv - 1, tr = tj / a.Cc, tc = tj - tr * a.Cc;
+        const bool tlive = tv >= 1 && tv < T;
+        unsigned colmask = 0;
+#pragma unroll
+        for (int kx = 0; kx < ksz; kx++) { const int cc = tc + kx - pad; if (cc >= 0 && cc < a.Cc) colmask |= 1u << kx; }
+        int game = 0, player = 0;
+        if (SRC) {
+            int g = -1;
+            const uint4 rk = rankv[tid];
+            const unsigned myrank[4] = {rk.x, rk.y, rk.z, rk.w};
+#pragma unroll
+            for (int q = 0; q < 8; q++) if (((myrank[q >> 1] >> (16 * (q & 1))) & 0xffffu) == (unsigned)board) g = my_lo + q;
+            if (my_per > 8) {
+                unsigned long long run2 = 0ull;
+                for (int w = 0; w < my_per; w++) {
+                    const unsigned c = my_lo + w < a.src.flag_bytes ? (unsigned)a.src.leaf_flag[my_lo + w] : 0u;
+                    if (!c) continue;
+                    const unsigned r = (unsigned)(((c <= 4 ? cb_lo : cb_hi) >> (16 * ((c - 1) & 3))) & 0xffffull) + (unsigned)((run2 >> (8 * (c - 1))) & 0xffull);
+                    run2 += 1ull << (8 * (c - 1));
+                    if (w >= 8 && r == (unsigned)board) g = my_lo + w;
+                }
+            }
+            if (g >= 0) { scan[9] = g; a.src.leaf_slot[g] = board; }
+            __syncthreads();
+            game = scan[9];
+        }
+        unsigned wbits = 0;                             // lane i holds bits [32 (i-1), 32 i) of the board bit string (lane 0: zeros)
+        constexpr int NQ = 8;
+        if (ncell <= 64 * NQ) {
+            bool on[NQ];
+            if (SRC) {
+                int code[NQ], chq[NQ];
+                const auto *cells = a.src.leaf_cells + (size_t)game * a.src.rc_pad;
+#pragma unroll
+                for (int q = 0; q < NQ; q++) {
+                    const int e = min(q * 64 + lane_b, ncell - 1);
+                    chq[q] = (e >= RC) + (e >= 2 * RC);
+                    code[q] = cells[(unsigned)(e - chq[q] * RC)];
+                }
+                player = (a.src.to_move[game] + a.src.leaf_depth[game]) & 1;
+#pragma unroll
+                for (int q = 0; q < NQ; q++)
+                    on[q] = q * 64 + lane_b < ncell && (chq[q] == 2 ? player != 0 : ((code[q] >> (chq[q] ^ player)) & 1) != 0);
+            } else if (a.boards_f32) {
+                float raw[NQ];
+                const float *bp32 = (const float *)a.boards + (size_t)board * ncell;
+#pragma unroll
+                for (int q = 0; q < NQ; q++) raw[q] = bp32[(unsigned)min(q * 64 + lane_b, ncell - 1)];
+#pragma unroll
+                for (int q = 0; q < NQ; q++) on[q] = q * 64 + lane_b < ncell && raw[q] != 0.0f;
+            } else {
+                unsigned short raw[NQ];
+                const unsigned short *bp16 = (const unsigned short *)a.boards + (size_t)board * ncell;
+#pragma unroll
+                for (int q = 0; q < NQ; q++) raw[q] = bp16[(unsigned)min(q * 64 + lane_b, ncell - 1)];
+#pragma unroll
+                for (int q = 0; q < NQ; q++) on[q] = q * 64 + lane_b < ncell && (raw[q] & 0x7fff) != 0;
+            }
+#pragma unroll
+            for (int q = 0; q < NQ; q++) {
+                const unsigned long long m = __ballot(on[q]);
+                if ((lane_b - 1) >> 1 == q && lane_b >= 1) wbits = ((lane_b - 1) & 1) ? (unsigned)(m >> 32) : (unsigned)m;
+            }
+        } else {
+            if (SRC) player = (a.src.to_move[game] + a.src.leaf_depth[game]) & 1;
+            for (int q = 0; q * 64 < ncell; q++) {
+                const int e = q * 64 + lane;
+                bool on = false;
+                if (SRC) {
+                    if (e < ncell) {
+                        const int ch = (e >= RC) + (e >= 2 * RC), cell = e - ch * RC;
+                        const int code = a.src.leaf_cells[(size_t)game * a.src.rc_pad + cell];
+                        on = ch == 2 ? player != 0 : ((code >> (ch ^ player)) & 1) != 0;
+                    }
+                } else if (e < ncell)
+                    on = a.boards_f32 ? ((const float *)a.boards)[(size_t)board * ncell + e] != 0.0f
+                                      : (((const unsigned short *)a.boards)[(size_t)board * ncell + e] & 0x7fff) != 0;
+                const unsigned long long m = __ballot(on);
+                if ((lane - 1) >> 1 == q && lane >= 1) wbits = ((lane - 1) & 1) ? (unsigned)(m >> 32) : (unsigned)m;
+            }
+        }
+        // ---- patch bits of this thread's token; dirty = some stone in the patch ----
+        unsigned long long plo = 0;
+        {
+            unsigned lo[NC * KSZ], hi[NC * KSZ];
+#pragma unroll
+            for (int ch = 0; ch < NC; ch++)
+#pragma unroll
+                for (int ky = 0; ky < KSZ; ky++) {
+                    const int rr = tr + ky - pad;
+                    int off = 32 + ch * RC + (rr < 0 ? 0 : (rr >= a.R ? a.R - 1 : rr)) * a.Cc + (tc - pad);
+                    if (!tlive) off = 32;
+                    lo[ch * KSZ + ky] = __shfl(wbits, off >> 5); hi[ch * KSZ + ky] = __shfl(wbits, (off >> 5) + 1);
+                }
+#pragma unroll
+            for (int ch = 0; ch < NC; ch++)
+#pragma unroll
+                for (int ky = 0; ky < KSZ; ky++) {
+                    const int rr = tr + ky - pad;
+                    int off = 32 + ch * RC + (rr < 0 ? 0 : (rr >= a.R ? a.R - 1 : rr)) * a.Cc + (tc - pad);
+                    if (!tlive) off = 32;
+                    unsigned bits = __funnelshift_r(lo[ch * KSZ + ky], hi[ch * KSZ + ky], off & 31) & colmask;
+                    if (!tlive || rr < 0 || rr >= a.R) bits = 0;
+                    plo |= (unsigned long long)bits << (ch * kk + ky * ksz);
+                }
+        }
+        const bool dirty = plo != 0ull;
+        const unsigned long long dm = __ballot(dirty);
+        if (lane == 0) scan[4 + wave] = __popcll(dm);
+        __syncthreads();                                  // (also: every wave is done with the previous board's lists and output image)
+        int dpos = __popcll(dm & ((1ull << lane) - 1ull));
+        for (int w = 0; w < wave; w++) dpos += scan[4 + w];
+        const int nd = scan[4] + scan[5] + scan[6] + scan[7];
+        const int ntile = (nd + 15) >> 4;
+        if (dirty) {
+            dlist[dpos] = tid;
+            pbits[dpos] = make_uint2((unsigned)plo, (unsigned)(plo >> 32));
+        }
+        if (tid < 16 && nd + tid < ntile * 16) { dlist[nd + tid] = T; pbits[nd + tid] = make_uint2(0u, 0u); }   // null tokens fill the last tile
+        __syncthreads();
+        ws_boards += 1; ws_tiles += ntile;
+
+        // ---- the wave's tiles ----
+        float L = 0.f;                                    // per head (lane&15 < NH): this lane group's share of sum (w - wconst)
+        f32x4 Pw[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) Pw[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        bool drew = false;
+        for (int tile = wave; tile < ntile; tile += 4) {
+            const int base = 16 * tile;
+            const int4 tk = *(const int4 *)(dlist + base + 4 * l4);
+            const int tks[4] = {tk.x, tk.y, tk.z, tk.w};
+            float ut[4][4], scn[4], wcn[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const unsigned ou = ((unsigned)tks[r] * 64u + (unsigned)l15) * 4u, os = ((unsigned)tks[r] * 16u + (unsigned)l15) * 4u;
+#pragma unroll
+                for (int q = 0; q < 4; q++) ut[r][q] = *(const float *)((const char *)a.u2T + ou + 64u * q);
+                scn[r] = *(const float *)((const char *)a.scoreT + os);
+                wcn[r] = *(const float *)((const char *)a.wcT + os);
+            }
+            if (tid == 0 && !drew) {                      // next board: the round trip hides under this tile
+                __builtin_amdgcn_sched_barrier(0);
+                nxt = atomicAdd(a.sched, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                drew = true;
+            }
+            const uint2 pa = pbits[base + l15];
+            union { uint4 u; f16x8 v; } af[2];
+            af[0].u = alut[(pa.x >> (8 * l4)) & 0xffu];
+            af[1].u = alut[(pa.y >> (8 * l4)) & 0xffu];
+            f32x4 Y[4], E = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < 4; q++) Y[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s2 = 0; s2 < 2; s2++) {
+                { union { uint4 u; f16x8 v; } b; b.u = eh[s2]; E = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[s2].v, b.v, E, 0, 0, 0);
+                  b.u = el[s2]; E = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[s2].v, b.v, E, 0, 0, 0); }
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    union { uint4 u; f16x8 v; } b;
+                    b.u = gh[q][s2]; Y[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[s2].v, b.v, Y[q], 0, 0, 0);
+                    b.u = gl[q][s2]; Y[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[s2].v, b.v, Y[q], 0, 0, 0);
+                }
+            }
+            // ---- per token (row 4 l4 + r): variance from the quadratic form, scores, weights ----
+            const int4 pq0 = *(const int4 *)(pbits + base + 4 * l4), pq1 = *(const int4 *)(pbits + base + 4 * l4 + 2);
+            const unsigned prx[4] = {(unsigned)pq0.x, (unsigned)pq0.z, (unsigned)pq1.x, (unsigned)pq1.z};
+            const unsigned pry[4] = {(unsigned)pq0.y, (unsigned)pq0.w, (unsigned)pq1.y, (unsigned)pq1.w};
+            float av[4];
+            unsigned bsel[4][4];                           // patch bit of token r at column 16 q + l15 (0 / 1)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                float qd = 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const unsigned bit = ((q < 2 ? prx[r] : pry[r]) >> (16 * (q & 1) + l15)) & 1u;
+                    bsel[r][q] = bit;
+                    qd += bit ? fmaf(Y[q][r], ginv, ut[r][q]) : 0.f;
+                }
+                qd = row16_sum(qd);
+                const float e = fmaf(E[r], einv, scn[r]);                        // head lanes: the raw score; lane 15: n_t
+                const float nt = __shfl(e, (lane & 48) | 15);
+                const float rstd = __builtin_amdgcn_rsqf(fmaxf((qd + nt) * invD, 0.f) + a.eps);
+                const float w = __expf(rstd * e - sref);                           // (0 beyond the heads: their reference is +1e30)
+                const float rc = __shfl(wcn[r], (lane & 48) | 15);
+                av[r] = w * rstd;
+                L += w - wcn[r];
+                if (l15 < NH) bw[(base + 4 * l4 + r) * 8 + l15] = av[r] - wcn[r] * rc;
+            }
+            // ---- pooled patch: Pw[h][k] += a_t[h] p_tk, a as bf16 hi + remainder in the eight k-slots of the lane group ----
+            union { bf16x8 v; s16x4 h[2]; } wa;
+            wa.h[0] = pack4_bf16(f32x2{av[0], av[1]}, f32x2{av[2], av[3]});
+            {
+                const u32x2 hh = __builtin_bit_cast(u32x2, wa.h[0]);
+                const float r0 = av[0] - __uint_as_float(hh[0] << 16), r1 = av[1] - __uint_as_float(hh[0] & 0xffff0000u);
+                const float r2 = av[2] - __uint_as_float(hh[1] << 16), r3 = av[3] - __uint_as_float(hh[1] & 0xffff0000u);
+                wa.h[1] = pack4_bf16(f32x2{r0, r1}, f32x2{r2, r3});
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const unsigned b01 = (bsel[0][q] ? 0x3F80u : 0u) | (bsel[1][q] ? 0x3F800000u : 0u);
+                const unsigned b23 = (bsel[2][q] ? 0x3F80u : 0u) | (bsel[3][q] ? 0x3F800000u : 0u);
+                union { uint4 u; bf16x8 v; } pb;
+                pb.u = make_uint4(b01, b23, b01, b23);
+                Pw[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa.v, pb.v, Pw[q], 0, 0, 0);
+            }
+        }
+        if (tid == 0 && !drew) nxt = atomicAdd(a.sched, 1);
+        // ---- the waves' sums meet ----
+        {
+            float Lw = L + __shfl_xor(L, 16);
+            Lw += __shfl_xor(Lw, 32);
+            if (lane < 8) lred[wave * 8 + lane] = lane < NH ? Lw : 0.f;
+            if (l4 < 2) {
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+#pragma unroll
+                    for (int j = 0; j < 4; j++) pwred[(wave * 8 + 4 * l4 + j) * 64 + 16 * q + l15] = Pw[q][j];
+            }
+        }
+        __syncthreads();
+        // ---- output image: [head][0, T) token weights / L, [T, T+3) 1 / L (hi, lo, hi), [256, 320) pooled patch / L ----
+        {
+            float inv[NH];
+#pragma unroll
+            for (int h = 0; h < NH; h++) inv[h] = 1.0f / (a.lall[h] + ((lred[h] + lred[8 + h]) + (lred[16 + h] + lred[24 + h])));
+            const bool isL = tid >= T && tid < T + 3;
+#pragma unroll
+            for (int h = 0; h < NH; h++) {
+                float v = 0.f;
+                if (dirty) v = bw[dpos * 8 + h] * inv[h];
+                unsigned o = bf16_rne(v);
+                if (isL) {
+                    const unsigned hi = bf16_rne(inv[h]);
+                    o = tid == T + 1 ? bf16_rne(inv[h] - __uint_as_float(hi << 16)) : hi;
+                }
+                orow[h * FOLD_ROW + tid] = (unsigned short)o;
+            }
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                const int e = 2 * tid + i, h = e >> 6, k = e & 63;
+                if (h < NH) {
+                    const float v = ((pwred[(0 * 8 + h) * 64 + k] + pwred[(1 * 8 + h) * 64 + k]) + (pwred[(2 * 8 + h) * 64 + k] + pwred[(3 * 8 + h) * 64 + k])) * inv[h];
+                    orow[h * FOLD_ROW + 256 + k] = (unsigned short)bf16_rne(v);
+                    orow[h * FOLD_ROW + 320 + k] = 0;
+                }
+            }
+        }
+        __syncthreads();
+        {
+            const uint4 *src4 = (const uint4 *)orow;
+            uint4 *dst4 = (uint4 *)(a.out + (size_t)board * NH * FOLD_ROW);
+            for (int i = tid; i < NH * FOLD_ROW / 8; i += 256) dst4[i] = src4[i];
+        }
+        if (tid == 0) {
+            if (nxt == nvalid - 1) a.sched[0] = 0;
+            scan[8] = (int)gridDim.x + nxt;
+        }
+        __syncthreads();
+        board = scan[8];
+    }
+    }
+    if (a.wstats != nullptr && tid == 0 && ws_boards) { atomicAdd(a.wstats, (unsigned long long)ws_boards); atomicAdd(a.wstats + 1, (unsigned long long)ws_tiles); }
+}
+
+template <int NC, int KSZ, int NH, bool SRC>
+int launch_embed_fold(const EmbedFoldArgs &a, hipStream_t st) {
+    const int tp16 = ((a.T + 15) / 16) * 16;
+    const int lds = 256 * 16 + tp16 * 8 + tp16 * 4 + 128 + 128 + tp16 * 32 + 4 * 8 * 64 * 4 + 8 * FOLD_ROW * 2 + (SRC ? 256 * 16 : 0);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void *)k_embed_fold<NC, KSZ, NH, SRC>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return AZK_ERR_HIP;
+        attr_set = true;
+    }
+    const int blocks = a.n < 512 ? a.n : 512;
+    k_embed_fold<NC, KSZ, NH, SRC><<<blocks, 256, lds, st>>>(a);
+    return hipGetLastError() == hipSuccess ? AZK_OK : AZK_ERR_HIP;
+}
+}  // namespace
+
+static int32_t embed_fold_impl(const void *boards_dev, int32_t boards_are_f32, const azk_leaf_source *src, const azk_embed_fold_consts *k,
+                               void *rows_out, int32_t n, int32_t channels, int32_t rows, int32_t cols, const int32_t *n_valid_dev,
+                               int32_t *sched_dev, void *stream) {
+    if ((!boards_dev && !src) || !k || !rows_out || !sched_dev) return AZK_ERR_ARG;
+    if (!k->g_frag || !k->e_frag || !k->u2_tok || !k->score_tok || !k->wconst_tok || !k->l_all || !k->score_ref || !k->inv_scales) return AZK_ERR_ARG;
+    const int ksize = k->ksize;
+    if (n < 0 || channels < 1 || rows < 1 || cols < 1 || ksize < 1 || (ksize & 1) == 0 || channels * ksize * ksize > 64) return AZK_ERR_ARG;
+    if (channels * rows * cols > 62 * 32 || k->embed_dim != 512) return AZK_ERR_ARG;
+    if (rows * cols + 1 + 3 > 256) return AZK_ERR_ARG;             // one thread per token, three more for 1 / L
+    if (k->num_heads != 8 && k->num_heads != 4) return AZK_ERR_ARG;
+    if (n == 0) return AZK_OK;
+    EmbedFoldArgs a;
+    memset(&a, 0, sizeof a);
+    a.boards = boards_dev; a.boards_f32 = boards_are_f32; a.gfrag = (const uint4 *)k->g_frag; a.efrag = (const uint4 *)k->e_frag;
+    a.u2T = k->u2_tok; a.scoreT = k->score_tok; a.wcT = k->wconst_tok; a.lall = k->l_all; a.sref = k->score_ref; a.inv_scales = k->inv_scales;
+    a.out = (unsigned short *)rows_out; a.count = n_valid_dev; a.sched = sched_dev; a.wstats = (unsigned long long *)k->work_stats;
+    a.n = n; a.R = rows; a.Cc = cols; a.T = rows * cols + 1; a.eps = k->ln_eps;
+    if (src) a.src = *src;
+    hipStream_t st = (hipStream_t)stream;
+    const int nh = k->num_heads;
+#define CASE(NC_, KSZ_, NH_) if (channels == NC_ && ksize == KSZ_ && nh == NH_) \
+        return src ? launch_embed_fold<NC_, KSZ_, NH_, true>(a, st) : launch_embed_fold<NC_, KSZ_, NH_, false>(a, st)
+    CASE(2, 5, 8); CASE(2, 5, 4); CASE(2, 3, 8); CASE(2, 3, 4); CASE(3, 3, 8); CASE(3, 3, 4);
+#undef CASE
+    return AZK_ERR_ARG;
+}
+
+extern "C" int32_t azk_nn_embed_fold(const void *boards_dev, int32_t boards_are_f32, const azk_embed_fold_consts *consts, void *rows_out_bf16_dev,
+                                     int32_t n, int32_t channels, int32_t rows, int32_t cols, const int32_t *n_valid_dev, int32_t *sched_dev,
+                                     void *stream) {
+    if (!boards_dev) return AZK_ERR_ARG;
+    return embed_fold_impl(boards_dev, boards_are_f32, nullptr, consts, rows_out_bf16_dev, n, channels, rows, cols, n_valid_dev, sched_dev, stream);
+}
+
+extern "C" int32_t azk_nn_embed_fold_leaves(const azk_leaf_source *src, const azk_embed_fold_consts *consts, void *rows_out_bf16_dev,
+                                            int32_t *sched_dev, void *stream) {
+    if (!src || !src->leaf_flag || !src->leaf_cells || !src->to_move || !src->leaf_depth || !src->leaf_slot || !src->n_leaf) return AZK_ERR_ARG;
+    if (src->n_games < 1 || src->rows * src->cols != src->rc || src->flag_bytes < src->n_games) return AZK_ERR_ARG;
+    if (src->n_games > AZK_EMBED_POOL_COMPACT_MAX_SLOTS) return AZK_ERR_ARG;
+    return embed_fold_impl(nullptr, 0, src, consts, rows_out_bf16_dev, src->n_games, src->planes, src->rows, src->cols, nullptr, sched_dev, stream);
+}
+
+// =====================================================================================================
 // cls-row tail (nn.py:54-60, 78-83 for the one row the heads read): small-M GEMMs with a device-side row count.
 //   k_gemm_rows: C[M][N] = A[M][K] (bf16, row-major) x W^T, W packed in MFMA B-fragment order (one 16-byte load per
 //   fragment, 1 KB contiguous per wave); wave tile 64 rows x 64 columns (16 accumulators), no LDS: the four waves of a
@@ -2367,7 +2838,7 @@ int launch_tail(TailArgs &a, hipStream_t st) {
 
 extern "C" int32_t azk_nn_tail_gemm(const azk_tail_gemm *t, void *stream) {
     if (!t || !t->a_bf16 || !t->w_packed || t->m < 0 || t->n_out < 64 || (t->n_out & 63) || t->nbatch < 1) return AZK_ERR_ARG;
-    if ((t->k != 512 && t->k != 2048) || t->lda < t->k || (t->lda & 7) || (t->a_batch_stride & 7)) return AZK_ERR_ARG;
+    if ((t->k != 512 && t->k != 2048 && t->k != 384) || t->lda < t->k || (t->lda & 7) || (t->a_batch_stride & 7)) return AZK_ERR_ARG;
     if (t->epilogue < 0 || t->epilogue > 3 || (t->layernorm_a && (t->k != 512 || !t->a_stats || t->a_stats_groups != 8))) return AZK_ERR_ARG;
     if (t->epilogue == TAIL_EPI_HEADS ? (!t->logits_out || !t->values_out || t->action_dim + 1 > t->n_out * t->nbatch) : (!t->out_bf16 || t->ldo < t->n_out * t->nbatch || (t->ldo & 3)))
         return AZK_ERR_ARG;
@@ -2381,6 +2852,8 @@ extern "C" int32_t azk_nn_tail_gemm(const azk_tail_gemm *t, void *stream) {
     a.action_dim = t->action_dim; a.stats_in = t->a_stats; a.stats_groups = t->a_stats_groups; a.stats_out = t->stats_out;
     hipStream_t st = (hipStream_t)stream;
     const bool wide = t->n_out % 128 == 0 && t->n_out >= 1024;          // many column groups: 2 x 2 waves share A rows and weight fragments in L1
+    if (t->k == 384)                                                    // the embed-fold rows (AZK_EMBED_FOLD_ROW) against [D_t; U_all; M_h]: K split over four waves
+        return !t->layernorm_a && t->epilogue == TAIL_EPI_BF16 ? launch_tail<2, 2, 3, 0, TAIL_EPI_BF16, 1, 1, 4>(a, st) : AZK_ERR_ARG;
     if (t->k == 512) {
         if (t->layernorm_a) {
             if (t->epilogue == TAIL_EPI_GELU) return wide ? launch_tail<2, 4, 16, 1, TAIL_EPI_GELU, 2, 2>(a, st) : launch_tail<2, 2, 16, 1, TAIL_EPI_GELU, 1, 1>(a, st);

@@ -153,6 +153,8 @@ class PolicyValueNet:
         self._tail_ws_retired = []      # outgrown workspaces, kept alive (captured graphs may hold their addresses)
         self._compact = None            # azk.EmbedPoolTables when the compacting kernel covers this configuration (static softmax reference)
         self.use_compact = True
+        self._foldu = None              # azk.EmbedFoldTables when the patch-pooling kernel (k_embed_fold) covers this configuration
+        self.use_fold_u = True
         self._scheds = {}               # work-queue words of the compacting kernel, one buffer per board source (= per stepping stream)
         self.kernel_timers = None   # optional timers with start()/stop() (HIP events): (embed+pool, tail) on the fused path, (embed, pool, tail) otherwise
         self.live_count = None      # optional int32 CUDA tensor: number of valid rows at the head of the batch (graph stepping)
@@ -176,7 +178,7 @@ class PolicyValueNet:
         want = reference_key_shapes(self.cfg)
         for k_, shape in want.items():
             assert k_ in sd and tuple(sd[k_].shape) == tuple(shape), k_
-        names = ("w", "_hip", "_fold", "_compact", "_exact")
+        names = ("w", "_hip", "_fold", "_compact", "_exact", "_foldu")
         old = {n_: getattr(self, n_, None) for n_ in names}
         old_flags = (self.fused_embed_pool, self.chain_tail, self.hip_tail, self._gelu_epilogue)
         self.master = {k_: torch.as_tensor(sd[k_]).detach().to("cpu", torch.float32).clone() for k_ in want}
@@ -201,6 +203,7 @@ class PolicyValueNet:
         self._fold = None
         self._gelu_epilogue = False
         self._exact = None
+        self._foldu = None
         if self.device.type == "cuda" and self.dtype == torch.bfloat16:
             self._prepare_hip_embed()
             if self._hip is not None:
@@ -343,6 +346,83 @@ class PolicyValueNet:
         x2 = x1 + hh @ f8(r["W3"]).t() + f8(r["b3"])
         out = ln(x2) @ f8(r["WhG"]).t() + f8(r["bhG"])
         return out[:, :A].float(), torch.tanh(out[:, A:A + 1]).float(), z.float()
+
+    def fold_u(self, dev=None):
+        """Operands of the patch-pooling form of the cls path (csrc/azk_nn.hip k_embed_fold), float64, from the float32 master weights.
+        With x_t = Wc p_t + cpos_t (p_t the 0/1 patch of token t) everything LayerNorm1 and the cls attention need of a token is a
+        function of its <= 64 patch bits, and the pooled row is LINEAR in x_t, so the D-wide token rows are never formed:
+            x_t - mean(x_t) = Wt p_t + ct_t                 Wt = Wc - column means, ct_t = cpos_t - mean(cpos_t)
+            D var_t        = p_t' G p_t + 2 U_t . p_t + n_t   G = Wt' Wt, U_t = Wt' ct_t, n_t = |ct_t|^2
+            s_t[h]         = rstd_t (S_h . p_t + sc_t[h])     S_h = Wt' m'_h, sc_t[h] = m'_h . ct_t        (m'_h: exact_fold's m_n)
+            u_h = Wv'_h z_h = (1 / L_h) sum_t a_t[h] (M_h p_t + D_t[h]),   a = w rstd,  M_h = Wv'_h Wt,  D_t[h] = Wv'_h ct_t
+        u is the output of the tail's first link (nn.py:54-56 up to the value projection).  The kernel emits, per board and head,
+        the token weights b_t = (a_t - ac_t) / L (ac: the token as an empty-patch constant; zero for tokens no stone reaches), 1 / L,
+        and the pooled patch sum_t a_t p_t / L; one batched GEMM against [D_t[h]; U_all[h]; M_h] then gives u.  Returns None when the
+        configuration is not covered."""
+        cfg, m = self.cfg, self.master
+        D, H, T = cfg.embed_dim, cfg.num_heads, cfg.tokens
+        kreal = cfg.channels * cfg.patch_size ** 2
+        if not (cfg.depth == 1 and D == 512 and H in (4, 8) and D // H == 64 and T + 3 <= 256 and kreal <= 64 and cfg.channels in (2, 3)
+                and cfg.patch_size in (3, 5)):
+            return None
+        dev = self.device if dev is None else torch.device(dev)
+        dh, eps, kp = D // H, 1e-5, 64
+        dd = lambda k_: m[k_].to(dev, torch.float64)
+        Wc = dd("embedding.patch_embed.patch_embed.weight").reshape(D, kreal)
+        cpos = dd("embedding.pos_embedding")[0].clone()
+        cpos[0] += dd("embedding.cls_token")[0, 0]
+        cpos[1:] += dd("embedding.patch_embed.patch_embed.bias")
+        b = "blocks.0."
+        g1, b1 = dd(b + "norm1.weight"), dd(b + "norm1.bias")
+        Wi, bi = dd(b + "attn.in_proj_weight"), dd(b + "attn.in_proj_bias")
+        h0 = F.layer_norm(cpos[0], (D,), g1, b1, eps)
+        q = (Wi[:D] @ h0 + bi[:D]).view(H, dh)
+        m_n = torch.einsum("he,hed->hd", q, Wi[D:2 * D].view(H, dh, D)) * (1.0 / math.sqrt(dh)) * g1      # [H, D]
+        if float((math.sqrt(D) * m_n.norm(dim=1)).max()) > 40.0:
+            return None
+        Wvn = (Wi[2 * D:].view(H, dh, D) * g1).reshape(D, D)                                            # row h*dh + j = Wv'_h[j]
+        Wt = torch.zeros(D, kp, dtype=torch.float64, device=dev)
+        Wt[:, :kreal] = Wc - Wc.mean(0, keepdim=True)
+        ct = cpos - cpos.mean(1, keepdim=True)
+        G = Wt.t() @ Wt                                                                                  # [kp, kp]
+        U2 = 2.0 * (ct @ Wt)                                                                             # [T, kp]
+        nt = (ct * ct).sum(1)                                                                            # [T]
+        ext = torch.zeros(kp, 16, dtype=torch.float64, device=dev)
+        ext[:, :H] = Wt.t() @ m_n.t()
+        sct = ct @ m_n.t()                                                                               # [T, H]
+        Dtab = ct @ Wvn.t()                                                                              # [T, D]
+        M = Wvn @ Wt                                                                                     # [D, kp]
+        rstdc = 1.0 / torch.sqrt(nt / D + eps)
+        s_c = rstdc[:, None] * sct
+        ref = s_c.max(0).values                                                                          # static softmax reference per head
+        wc = torch.exp(s_c - ref[None])
+        ac = wc * rstdc[:, None]
+        uall = torch.einsum("th,thj->hj", ac, Dtab.view(T, H, dh)).reshape(D)
+        return dict(G=G, ext=ext, U2=U2, nt=nt, sct=sct, Dtab=Dtab, M=M, rstdc=rstdc, ref=ref, wc=wc, uall=uall, lall=wc.sum(0), kreal=kreal)
+
+    def forward_fold_u_emulated(self, x, r=None):
+        """u (float64 [n, D]) by fold_u's formulas, step by step in torch on any device: checks the fold against the plain forward on
+        the CPU and the kernel against the fold on the GPU.  Also returns the kernel's outputs before rounding: b / L [n, H, T],
+        1 / L [n, H], pooled patch / L [n, H, kp]."""
+        cfg = self.cfg
+        r = r or self.fold_u(x.device)
+        D, H, T, k = cfg.embed_dim, cfg.num_heads, cfg.tokens, cfg.patch_size
+        n, kp = x.shape[0], r["G"].shape[0]
+        cols = F.unfold(x.double(), kernel_size=k, padding=k // 2).transpose(1, 2)
+        P = torch.zeros(n, T, kp, dtype=torch.float64, device=x.device)
+        P[:, 1:, :cols.shape[2]] = cols
+        var = (torch.einsum("ntk,kl,ntl->nt", P, r["G"], P) + (P * r["U2"][None]).sum(2) + r["nt"][None]) / D
+        rstd = 1.0 / torch.sqrt(var.clamp_min(0.0) + 1e-5)
+        s = rstd[..., None] * (P @ r["ext"][:, :H] + r["sct"][None])
+        w = torch.exp(s - r["ref"][None, None])
+        a = w * rstd[..., None]
+        L = r["lall"][None] + (w - r["wc"][None]).sum(1)                                                 # [n, H]
+        bw = (a - (r["wc"] * r["rstdc"][:, None])[None]) / L[:, None, :]                                 # [n, T, H]
+        pw = torch.einsum("nth,ntk->nhk", a, P) / L[..., None]                                           # [n, H, kp]
+        dh = D // H
+        u = (torch.einsum("nth,thj->nhj", bw, r["Dtab"].view(T, H, dh)) + r["uall"].view(1, H, dh) / L[..., None]
+             + torch.einsum("nhk,hjk->nhj", pw, r["M"].view(H, dh, kp))).reshape(n, D)
+        return u, bw.transpose(1, 2), 1.0 / L, pw
 
     def forward_exact(self, x):
         """The fp32-accurate folded cls path: boards (or the engine's pending leaves) -> z float32 [n, H, D] -> logits, tanh(value)."""
@@ -543,6 +623,11 @@ class PolicyValueNet:
                 f["W0GP"] = azk.pack_linear_weight(W0 * g2[None, :])
                 f["b0G_f"] = (W0 @ b2 + b0_).float().contiguous()
                 f["b3_f"] = m[b + "mlp.3.bias"].to(dev, torch.float32).contiguous()
+                if self.fused_embed_pool:
+                    # the patch-pooling form of embedding + pooling + value projection (k_embed_fold + one batched GEMM), tables in float64
+                    r = self.fold_u(dev)
+                    if r is not None:
+                        self._foldu = azk.EmbedFoldTables(r, H, cfg.patch_size, D, dev)
             for k_, src in (("ln2_w", b + "norm2.weight"), ("ln2_b", b + "norm2.bias"), ("lnf_w", "norm.weight"),
                             ("lnf_b", "norm.bias"), ("b3", b + "mlp.3.bias")):
                 f[k_] = m[src].to(dev, torch.float32).contiguous()
@@ -643,7 +728,11 @@ class PolicyValueNet:
                       st2=torch.empty((rows, D // 64, 2), dtype=torch.float32, device=dev))
             self._tail_ws[key] = ws
         ws = {k_: (v[:n] if k_ != "rows" else v) for k_, v in ws.items()}
-        self._launch(azk.nn_tail_gemm, z.view(n, H * D), f["WvHP"], D // H, D, azk.TAIL_BF16, nbatch=H, a_batch_stride=D, out=ws["u"], count=cnt)
+        if z.shape[-1] == azk.EMBED_FOLD_ROW:      # k_embed_fold's rows against [D_t; U_all; M_h]: the value-projected row directly
+            kf = azk.EMBED_FOLD_ROW
+            self._launch(azk.nn_tail_gemm, z.view(n, H * kf), self._foldu.weight, D // H, kf, azk.TAIL_BF16, nbatch=H, a_batch_stride=kf, out=ws["u"], count=cnt)
+        else:
+            self._launch(azk.nn_tail_gemm, z.view(n, H * D), f["WvHP"], D // H, D, azk.TAIL_BF16, nbatch=H, a_batch_stride=D, out=ws["u"], count=cnt)
         self._launch(azk.nn_tail_gemm, ws["u"], f["WoP"], D, D, azk.TAIL_BF16, bias=f["bias1_f"], out=ws["x1"], stats_out=ws["st1"], count=cnt)
         self._launch(azk.nn_tail_gemm, ws["x1"], f["W0GP"], 4 * D, D, azk.TAIL_GELU, bias=f["b0G_f"], out=ws["hh"], a_stats=ws["st1"], count=cnt)
         self._launch(azk.nn_tail_gemm, ws["hh"], f["W3P"], D, 4 * D, azk.TAIL_RESID, bias=f["b3_f"], resid=ws["x1"], out=ws["x2"], stats_out=ws["st2"], count=cnt)
@@ -881,7 +970,15 @@ class PolicyValueNet:
                     if x.dtype not in (torch.bfloat16, torch.float32):
                         x = x.float()
                     compact_ok = self.leaf_source is None or self.leaf_source.n_games <= azk.EMBED_POOL_COMPACT_MAX_SLOTS
-                    if self.fused_embed_pool and self._compact is not None and self.use_compact and compact_ok:
+                    if self._foldu is not None and self.use_fold_u and self.chain_tail and self.use_chain_tail and compact_ok:
+                        # the token rows are never formed: per head the token weights, 1 / L and the pooled patch (k_embed_fold);
+                        # the tail's first GEMM turns them into the value-projected row
+                        if self.leaf_source is not None:
+                            z = azk.nn_embed_fold_leaves(self.leaf_source, self._foldu, self._sched_for(self.leaf_source), timers=self.kernel_timers)
+                        else:
+                            z = azk.nn_embed_fold(x.contiguous(), self._foldu, self.cfg.rows, self.cfg.cols, self._sched_for(None),
+                                                  count=self.live_count, timers=self.kernel_timers)
+                    elif self.fused_embed_pool and self._compact is not None and self.use_compact and compact_ok:
                         # only the tokens a stone can reach are evaluated (k_embed_pool_c); boards pulled from a device queue
                         if self.leaf_source is not None:
                             z = azk.nn_embed_pool_compact_leaves(self.leaf_source, self._compact, self._sched_for(self.leaf_source),

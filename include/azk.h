@@ -29,7 +29,7 @@ extern "C" {
 
 /* 2: azk_emit_finished's game_base_dev became int64*, azk_leaf_source gained cache_stamp, azk_config gained cache_shared /
  * leaves_per_step (round 2); callers compare azk_abi_version() with the header they were built against */
-#define AZK_ABI_VERSION 2
+#define AZK_ABI_VERSION 3
 
 /* games (games/tictactoe.py, games/connect4.py, games/gomoku.py) */
 #define AZK_TICTACTOE 0
@@ -398,7 +398,7 @@ int32_t azk_nn_gemm_rows(const void *a_bf16_dev, int32_t lda, const void *w_pack
  *   a_bf16 [m][lda] row-major; batch b reads A columns [b * a_batch_stride, b * a_batch_stride + k), multiplies them with
  *   weight block b and writes output columns [b * n_out, (b + 1) * n_out) - nbatch = 1 is a plain GEMM, nbatch = heads is the
  *   block-diagonal per-head value projection.  w_packed: nbatch consecutive nn.Linear weights [n_out][k] in
- *   azk_nn_gemm_rows' fragment packing.  k = 512 or 2048; n_out a multiple of 64.
+ *   azk_nn_gemm_rows' fragment packing.  k = 512 or 2048 (or 384 = AZK_EMBED_FOLD_ROW, plain bf16 epilogue only); n_out a multiple of 64.
  *   layernorm_a (k = 512): A = LayerNorm(rows) without affine (fold it into weight / bias: W diag(gamma), W beta + b); the row
  *            statistics are read from a_stats [m][a_stats_groups][2] = per 64-column group (sum, sum of squares) of the row, as
  *            left by the GEMM that produced A (its stats_out); a_stats_groups must be 8 (= k / 64; 64-byte rows, 16-byte aligned).
@@ -437,6 +437,43 @@ int32_t azk_nn_layernorm_sum(const float *partials_dev, int32_t nsplit, int32_t 
 int32_t azk_nn_heads_finalize_sum(const float *partials_dev, int32_t nsplit, int32_t m_stride, int32_t ld, const float *bias_dev,
                                   int32_t action_dim, int32_t n, float *logits_out_dev, float *values_out_dev,
                                   const int32_t *n_valid_dev, void *stream);
+
+/* azk_nn_embed_fold(_leaves) - the embedding + cls pooling WITHOUT forming the token rows (round 3; ai/nn.py:7-27, 36-56 for the
+ * cls row, as azk_nn_embed_pool_compact + the first azk_nn_tail_gemm link).  With x_t = Wc p_t + cpos_t (p_t: the 0/1 patch of token
+ * t, <= 64 bits) LayerNorm1's statistics and the cls scores of a token are functions of its patch bits alone:
+ *     x_t - mean(x_t) = Wt p_t + ct_t        D var_t = p_t' G p_t + u2_t . p_t + n_t        s_t[h] = rstd_t (S_h . p_t + sc_t[h])
+ * (Wt = Wc minus its column means, ct_t = cpos_t minus its mean, G = Wt' Wt, u2_t = 2 Wt' ct_t, n_t = |ct_t|^2, S_h = Wt' m'_h,
+ * sc_t[h] = m'_h . ct_t), and the value-projected pooled row is linear in x_t:
+ *     u_h = Wv'_h z_h = (1 / L_h) sum_t a_t[h] (M_h p_t + D_t[h]),   a = w rstd,   M_h = Wv'_h Wt,   D_t[h] = Wv'_h ct_t.
+ * The kernel evaluates the tokens a stone can reach (the rest are constants of the weights, summed ahead: U_all, l_all) and writes,
+ * per board and head, one bf16 row of AZK_EMBED_FOLD_ROW entries:
+ *     [0, T)       (a_t - aconst_t) / L      (0 for tokens no stone reaches)
+ *     [T, T+3)     1 / L as bf16 hi, lo, hi  (against U_all hi, U_all hi, U_all lo in the weight)
+ *     [256, 320)   sum_t a_t p_t / L         (the pooled patch; entries >= channels ksize^2 are 0)
+ *     elsewhere 0
+ * so that ONE batched azk_nn_tail_gemm (nbatch = heads, k = AZK_EMBED_FOLD_ROW, weight rows [D_t[h]; U_all; ...; M_h]) yields u, the
+ * input of the output projection.  Tables (T = rows cols + 1 tokens, row T = the null token that pads the last tile):
+ *   g_frag      f16 [2 (hi, lo)][4 column tiles][2 k-steps][64 lanes][8]: G x g_scale as two terms, MFMA B-fragment order
+ *               (element [t][q][s][l][i] = term t of G[16 q + (l & 15)][32 s + 8 (l >> 4) + i])
+ *   e_frag      f16 [2][2][64][8]: the score columns S (column h < heads; others 0) x e_scale, same order
+ *   u2_tok      f32 [T+1][64];   score_tok f32 [T+1][16]: sc_t[h], column 15 = n_t (row T: -1e30 in the head columns, column 15 = 512)
+ *   wconst_tok  f32 [T+1][16]: exp(rstdc_t sc_t[h] - ref[h]), column 15 = rstdc_t = rsqrt(n_t / 512 + eps)
+ *   l_all, score_ref f32 [16] (score_ref >= 1e30 beyond the heads)
+ * Covered: embed_dim 512, head dim 64, 4 / 8 heads, channels ksize^2 <= 64, T + 3 <= 256. */
+#define AZK_EMBED_FOLD_ROW 384
+typedef struct azk_embed_fold_consts {
+    const void *g_frag, *e_frag;
+    const float *u2_tok, *score_tok, *wconst_tok, *l_all, *score_ref;
+    const float *inv_scales;    /* device [2]: 1 / g_scale, 1 / e_scale (device data, so that new weights can be copied in under a captured graph) */
+    int32_t num_heads, ksize, embed_dim;
+    float ln_eps;
+    uint64_t *work_stats;   /* optional device uint64 [2]: += boards evaluated, += 16-token tiles evaluated */
+} azk_embed_fold_consts;
+int32_t azk_nn_embed_fold(const void *boards_dev, int32_t boards_are_f32, const azk_embed_fold_consts *consts, void *rows_out_bf16_dev,
+                          int32_t n, int32_t channels, int32_t rows, int32_t cols, const int32_t *n_valid_dev, int32_t *sched_dev,
+                          void *stream);
+int32_t azk_nn_embed_fold_leaves(const azk_leaf_source *src, const azk_embed_fold_consts *consts, void *rows_out_bf16_dev,
+                                 int32_t *sched_dev, void *stream);
 
 /* ---- fp32-accurate network path (csrc/azk_nnx.hip): the reference evaluates its network in float32 (ai/nn.py:74-84 called at
  * ai/mcts.py:46), and north_star asks for visit-count policies within 1e-5 of it.  The same two stages as above - boards -> pooled
