@@ -205,6 +205,7 @@ def main():
                     help="cls-row tail: the all-hand-written GEMM chain (azk_nn_tail_gemm: honours the live leaf count; default) or "
                          "hipBLASLt GEMMs + the hand-written LN / heads kernels (always runs the full 2048-row buffer)")
     ap.add_argument("--no-graph", action="store_true", help="eager stepping with a host sync per simulation (n_leaf-sized batches)")
+    ap.add_argument("--embed", choices=("fold", "conv"), default="fold", help="bf16 embedding + pooling: fold = k_embed_fold (patch-pooling form), conv = k_embed_pool_c")
     ap.add_argument("--split", type=int, default=1, help="independent game groups stepped on separate streams inside the step graph")
     ap.add_argument("--cache-entries", type=int, default=32768, help="per-game eval-cache entries (MCTS.cache; 64 GB of HBM at 2048 games x 32768); 0 = off")
     ap.add_argument("--cache", default="shared", choices=["shared", "per-game"],
@@ -288,7 +289,10 @@ def main():
         net.use_chain_tail = args.tail == "chain"
         kt = KernelTimer(stride=args.timer_stride)
         exact = getattr(net, "_exact", None) is not None and args.nn_path == "clsfold"      # fp32: the hand-written fp32-accurate kernels (csrc/azk_nnx.hip)
-        ep_tables = net._exact["tables"] if exact else getattr(net, "_compact", None)
+        net.use_fold_u = args.embed == "fold"
+        fold = (not exact and getattr(net, "_foldu", None) is not None and net.use_fold_u and args.tail == "chain" and getattr(net, "chain_tail", False)
+                and args.nn_path == "clsfold")         # k_embed_fold: patch-pooling form, token rows never formed
+        ep_tables = net._exact["tables"] if exact else (net._foldu if fold else getattr(net, "_compact", None))
         ep_stats = ep_tables.enable_work_stats() if ep_tables is not None else None   # device counters: boards / 16-token tiles evaluated
         if args.train_step:
             from azk import DeviceReplay
@@ -446,30 +450,37 @@ def main():
             ep_traffic = None
             try:
                 # the counters were collected on the bf16 build's kernel: no figure for k_embed_pool_x unless the file holds one
-                ep_traffic = next(v["bytes_per_launch"] for k_, v in pmc.items() if k_.startswith("k_embed_pool_x" if exact else "k_embed_pool_c"))
+                ep_traffic = next(v["bytes_per_launch"] for k_, v in pmc.items() if k_.startswith("k_embed_pool_x" if exact else ("k_embed_fold" if fold else "k_embed_pool_c")))
             except Exception:
                 pass
-            compact = exact or (getattr(net, "_compact", None) is not None and getattr(net, "use_compact", False))
+            compact = exact or fold or (getattr(net, "_compact", None) is not None and getattr(net, "use_compact", False))
             executed_share = None
             if compact and ep_stats is not None:
                 # share of the 16-token tiles the compacting kernel really evaluated IN THIS RUN (device counters of the kernel itself)
                 eb, et = (int(v) for v in ep_stats.tolist())
                 executed_share = et / max(1, eb) / ((T_tok + 15) // 16)
+                if fold:
+                    # k_embed_fold issues 24 MFMAs of 16 x 16 x 32 per evaluated tile (quadratic form 16, score columns 4, pooled patch 4)
+                    executed_share = et * 24 * 2 * 16 * 16 * 32 / max(1, eb) / per_board
             ep_peak = MFMA_BF16_PEAK_TFLOPS
             if exact:
                 # two matrix pipes rates in one kernel: conv / score columns on the fp16 pipe (weights as hi + lo: two MFMAs per product),
                 # the weighted token sum on v_mfma_f32_16x16x4_f32.  peak = the blended rate at which the algorithmic flops could issue
                 pool_fl = 2 * T_tok * cfg.num_heads * Dm
                 ep_peak = per_board / ((per_board - pool_fl) / MFMA_BF16_PEAK_TFLOPS + pool_fl / MFMA_F32_PEAK_TFLOPS)
-            kernels.append({"kernel": "k_embed_pool_x" if exact else ("k_embed_pool_c" if compact else "k_embed_pool"), "bound": "mfma", "achieved": fl / (ms * 1e-3) / 1e12,
+            kernels.append({"kernel": "k_embed_pool_x" if exact else ("k_embed_fold" if fold else ("k_embed_pool_c" if compact else "k_embed_pool")), "bound": "mfma", "achieved": fl / (ms * 1e-3) / 1e12,
                             "peak": ep_peak, "unit": "TFLOP/s", "frac": fl / (ms * 1e-3) / 1e12 / ep_peak, "avg_launch_us": ms * 1e3,
                             "algorithmic_flops_per_launch": fl, "traffic": ep_traffic,
                             "traffic_source": traffic_src if ep_traffic else None, "event_samples": len(ch.pairs),
                             "executed_share_of_algorithmic_flops": executed_share if compact else 1.0,
-                            "note": f"{per_board} flop per live board (the function's conv + score columns + weighted token sum over all {T_tok} tokens) x "
-                                    f"{live:.0f} live boards per launch; the compacting kernel evaluates only the tokens a stone can reach and takes the "
-                                    "rest as precomputed constants (executed_share_of_algorithmic_flops: MFMA work actually issued); HBM traffic is "
-                                    "~9 KB per board (board in, z out): bound by VALU/MFMA issue and LDS, not HBM"})
+                            "note": (f"{per_board} flop per live board (the function's conv + score columns + weighted token sum over all {T_tok} tokens) x "
+                                     f"{live:.0f} live boards per launch; ") +
+                                    ("k_embed_fold computes the same function from the patch bits - LayerNorm's variance as a quadratic form, scores linear, "
+                                     "the pooled row as token weights + pooled patch for the next GEMM - and only for the tokens a stone can reach: "
+                                     "executed_share_of_algorithmic_flops = MFMA flops it issues / the function's; ~6 KB out per board" if fold else
+                                     "the compacting kernel evaluates only the tokens a stone can reach and takes the "
+                                     "rest as precomputed constants (executed_share_of_algorithmic_flops: MFMA work actually issued); HBM traffic is "
+                                     "~9 KB per board (board in, z out): bound by VALU/MFMA issue and LDS, not HBM")})
         ch = kt.children.get("k_tail")                  # the cls-row tail (five k_tail_gemm launches, or the library GEMMs): MFMA-bound
         ms = ch.mean_ms() if ch else None
         if ms and args.nn_path == "clsfold" and (exact or args.tail == "chain"):
@@ -504,7 +515,7 @@ def main():
             kreal_ = cfg.channels * cfg.patch_size ** 2
             front = 2 * (cfg.tokens - 1) * cfg.embed_dim * kreal_ + 2 * 2 * cfg.tokens * cfg.embed_dim * cfg.num_heads
             # the embedding / pooling kernel always honours the live count; the compacting kernel issues only `share` of its tiles
-            share = next((k_["executed_share_of_algorithmic_flops"] for k_ in kernels if k_["kernel"].startswith("k_embed_pool")), None) or 1.0
+            share = next((k_["executed_share_of_algorithmic_flops"] for k_ in kernels if k_["kernel"].startswith(("k_embed_pool", "k_embed_fold"))), None) or 1.0
             nn_flop_alg = leaves_all * front + evals * (flops - front)
             nn_flop_issued = leaves_all * front * share + evals * (flops - front)
         out = {
@@ -516,7 +527,8 @@ def main():
             "config": {"workload": f"Gomoku {args.size}x{args.size}, {args.sims} sims/move, {args.games} concurrent self-play games per GPU "
                                    f"(BASELINE.json configs[2]), continuous self-play", "games_per_gpu": args.games,
                        "sims_per_move": args.sims, "net": f"ViT patch5 embed512 heads8 depth1 (ai/nn.py), random init seed 0, path={args.nn_path}, "
-                                                           f"{args.nn_dtype}" + (f", tail={args.tail}" if args.nn_path == "clsfold" else ""),
+                                                           f"{args.nn_dtype}" + (f", tail={args.tail}" if args.nn_path == "clsfold" else "")
+                                                           + (f", embed={args.embed}" if args.nn_dtype == "bf16" and args.nn_path == "clsfold" else ""),
                        "parallelism": f"games sharded over {world} GPU(s), no collectives on the generation path"},
             "sims_per_sec": sims_all / dt_max, "leaf_evals_per_sec": leaves_all / dt_max,
             "eval_cache": {"entries_per_game": args.cache_entries, "mode": args.cache, "hits_rank0": c.get("cache_hits", 0),

@@ -79,3 +79,38 @@ def test_exact_fold_is_the_same_function():
     # configurations the fold does not cover are refused, not approximated
     assert PolicyValueNet(NetConfig(15, 15, 2, 225, 5, 512, 8, 2), seed=0).exact_fold() is None
     assert PolicyValueNet(NetConfig(7, 7, 2, 49, 5, 32, 4, 1), seed=0).exact_fold() is None
+
+
+def test_patch_pooling_fold_is_the_same_function():
+    """pvnet.fold_u (the operands of k_embed_fold: LayerNorm1's variance as a quadratic form of the patch bits, scores linear in them,
+    the value-projected pooled row as token weights against D_t plus the pooled patch against M_h) evaluated in float64 against the
+    value-projected row of the plain pooled tokens (forward_exact_emulated's z through Wv'), boards with 0 .. 112 stones per side;
+    and carried through the rest of the tail against the reference's seed-0 logits."""
+    import torch.nn.functional as F
+    cfg = NetConfig(15, 15, 2, 225, patch_size=5, embed_dim=512, num_heads=8, depth=1)
+    net = PolicyValueNet(cfg, seed=0, path="full")
+    rng = np.random.RandomState(1)
+    xb = torch.zeros(6, 2, 15, 15)
+    for b, n in enumerate([0, 1, 5, 20, 60, 112]):
+        cells = rng.choice(225, size=2 * n, replace=False)
+        xb[b, 0].view(-1)[cells[:n]] = 1
+        xb[b, 1].view(-1)[cells[n:]] = 1
+    r = net.exact_fold("cpu")
+    _, _, z = net.forward_exact_emulated(xb, r)
+    u_ref = torch.einsum("nhd,hed->nhe", z.double(), r["Wvn"].double()).reshape(6, 512)
+    u, bw, inv_l, pw = net.forward_fold_u_emulated(xb)
+    assert (u - u_ref).abs().max().item() < 2e-7 * u_ref.abs().max().item() + 1e-7
+    # tokens no stone reaches carry no weight: the kernel leaves them out
+    cols = F.unfold(xb.double(), kernel_size=5, padding=2).transpose(1, 2)
+    clean = torch.cat([torch.ones(6, 1, dtype=torch.bool), cols.abs().sum(2) == 0], 1)               # [n, T]
+    assert bw.transpose(1, 2)[clean].abs().max().item() < 1e-15
+    # the rest of the tail on that row: the reference's own outputs for its seed-0 input
+    x = torch.from_numpy(Z["full_x"])
+    u, _, _, _ = net.forward_fold_u_emulated(x)
+    f8 = lambda t: t.double()
+    ln = lambda t: (t - t.mean(1, keepdim=True)) / torch.sqrt(t.var(1, unbiased=False, keepdim=True) + 1e-5)
+    x1 = u @ f8(r["Wo"]).t() + f8(r["bias1"])
+    x2 = x1 + F.gelu(ln(x1) @ f8(r["W0G"]).t() + f8(r["b0G"])) @ f8(r["W3"]).t() + f8(r["b3"])
+    out = ln(x2) @ f8(r["WhG"]).t() + f8(r["bhG"])
+    np.testing.assert_allclose(out[:, :225].float().numpy(), Z["full_logits"], rtol=0, atol=5e-6)
+    assert PolicyValueNet(NetConfig(15, 15, 2, 225, 5, 512, 8, 2), seed=0).fold_u() is None
