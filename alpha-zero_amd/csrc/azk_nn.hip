@@ -1728,6 +1728,7 @@ struct EmbedFoldArgs {
     const int *count;
     int *sched;
     unsigned long long *wstats;
+    long long *dbg;                // debug only (AZK_EP_STAMPS build + AZK_EMBED_POOL_STAMPS): [8] cycle sums per phase, wave 0 of every workgroup
     int n, R, Cc, T;
     float eps;
     azk_leaf_source src;
@@ -1739,9 +1740,12 @@ __device__ __forceinline__ unsigned bf16_rne(float v) {
 }
 
 constexpr int FOLD_ROW = AZK_EMBED_FOLD_ROW;
+// B fragments of the quadratic form / score columns: in registers (80 VGPRs: two workgroups per CU) or in LDS (three per CU)
+constexpr bool FOLD_FRAG_REGS = true;
+constexpr int FOLD_WG_PER_CU = FOLD_FRAG_REGS ? 2 : 3;
 
 template <int NC, int KSZ, int NH, bool SRC>
-__global__ __launch_bounds__(256, 2) void k_embed_fold(EmbedFoldArgs a) {
+__global__ __launch_bounds__(256, FOLD_WG_PER_CU) void k_embed_fold(EmbedFoldArgs a) {
     static_assert(NC * KSZ * KSZ <= 64, "the patch is one 64-bit word");
     constexpr int D = 512;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1751,7 +1755,8 @@ __global__ __launch_bounds__(256, 2) void k_embed_fold(EmbedFoldArgs a) {
     int *dlist = (int *)(pbits + Tp16);                           // [Tp16] their token indices (null token = T past the end)
     int *scan = dlist + Tp16;                                     // [4] SRC wave totals, [4] dirty counts per wave, [8] next board, [9] game, [16..31] class totals
     float *lred = (float *)(scan + 32);                           // [4 waves][8 heads]
-    float *bw = lred + 32;                                        // [Tp16][8]  a - aconst per dirty token and head
+    float *lall_s = lred + 32;                                    // [8] l_all
+    float *bw = lall_s + 8;                                       // [Tp16][8]  a - aconst per dirty token and head
     float *pwred = bw + Tp16 * 8;                                 // [4 waves][8 heads][64]
     unsigned short *orow = (unsigned short *)(pwred + 4 * 8 * 64);// [NH][FOLD_ROW] the board's output image
     uint4 *rankv = (uint4 *)(orow + 8 * FOLD_ROW);                // SRC: [256 threads] ranks of the thread's first eight games, 16 bits each
@@ -1766,14 +1771,24 @@ __global__ __launch_bounds__(256, 2) void k_embed_fold(EmbedFoldArgs a) {
         my_lo = tid * my_per;
         if (my_lo < a.src.flag_bytes) myflags = *(const unsigned long long *)(a.src.leaf_flag + my_lo);
     }
-    // the quadratic form's and the score columns' B fragments live in registers for the whole launch (80 VGPRs; 20 KB per wave, once)
-    uint4 gh[4][2], gl[4][2], eh[2], el[2];
+    // the quadratic form's and the score columns' B fragments (20 KB) go to LDS once per workgroup: in registers they cost 80 VGPRs,
+    // a wave per SIMD less - and this kernel is a chain of round trips that only more waves hide
+    uint4 *gfl = rankv + (SRC ? 256 : 0);                         // [2][4][2][64] then [2][2][64]
+    uint4 gfr[FOLD_FRAG_REGS ? 16 : 1], efr[FOLD_FRAG_REGS ? 4 : 1];
+    if (FOLD_FRAG_REGS) {
 #pragma unroll
-    for (int q = 0; q < 4; q++)
+        for (int i = 0; i < 16; i++) gfr[i] = a.gfrag[i * 64 + lane];
 #pragma unroll
-        for (int s2 = 0; s2 < 2; s2++) { gh[q][s2] = a.gfrag[((0 * 4 + q) * 2 + s2) * 64 + lane]; gl[q][s2] = a.gfrag[((1 * 4 + q) * 2 + s2) * 64 + lane]; }
+        for (int i = 0; i < 4; i++) efr[i] = a.efrag[i * 64 + lane];
+    } else {
+        uint4 fr[5];
 #pragma unroll
-    for (int s2 = 0; s2 < 2; s2++) { eh[s2] = a.efrag[(0 * 2 + s2) * 64 + lane]; el[s2] = a.efrag[(1 * 2 + s2) * 64 + lane]; }
+        for (int i = 0; i < 4; i++) fr[i] = a.gfrag[tid + 256 * i];
+        fr[4] = a.efrag[tid];
+#pragma unroll
+        for (int i = 0; i < 5; i++) gfl[tid + 256 * i] = fr[i];
+    }
+    const uint4 *gfw = gfl + lane, *efw = gfl + 1024 + lane;
     if (SRC) {
         // leaf flags -> ranks (class descending, game ascending), as k_embed_pool_c
         unsigned long long c_lo = 0ull, c_hi = 0ull;
@@ -1830,6 +1845,13 @@ __global__ __launch_bounds__(256, 2) void k_embed_fold(EmbedFoldArgs a) {
     }
     int board = blockIdx.x;
     int ws_boards = 0, ws_tiles = 0;
+#ifdef AZK_EP_STAMPS
+    const bool stamp = a.dbg != nullptr && tid == 0;
+    long long tp = stamp ? clock64() : 0, tacc[5] = {0, 0, 0, 0, 0};
+#define AZK_FSTAMP(i) do { if (stamp) { const long long tn_ = clock64(); tacc[i] += tn_ - tp; tp = tn_; } } while (0)
+#else
+#define AZK_FSTAMP(i) do { } while (0)
+#endif
     if (board < nvalid) {
     {
         unsigned r[4];
@@ -1840,9 +1862,11 @@ __global__ __launch_bounds__(256, 2) void k_embed_fold(EmbedFoldArgs a) {
     constexpr int ksz = KSZ, kk = KSZ * KSZ, pad = KSZ / 2;
     const int RC = a.R * a.Cc, T = a.T, ncell = NC * RC;
     const float sref = a.sref[l15];
+    if (tid < 8) lall_s[tid] = a.lall[tid];
     const float invD = 1.0f / (float)D, ginv = a.inv_scales[0], einv = a.inv_scales[1];
     int nxt = 0;
     __syncthreads();
+    AZK_FSTAMP(0);                                                // launch prologue: ranks, fragments staged
 
     while (board < nvalid) {
         int tv = tid;
@@ -1929,6 +1953,7 @@ __global__ __launch_bounds__(256, 2) void k_embed_fold(EmbedFoldArgs a) {
                 if ((lane - 1) >> 1 == q && lane >= 1) wbits = ((lane - 1) & 1) ? (unsigned)(m >> 32) : (unsigned)m;
             }
         }
+        AZK_FSTAMP(1);                                            // board resolved, loaded, bit string built
         // ---- patch bits of this thread's token; dirty = some stone in the patch ----
         unsigned long long plo = 0;
         {
@@ -1969,32 +1994,49 @@ __global__ __launch_bounds__(256, 2) void k_embed_fold(EmbedFoldArgs a) {
         if (tid < 16 && nd + tid < ntile * 16) { dlist[nd + tid] = T; pbits[nd + tid] = make_uint2(0u, 0u); }   // null tokens fill the last tile
         __syncthreads();
         ws_boards += 1; ws_tiles += ntile;
+        AZK_FSTAMP(2);                                            // patch bits + compaction
 
         // ---- the wave's tiles ----
         float L = 0.f;                                    // per head (lane&15 < NH): this lane group's share of sum (w - wconst)
         f32x4 Pw[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) Pw[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-        bool drew = false;
-        for (int tile = wave; tile < ntile; tile += 4) {
-            const int base = 16 * tile;
-            const int4 tk = *(const int4 *)(dlist + base + 4 * l4);
+        // the per-token constants are gathered (L2) one tile ahead: the round trip runs under the previous tile's arithmetic
+        f32x4 utn[4];
+        float scnn[4], wcnn[4];
+        auto gather = [&](int t) {
+            const int4 tk = *(const int4 *)(dlist + 16 * t + 4 * l4);
             const int tks[4] = {tk.x, tk.y, tk.z, tk.w};
-            float ut[4][4], scn[4], wcn[4];
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                const unsigned ou = ((unsigned)tks[r] * 64u + (unsigned)l15) * 4u, os = ((unsigned)tks[r] * 16u + (unsigned)l15) * 4u;
+                // (the cross term u2_t . p_t is summed over the lane group like the quadratic form, but with ITS OWN column split: lane
+                //  l15 takes columns 4 l15 .. 4 l15 + 3 - one 16-byte load per token instead of four 4-byte ones)
+                const unsigned ou = ((unsigned)tks[r] * 64u + 4u * (unsigned)l15) * 4u, os = ((unsigned)tks[r] * 16u + (unsigned)l15) * 4u;
+                utn[r] = *(const f32x4 *)((const char *)a.u2T + ou);
+                scnn[r] = *(const float *)((const char *)a.scoreT + os);
+                wcnn[r] = *(const float *)((const char *)a.wcT + os);
+            }
+        };
+        if (wave < ntile) gather(wave);
+        for (int tile = wave; tile < ntile; tile += 4) {
+            const int base = 16 * tile;
+            // patch bits of this lane group's four tokens (rows 4 l4 + r)
+            const int4 pq0 = *(const int4 *)(pbits + base + 4 * l4), pq1 = *(const int4 *)(pbits + base + 4 * l4 + 2);
+            const unsigned prx[4] = {(unsigned)pq0.x, (unsigned)pq0.z, (unsigned)pq1.x, (unsigned)pq1.z};
+            const unsigned pry[4] = {(unsigned)pq0.y, (unsigned)pq0.w, (unsigned)pq1.y, (unsigned)pq1.w};
+            // the gathered rows are consumed at once (their registers take the next tile's): this lane's share of u2_t . p_t
+            float cross[4], scn[4], wcn[4];
 #pragma unroll
-                for (int q = 0; q < 4; q++) ut[r][q] = *(const float *)((const char *)a.u2T + ou + 64u * q);
-                scn[r] = *(const float *)((const char *)a.scoreT + os);
-                wcn[r] = *(const float *)((const char *)a.wcT + os);
+            for (int r = 0; r < 4; r++) {
+                const unsigned nib = ((l15 < 8 ? prx[r] : pry[r]) >> (4 * (l15 & 7))) & 0xfu;           // patch bits 4 l15 .. 4 l15 + 3
+                float c = 0.f;
+#pragma unroll
+                for (int cidx = 0; cidx < 4; cidx++) c += (nib >> cidx) & 1u ? utn[r][cidx] : 0.f;
+                cross[r] = c; scn[r] = scnn[r]; wcn[r] = wcnn[r];
             }
-            if (tid == 0 && !drew) {                      // next board: the round trip hides under this tile
-                __builtin_amdgcn_sched_barrier(0);
-                nxt = atomicAdd(a.sched, 1);
-                __builtin_amdgcn_sched_barrier(0);
-                drew = true;
-            }
+            __builtin_amdgcn_sched_barrier(0);
+            gather(tile + 4 < ntile ? tile + 4 : tile);          // (the last tile refetches itself: no branch around loads)
+            __builtin_amdgcn_sched_barrier(0);
             const uint2 pa = pbits[base + l15];
             union { uint4 u; f16x8 v; } af[2];
             af[0].u = alut[(pa.x >> (8 * l4)) & 0xffu];
@@ -2004,19 +2046,16 @@ __global__ __launch_bounds__(256, 2) void k_embed_fold(EmbedFoldArgs a) {
             for (int q = 0; q < 4; q++) Y[q] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s2 = 0; s2 < 2; s2++) {
-                { union { uint4 u; f16x8 v; } b; b.u = eh[s2]; E = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[s2].v, b.v, E, 0, 0, 0);
-                  b.u = el[s2]; E = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[s2].v, b.v, E, 0, 0, 0); }
+                { union { uint4 u; f16x8 v; } b; b.u = FOLD_FRAG_REGS ? efr[0 * 2 + s2] : efw[(0 * 2 + s2) * 64]; E = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[s2].v, b.v, E, 0, 0, 0);
+                  b.u = FOLD_FRAG_REGS ? efr[1 * 2 + s2] : efw[(1 * 2 + s2) * 64]; E = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[s2].v, b.v, E, 0, 0, 0); }
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     union { uint4 u; f16x8 v; } b;
-                    b.u = gh[q][s2]; Y[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[s2].v, b.v, Y[q], 0, 0, 0);
-                    b.u = gl[q][s2]; Y[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[s2].v, b.v, Y[q], 0, 0, 0);
+                    b.u = FOLD_FRAG_REGS ? gfr[(0 * 4 + q) * 2 + s2] : gfw[((0 * 4 + q) * 2 + s2) * 64]; Y[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[s2].v, b.v, Y[q], 0, 0, 0);
+                    b.u = FOLD_FRAG_REGS ? gfr[(1 * 4 + q) * 2 + s2] : gfw[((1 * 4 + q) * 2 + s2) * 64]; Y[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[s2].v, b.v, Y[q], 0, 0, 0);
                 }
             }
             // ---- per token (row 4 l4 + r): variance from the quadratic form, scores, weights ----
-            const int4 pq0 = *(const int4 *)(pbits + base + 4 * l4), pq1 = *(const int4 *)(pbits + base + 4 * l4 + 2);
-            const unsigned prx[4] = {(unsigned)pq0.x, (unsigned)pq0.z, (unsigned)pq1.x, (unsigned)pq1.z};
-            const unsigned pry[4] = {(unsigned)pq0.y, (unsigned)pq0.w, (unsigned)pq1.y, (unsigned)pq1.w};
             float av[4];
             unsigned bsel[4][4];                           // patch bit of token r at column 16 q + l15 (0 / 1)
 #pragma unroll
@@ -2026,8 +2065,9 @@ __global__ __launch_bounds__(256, 2) void k_embed_fold(EmbedFoldArgs a) {
                 for (int q = 0; q < 4; q++) {
                     const unsigned bit = ((q < 2 ? prx[r] : pry[r]) >> (16 * (q & 1) + l15)) & 1u;
                     bsel[r][q] = bit;
-                    qd += bit ? fmaf(Y[q][r], ginv, ut[r][q]) : 0.f;
+                    qd += bit ? Y[q][r] : 0.f;
                 }
+                qd = fmaf(qd, ginv, cross[r]);
                 qd = row16_sum(qd);
                 const float e = fmaf(E[r], einv, scn[r]);                        // head lanes: the raw score; lane 15: n_t
                 const float nt = __shfl(e, (lane & 48) | 15);
@@ -2056,7 +2096,10 @@ __global__ __launch_bounds__(256, 2) void k_embed_fold(EmbedFoldArgs a) {
                 Pw[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa.v, pb.v, Pw[q], 0, 0, 0);
             }
         }
-        if (tid == 0 && !drew) nxt = atomicAdd(a.sched, 1);
+        // next board: one ticket per board, drawn by the wave with the fewest tiles behind its last one (a returning atomic is waited
+        // for where it is issued: in wave 0 it sat on the board's critical path)
+        if (tid == 192) scan[10] = atomicAdd(a.sched, 1);
+        AZK_FSTAMP(3);                                            // wave 0's tiles
         // ---- the waves' sums meet ----
         {
             float Lw = L + __shfl_xor(L, 16);
@@ -2074,7 +2117,7 @@ __global__ __launch_bounds__(256, 2) void k_embed_fold(EmbedFoldArgs a) {
         {
             float inv[NH];
 #pragma unroll
-            for (int h = 0; h < NH; h++) inv[h] = 1.0f / (a.lall[h] + ((lred[h] + lred[8 + h]) + (lred[16 + h] + lred[24 + h])));
+            for (int h = 0; h < NH; h++) inv[h] = 1.0f / (lall_s[h] + ((lred[h] + lred[8 + h]) + (lred[16 + h] + lred[24 + h])));
             const bool isL = tid >= T && tid < T + 3;
 #pragma unroll
             for (int h = 0; h < NH; h++) {
@@ -2104,26 +2147,37 @@ __global__ __launch_bounds__(256, 2) void k_embed_fold(EmbedFoldArgs a) {
             for (int i = tid; i < NH * FOLD_ROW / 8; i += 256) dst4[i] = src4[i];
         }
         if (tid == 0) {
+            nxt = scan[10];
             if (nxt == nvalid - 1) a.sched[0] = 0;
             scan[8] = (int)gridDim.x + nxt;
         }
         __syncthreads();
         board = scan[8];
+        AZK_FSTAMP(4);                                            // sums, output image, store, next board known
     }
     }
     if (a.wstats != nullptr && tid == 0 && ws_boards) { atomicAdd(a.wstats, (unsigned long long)ws_boards); atomicAdd(a.wstats + 1, (unsigned long long)ws_tiles); }
+#undef AZK_FSTAMP
+#ifdef AZK_EP_STAMPS
+    if (stamp) {
+        atomicMax((unsigned long long *)a.dbg + 5, (unsigned long long)(tacc[0] + tacc[1] + tacc[2] + tacc[3] + tacc[4]));   // the busiest workgroup of any launch
+        for (int i = 0; i < 5; i++) atomicAdd((unsigned long long *)a.dbg + i, (unsigned long long)tacc[i]);
+        atomicAdd((unsigned long long *)a.dbg + 6, (unsigned long long)ws_tiles);
+        atomicAdd((unsigned long long *)a.dbg + 7, (unsigned long long)ws_boards);
+    }
+#endif
 }
 
 template <int NC, int KSZ, int NH, bool SRC>
 int launch_embed_fold(const EmbedFoldArgs &a, hipStream_t st) {
     const int tp16 = ((a.T + 15) / 16) * 16;
-    const int lds = 256 * 16 + tp16 * 8 + tp16 * 4 + 128 + 128 + tp16 * 32 + 4 * 8 * 64 * 4 + 8 * FOLD_ROW * 2 + (SRC ? 256 * 16 : 0);
+    const int lds = 256 * 16 + tp16 * 8 + tp16 * 4 + 128 + 128 + 32 + tp16 * 32 + 4 * 8 * 64 * 4 + 8 * FOLD_ROW * 2 + (SRC ? 256 * 16 : 0) + (FOLD_FRAG_REGS ? 0 : 20 * 64 * 16);   // 53.8 KB with the fragments: three workgroups per CU
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void *)k_embed_fold<NC, KSZ, NH, SRC>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return AZK_ERR_HIP;
         attr_set = true;
     }
-    const int blocks = a.n < 512 ? a.n : 512;
+    const int blocks = a.n < 256 * FOLD_WG_PER_CU ? a.n : 256 * FOLD_WG_PER_CU;    // every workgroup resident; each pulls boards until the queue is dry
     k_embed_fold<NC, KSZ, NH, SRC><<<blocks, 256, lds, st>>>(a);
     return hipGetLastError() == hipSuccess ? AZK_OK : AZK_ERR_HIP;
 }
@@ -2147,6 +2201,22 @@ static int32_t embed_fold_impl(const void *boards_dev, int32_t boards_are_f32, c
     a.out = (unsigned short *)rows_out; a.count = n_valid_dev; a.sched = sched_dev; a.wstats = (unsigned long long *)k->work_stats;
     a.n = n; a.R = rows; a.Cc = cols; a.T = rows * cols + 1; a.eps = k->ln_eps;
     if (src) a.src = *src;
+    {
+        static long long *dbg_buf = nullptr;
+        const char *ds = getenv("AZK_EMBED_POOL_STAMPS");
+        if (ds && atoi(ds)) {
+            if (!dbg_buf && (hipMalloc((void **)&dbg_buf, 64) != hipSuccess || hipMemset(dbg_buf, 0, 64) != hipSuccess)) return AZK_ERR_HIP;
+            a.dbg = dbg_buf;
+            if (atoi(ds) == 2) {          // print-and-reset request
+                long long h[8];
+                if (hipMemcpy(h, dbg_buf, 64, hipMemcpyDeviceToHost) != hipSuccess) return AZK_ERR_HIP;
+                const double nb = (double)(h[7] ? h[7] : 1);
+                fprintf(stderr, "[embed_fold stamps] busiest workgroup %lld cycles | boards %lld tiles %lld | launch prologue (total) %lld | cycles per board: "
+                        "load %.0f, patch+compact %.0f, wave 0 tiles %.0f, sums+output %.0f\n", h[5], h[7], h[6], h[0], h[1] / nb, h[2] / nb, h[3] / nb, h[4] / nb);
+                if (hipMemset(dbg_buf, 0, 64) != hipSuccess) return AZK_ERR_HIP;
+            }
+        }
+    }
     hipStream_t st = (hipStream_t)stream;
     const int nh = k->num_heads;
 #define CASE(NC_, KSZ_, NH_) if (channels == NC_ && ksize == KSZ_ && nh == NH_) \

@@ -685,3 +685,9 @@ class KernelTimer:
         if not self.pairs:
             return None
         return sum(a.elapsed_time(b) for a, b in self.pairs) / len(self.pairs)
+
+    def spread_us(self):
+        """(median, max) of the samples in microseconds: a mean that sits far above the median is a few stalled samples, not the kernel."""
+        self.torch.cuda.synchronize()
+        t = sorted(a.elapsed_time(b) * 1e3 for a, b in self.pairs)
+        return (t[len(t) // 2], t[-1]) if t else (None, None)

@@ -470,6 +470,7 @@ def main():
                 ep_peak = per_board / ((per_board - pool_fl) / MFMA_BF16_PEAK_TFLOPS + pool_fl / MFMA_F32_PEAK_TFLOPS)
             kernels.append({"kernel": "k_embed_pool_x" if exact else ("k_embed_fold" if fold else ("k_embed_pool_c" if compact else "k_embed_pool")), "bound": "mfma", "achieved": fl / (ms * 1e-3) / 1e12,
                             "peak": ep_peak, "unit": "TFLOP/s", "frac": fl / (ms * 1e-3) / 1e12 / ep_peak, "avg_launch_us": ms * 1e3,
+                            "median_launch_us": ch.spread_us()[0], "max_launch_us": ch.spread_us()[1],
                             "algorithmic_flops_per_launch": fl, "traffic": ep_traffic,
                             "traffic_source": traffic_src if ep_traffic else None, "event_samples": len(ch.pairs),
                             "executed_share_of_algorithmic_flops": executed_share if compact else 1.0,
