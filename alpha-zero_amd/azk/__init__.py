@@ -820,6 +820,7 @@ def nn_embed_pool_compact_leaves(src, tables, sched, timers=None):
 
 
 EMBED_FOLD_ROW = 384        # include/azk.h AZK_EMBED_FOLD_ROW
+EMBED_FOLD_MAX_SLOTS = 8192 # include/azk.h AZK_EMBED_FOLD_MAX_SLOTS: pending-leaf slots azk_nn_embed_fold_leaves ranks in LDS
 
 
 class EmbedFoldTables:

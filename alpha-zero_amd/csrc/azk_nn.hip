@@ -1740,12 +1740,10 @@ __device__ __forceinline__ unsigned bf16_rne(float v) {
 }
 
 constexpr int FOLD_ROW = AZK_EMBED_FOLD_ROW;
-// B fragments of the quadratic form / score columns: in registers (80 VGPRs: two workgroups per CU) or in LDS (three per CU)
-constexpr bool FOLD_FRAG_REGS = true;
-constexpr int FOLD_WG_PER_CU = FOLD_FRAG_REGS ? 2 : 3;
+constexpr int FOLD_MAX_SLOTS = AZK_EMBED_FOLD_MAX_SLOTS;
 
 template <int NC, int KSZ, int NH, bool SRC>
-__global__ __launch_bounds__(256, FOLD_WG_PER_CU) void k_embed_fold(EmbedFoldArgs a) {
+__global__ __launch_bounds__(256, 2) void k_embed_fold(EmbedFoldArgs a) {
     static_assert(NC * KSZ * KSZ <= 64, "the patch is one 64-bit word");
     constexpr int D = 512;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1753,48 +1751,35 @@ __global__ __launch_bounds__(256, FOLD_WG_PER_CU) void k_embed_fold(EmbedFoldArg
     const int Tp16 = ((a.T + 15) >> 4) << 4;
     uint2 *pbits = (uint2 *)(alut + 256);                         // [Tp16] patch bits of the compacted dirty tokens
     int *dlist = (int *)(pbits + Tp16);                           // [Tp16] their token indices (null token = T past the end)
-    int *scan = dlist + Tp16;                                     // [4] SRC wave totals, [4] dirty counts per wave, [8] next board, [9] game, [16..31] class totals
+    int *scan = dlist + Tp16;                                     // [4 dirty counts per wave at 4..7], [10] next ticket, [16..31] class totals of the rank scan
     float *lred = (float *)(scan + 32);                           // [4 waves][8 heads]
     float *lall_s = lred + 32;                                    // [8] l_all
     float *bw = lall_s + 8;                                       // [Tp16][8]  a - aconst per dirty token and head
     float *pwred = bw + Tp16 * 8;                                 // [4 waves][8 heads][64]
-    unsigned short *orow = (unsigned short *)(pwred + 4 * 8 * 64);// [NH][FOLD_ROW] the board's output image
-    uint4 *rankv = (uint4 *)(orow + 8 * FOLD_ROW);                // SRC: [256 threads] ranks of the thread's first eight games, 16 bits each
+    unsigned short *gor = (unsigned short *)(pwred + 4 * 8 * 64); // SRC: [n_games] game of rank r (= of the launch's r-th board)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
-    int nvalid, my_lo = 0, my_per = 0;
-    unsigned long long cb_lo = 0ull, cb_hi = 0ull;
-    unsigned long long myflags = 0ull;
+    int nvalid;
+    // the quadratic form's and the score columns' B fragments live in registers for the whole launch (80 VGPRs, 20 KB per wave once).
+    // Measured against keeping them in LDS (154 VGPRs: three workgroups per CU, or two tiles per wave at a time): 86.5 vs 92.4 / 90.1 ms
+    // per move - every MFMA then waits for its ds_read.
+    uint4 gfr[16], efr[4];
+#pragma unroll
+    for (int i = 0; i < 16; i++) gfr[i] = a.gfrag[i * 64 + lane];
+#pragma unroll
+    for (int i = 0; i < 4; i++) efr[i] = a.efrag[i * 64 + lane];
     if (SRC) {
-        my_per = ((((a.src.n_games + 255) >> 8) + 7) >> 3) << 3;
-        my_lo = tid * my_per;
-        if (my_lo < a.src.flag_bytes) myflags = *(const unsigned long long *)(a.src.leaf_flag + my_lo);
-    }
-    // the quadratic form's and the score columns' B fragments (20 KB) go to LDS once per workgroup: in registers they cost 80 VGPRs,
-    // a wave per SIMD less - and this kernel is a chain of round trips that only more waves hide
-    uint4 *gfl = rankv + (SRC ? 256 : 0);                         // [2][4][2][64] then [2][2][64]
-    uint4 gfr[FOLD_FRAG_REGS ? 16 : 1], efr[FOLD_FRAG_REGS ? 4 : 1];
-    if (FOLD_FRAG_REGS) {
-#pragma unroll
-        for (int i = 0; i < 16; i++) gfr[i] = a.gfrag[i * 64 + lane];
-#pragma unroll
-        for (int i = 0; i < 4; i++) efr[i] = a.efrag[i * 64 + lane];
-    } else {
-        uint4 fr[5];
-#pragma unroll
-        for (int i = 0; i < 4; i++) fr[i] = a.gfrag[tid + 256 * i];
-        fr[4] = a.efrag[tid];
-#pragma unroll
-        for (int i = 0; i < 5; i++) gfl[tid + 256 * i] = fr[i];
-    }
-    const uint4 *gfw = gfl + lane, *efw = gfl + 1024 + lane;
-    if (SRC) {
-        // leaf flags -> ranks (class descending, game ascending), as k_embed_pool_c
-        unsigned long long c_lo = 0ull, c_hi = 0ull;
+        // A non-zero leaf flag is 1 + the leaf's cost class (0..7, by stone count).  Board r of the launch is the r-th flagged game in
+        // the order (class descending, game ascending): the stone-heavy boards are handed out first, the light ones fill the gaps at
+        // the end.  Every workgroup derives the same ranks - per-class counts of its threads' games (thread t owns games [t per, (t+1)
+        // per)), an exclusive scan over the 256 threads with the eight 16-bit counters packed in two 64-bit words - and keeps the
+        // inverse (game of rank r) in LDS: a board's game is then one LDS read, whoever asks.
+        const int my_per = ((((a.src.n_games + 255) >> 8) + 7) >> 3) << 3, my_lo = tid * my_per;
+        unsigned long long c_lo = 0ull, c_hi = 0ull;              // classes 0-3 / 4-7, 16 bits each
         for (int w = 0; w < my_per; w += 8)
             if (my_lo + w < a.src.flag_bytes) {
-                const unsigned long long f = w == 0 ? myflags : *(const unsigned long long *)(a.src.leaf_flag + my_lo + w);
+                const unsigned long long f = *(const unsigned long long *)(a.src.leaf_flag + my_lo + w);
 #pragma unroll
                 for (int q = 0; q < 8; q++) {
                     const unsigned c = (unsigned)((f >> (8 * q)) & 0xffull);
@@ -1815,30 +1800,27 @@ __global__ __launch_bounds__(256, FOLD_WG_PER_CU) void k_embed_fold(EmbedFoldArg
             if (w < wave) { b_lo += wtot[2 * w]; b_hi += wtot[2 * w + 1]; }
             t_lo += wtot[2 * w]; t_hi += wtot[2 * w + 1];
         }
-        const unsigned long long e_lo = b_lo + i_lo - c_lo, e_hi = b_hi + i_hi - c_hi;
+        const unsigned long long e_lo = b_lo + i_lo - c_lo, e_hi = b_hi + i_hi - c_hi;   // exclusive prefix over lower threads, per class
+        unsigned cbase[8];                                        // rank of this thread's first game of each class
         unsigned start = 0;
 #pragma unroll
-        for (int c = 7; c >= 0; c--) {
-            const unsigned tot = (unsigned)(((c < 4 ? t_lo : t_hi) >> (16 * (c & 3))) & 0xffffull);
-            const unsigned long long cb = (unsigned long long)(start + (unsigned)(((c < 4 ? e_lo : e_hi) >> (16 * (c & 3))) & 0xffffull)) << (16 * (c & 3));
-            if (c < 4) cb_lo |= cb; else cb_hi |= cb;
-            start += tot;
+        for (int c = 7; c >= 0; c--) {                            // class 7 (most stones) first
+            cbase[c] = start + (unsigned)(((c < 4 ? e_lo : e_hi) >> (16 * (c & 3))) & 0xffffull);
+            start += (unsigned)(((c < 4 ? t_lo : t_hi) >> (16 * (c & 3))) & 0xffffull);
         }
         nvalid = (int)start;
-        unsigned run = 0;
-        unsigned myrank[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+        for (int w = 0; w < my_per; w += 8)
+            if (my_lo + w < a.src.flag_bytes) {
+                const unsigned long long f = *(const unsigned long long *)(a.src.leaf_flag + my_lo + w);
 #pragma unroll
-        for (int q = 0; q < 8; q++) {
-            const unsigned c = (unsigned)((myflags >> (8 * q)) & 0xffull);
-            unsigned r = 0xffffu;
-            if (c) {
-                const unsigned bsel = (unsigned)(((c <= 4 ? cb_lo : cb_hi) >> (16 * ((c - 1) & 3))) & 0xffffull);
-                r = bsel + ((run >> (4 * (c - 1))) & 0xfu);
-                run += 1u << (4 * (c - 1));
+                for (int q = 0; q < 8; q++) {
+                    const unsigned c = (unsigned)((f >> (8 * q)) & 0xffull);
+                    if (c) {
+#pragma unroll
+                        for (int cc = 0; cc < 8; cc++) if (c == (unsigned)cc + 1u) { gor[cbase[cc]] = (unsigned short)(my_lo + w + q); cbase[cc] += 1u; }
+                    }
+                }
             }
-            myrank[q >> 1] = (q & 1) ? ((myrank[q >> 1] & 0x0000ffffu) | (r << 16)) : ((myrank[q >> 1] & 0xffff0000u) | r);
-        }
-        rankv[tid] = make_uint4(myrank[0], myrank[1], myrank[2], myrank[3]);
         if (blockIdx.x == 0 && tid == 0) { *a.src.n_leaf = nvalid; if (a.src.cache_stamp) *a.src.cache_stamp += 1u; }
     } else {
         nvalid = a.count ? min(a.n, *a.count) : a.n;
@@ -1864,11 +1846,31 @@ __global__ __launch_bounds__(256, FOLD_WG_PER_CU) void k_embed_fold(EmbedFoldArg
     const float sref = a.sref[l15];
     if (tid < 8) lall_s[tid] = a.lall[tid];
     const float invD = 1.0f / (float)D, ginv = a.inv_scales[0], einv = a.inv_scales[1];
-    int nxt = 0;
     __syncthreads();
     AZK_FSTAMP(0);                                                // launch prologue: ranks, fragments staged
 
+    // Boards of up to 512 plane cells: every load of a board is issued at once (one round trip), and the NEXT board's loads are issued
+    // as soon as its ticket is known - behind the tiles' barrier, under the output phase - so a board starts with its cells on hand.
+    constexpr int NQ = 8;
+    const bool fast = ncell <= 64 * NQ;
+    int codeN[NQ], tmN = 0, ldN = 0, game = 0;
+    auto load_cells = [&](int g) {                                // SRC: cell codes (one byte per cell) + the two words that give the side to move
+        const auto *cells = a.src.leaf_cells + (size_t)g * a.src.rc_pad;           // uniform base + 32-bit lane offsets
+        int lv = tid;                                             // (opaque: the eight offsets are recomputed per call, not kept across the board loop)
+        asm volatile("" : "+v"(lv));
+        lv &= 63;
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            const int e = min(q * 64 + lv, ncell - 1);
+            codeN[q] = cells[(unsigned)(e - ((e >= RC) + (e >= 2 * RC)) * RC)];
+        }
+        tmN = a.src.to_move[g]; ldN = a.src.leaf_depth[g];
+    };
+    if (SRC) { game = gor[board]; if (fast) load_cells(game); }
+
     while (board < nvalid) {
+        // Everything below that depends only on the thread index is recomputed per board from an opaque copy of the index: hoisted out of
+        // the board loop these values live through the tile loop and spill.
         int tv = tid;
         asm volatile("" : "+v"(tv));
         const int lane_b = tv & 63;
@@ -1877,44 +1879,19 @@ __global__ __launch_bounds__(256, FOLD_WG_PER_CU) void k_embed_fold(EmbedFoldArg
         unsigned colmask = 0;
 #pragma unroll
         for (int kx = 0; kx < ksz; kx++) { const int cc = tc + kx - pad; if (cc >= 0 && cc < a.Cc) colmask |= 1u << kx; }
-        int game = 0, player = 0;
-        if (SRC) {
-            int g = -1;
-            const uint4 rk = rankv[tid];
-            const unsigned myrank[4] = {rk.x, rk.y, rk.z, rk.w};
-#pragma unroll
-            for (int q = 0; q < 8; q++) if (((myrank[q >> 1] >> (16 * (q & 1))) & 0xffffu) == (unsigned)board) g = my_lo + q;
-            if (my_per > 8) {
-                unsigned long long run2 = 0ull;
-                for (int w = 0; w < my_per; w++) {
-                    const unsigned c = my_lo + w < a.src.flag_bytes ? (unsigned)a.src.leaf_flag[my_lo + w] : 0u;
-                    if (!c) continue;
-                    const unsigned r = (unsigned)(((c <= 4 ? cb_lo : cb_hi) >> (16 * ((c - 1) & 3))) & 0xffffull) + (unsigned)((run2 >> (8 * (c - 1))) & 0xffull);
-                    run2 += 1ull << (8 * (c - 1));
-                    if (w >= 8 && r == (unsigned)board) g = my_lo + w;
-                }
-            }
-            if (g >= 0) { scan[9] = g; a.src.leaf_slot[g] = board; }
-            __syncthreads();
-            game = scan[9];
-        }
+        int player = 0;
+        if (SRC && tid == 0) a.src.leaf_slot[game] = board;       // the slot the next expansion reads this game's outputs from
         unsigned wbits = 0;                             // lane i holds bits [32 (i-1), 32 i) of the board bit string (lane 0: zeros)
-        constexpr int NQ = 8;
-        if (ncell <= 64 * NQ) {
+        if (fast) {
             bool on[NQ];
             if (SRC) {
-                int code[NQ], chq[NQ];
-                const auto *cells = a.src.leaf_cells + (size_t)game * a.src.rc_pad;
+                // canonical planes from the cell codes (gomoku.py:34-40; 3-plane: mcts.py:126-137)
+                player = (tmN + ldN) & 1;                         // node.currentPlayer at the leaf
 #pragma unroll
                 for (int q = 0; q < NQ; q++) {
-                    const int e = min(q * 64 + lane_b, ncell - 1);
-                    chq[q] = (e >= RC) + (e >= 2 * RC);
-                    code[q] = cells[(unsigned)(e - chq[q] * RC)];
+                    const int e = min(q * 64 + lane_b, ncell - 1), chq = (e >= RC) + (e >= 2 * RC);
+                    on[q] = q * 64 + lane_b < ncell && (chq == 2 ? player != 0 : ((codeN[q] >> (chq ^ player)) & 1) != 0);
                 }
-                player = (a.src.to_move[game] + a.src.leaf_depth[game]) & 1;
-#pragma unroll
-                for (int q = 0; q < NQ; q++)
-                    on[q] = q * 64 + lane_b < ncell && (chq[q] == 2 ? player != 0 : ((code[q] >> (chq[q] ^ player)) & 1) != 0);
             } else if (a.boards_f32) {
                 float raw[NQ];
                 const float *bp32 = (const float *)a.boards + (size_t)board * ncell;
@@ -1953,7 +1930,7 @@ __global__ __launch_bounds__(256, FOLD_WG_PER_CU) void k_embed_fold(EmbedFoldArg
                 if ((lane - 1) >> 1 == q && lane >= 1) wbits = ((lane - 1) & 1) ? (unsigned)(m >> 32) : (unsigned)m;
             }
         }
-        AZK_FSTAMP(1);                                            // board resolved, loaded, bit string built
+        AZK_FSTAMP(1);                                            // board loaded, bit string built
         // ---- patch bits of this thread's token; dirty = some stone in the patch ----
         unsigned long long plo = 0;
         {
@@ -1982,7 +1959,7 @@ __global__ __launch_bounds__(256, FOLD_WG_PER_CU) void k_embed_fold(EmbedFoldArg
         const bool dirty = plo != 0ull;
         const unsigned long long dm = __ballot(dirty);
         if (lane == 0) scan[4 + wave] = __popcll(dm);
-        __syncthreads();                                  // (also: every wave is done with the previous board's lists and output image)
+        __syncthreads();                                  // (also: every wave is done with the previous board's lists and sums)
         int dpos = __popcll(dm & ((1ull << lane) - 1ull));
         for (int w = 0; w < wave; w++) dpos += scan[4 + w];
         const int nd = scan[4] + scan[5] + scan[6] + scan[7];
@@ -1996,14 +1973,14 @@ __global__ __launch_bounds__(256, FOLD_WG_PER_CU) void k_embed_fold(EmbedFoldArg
         ws_boards += 1; ws_tiles += ntile;
         AZK_FSTAMP(2);                                            // patch bits + compaction
 
-        // ---- the wave's tiles ----
+        // ---- the wave's tiles: wave, wave + 4, ... ----
         float L = 0.f;                                    // per head (lane&15 < NH): this lane group's share of sum (w - wconst)
         f32x4 Pw[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) Pw[q] = f32x4{0.f, 0.f, 0.f, 0.f};
         // the per-token constants are gathered (L2) one tile ahead: the round trip runs under the previous tile's arithmetic
         f32x4 utn[4];
-        float scnn[4], wcnn[4];
+        float scnn[4], wcnn[4], ntn[4], rcn[4];
         auto gather = [&](int t) {
             const int4 tk = *(const int4 *)(dlist + 16 * t + 4 * l4);
             const int tks[4] = {tk.x, tk.y, tk.z, tk.w};
@@ -2015,6 +1992,10 @@ __global__ __launch_bounds__(256, FOLD_WG_PER_CU) void k_embed_fold(EmbedFoldArg
                 utn[r] = *(const f32x4 *)((const char *)a.u2T + ou);
                 scnn[r] = *(const float *)((const char *)a.scoreT + os);
                 wcnn[r] = *(const float *)((const char *)a.wcT + os);
+                // the token's n_t and constant rstd sit in column 15 of the same rows: loaded by every lane of the group (one line, a
+                // tile ahead) instead of being broadcast from lane 15 through two ds_bpermute round trips on the tile's critical path
+                ntn[r] = *(const float *)((const char *)a.scoreT + (unsigned)tks[r] * 64u + 60u);
+                rcn[r] = *(const float *)((const char *)a.wcT + (unsigned)tks[r] * 64u + 60u);
             }
         };
         if (wave < ntile) gather(wave);
@@ -2025,14 +2006,14 @@ __global__ __launch_bounds__(256, FOLD_WG_PER_CU) void k_embed_fold(EmbedFoldArg
             const unsigned prx[4] = {(unsigned)pq0.x, (unsigned)pq0.z, (unsigned)pq1.x, (unsigned)pq1.z};
             const unsigned pry[4] = {(unsigned)pq0.y, (unsigned)pq0.w, (unsigned)pq1.y, (unsigned)pq1.w};
             // the gathered rows are consumed at once (their registers take the next tile's): this lane's share of u2_t . p_t
-            float cross[4], scn[4], wcn[4];
+            float cross[4], scn[4], wcn[4], ntv[4], rcv[4];
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const unsigned nib = ((l15 < 8 ? prx[r] : pry[r]) >> (4 * (l15 & 7))) & 0xfu;           // patch bits 4 l15 .. 4 l15 + 3
                 float c = 0.f;
 #pragma unroll
                 for (int cidx = 0; cidx < 4; cidx++) c += (nib >> cidx) & 1u ? utn[r][cidx] : 0.f;
-                cross[r] = c; scn[r] = scnn[r]; wcn[r] = wcnn[r];
+                cross[r] = c; scn[r] = scnn[r]; wcn[r] = wcnn[r]; ntv[r] = ntn[r]; rcv[r] = rcn[r];
             }
             __builtin_amdgcn_sched_barrier(0);
             gather(tile + 4 < ntile ? tile + 4 : tile);          // (the last tile refetches itself: no branch around loads)
@@ -2046,37 +2027,36 @@ __global__ __launch_bounds__(256, FOLD_WG_PER_CU) void k_embed_fold(EmbedFoldArg
             for (int q = 0; q < 4; q++) Y[q] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s2 = 0; s2 < 2; s2++) {
-                { union { uint4 u; f16x8 v; } b; b.u = FOLD_FRAG_REGS ? efr[0 * 2 + s2] : efw[(0 * 2 + s2) * 64]; E = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[s2].v, b.v, E, 0, 0, 0);
-                  b.u = FOLD_FRAG_REGS ? efr[1 * 2 + s2] : efw[(1 * 2 + s2) * 64]; E = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[s2].v, b.v, E, 0, 0, 0); }
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
+                for (int hl = 0; hl < 2; hl++) {
                     union { uint4 u; f16x8 v; } b;
-                    b.u = FOLD_FRAG_REGS ? gfr[(0 * 4 + q) * 2 + s2] : gfw[((0 * 4 + q) * 2 + s2) * 64]; Y[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[s2].v, b.v, Y[q], 0, 0, 0);
-                    b.u = FOLD_FRAG_REGS ? gfr[(1 * 4 + q) * 2 + s2] : gfw[((1 * 4 + q) * 2 + s2) * 64]; Y[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[s2].v, b.v, Y[q], 0, 0, 0);
+                    b.u = efr[hl * 2 + s2];
+                    E = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[s2].v, b.v, E, 0, 0, 0);
                 }
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+#pragma unroll
+                    for (int hl = 0; hl < 2; hl++) {
+                        union { uint4 u; f16x8 v; } b;
+                        b.u = gfr[(hl * 4 + q) * 2 + s2];
+                        Y[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[s2].v, b.v, Y[q], 0, 0, 0);
+                    }
             }
             // ---- per token (row 4 l4 + r): variance from the quadratic form, scores, weights ----
             float av[4];
-            unsigned bsel[4][4];                           // patch bit of token r at column 16 q + l15 (0 / 1)
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 float qd = 0.f;
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const unsigned bit = ((q < 2 ? prx[r] : pry[r]) >> (16 * (q & 1) + l15)) & 1u;
-                    bsel[r][q] = bit;
-                    qd += bit ? Y[q][r] : 0.f;
-                }
+                for (int q = 0; q < 4; q++) qd += ((q < 2 ? prx[r] : pry[r]) >> (16 * (q & 1) + l15)) & 1u ? Y[q][r] : 0.f;
                 qd = fmaf(qd, ginv, cross[r]);
                 qd = row16_sum(qd);
-                const float e = fmaf(E[r], einv, scn[r]);                        // head lanes: the raw score; lane 15: n_t
-                const float nt = __shfl(e, (lane & 48) | 15);
-                const float rstd = __builtin_amdgcn_rsqf(fmaxf((qd + nt) * invD, 0.f) + a.eps);
+                const float e = fmaf(E[r], einv, scn[r]);                        // head lanes: the raw score
+                const float rstd = __builtin_amdgcn_rsqf(fmaxf((qd + ntv[r]) * invD, 0.f) + a.eps);
                 const float w = __expf(rstd * e - sref);                           // (0 beyond the heads: their reference is +1e30)
-                const float rc = __shfl(wcn[r], (lane & 48) | 15);
                 av[r] = w * rstd;
                 L += w - wcn[r];
-                if (l15 < NH) bw[(base + 4 * l4 + r) * 8 + l15] = av[r] - wcn[r] * rc;
+                if (l15 < NH) bw[(base + 4 * l4 + r) * 8 + l15] = av[r] - wcn[r] * rcv[r];
             }
             // ---- pooled patch: Pw[h][k] += a_t[h] p_tk, a as bf16 hi + remainder in the eight k-slots of the lane group ----
             union { bf16x8 v; s16x4 h[2]; } wa;
@@ -2089,8 +2069,11 @@ __global__ __launch_bounds__(256, FOLD_WG_PER_CU) void k_embed_fold(EmbedFoldArg
             }
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                const unsigned b01 = (bsel[0][q] ? 0x3F80u : 0u) | (bsel[1][q] ? 0x3F800000u : 0u);
-                const unsigned b23 = (bsel[2][q] ? 0x3F80u : 0u) | (bsel[3][q] ? 0x3F800000u : 0u);
+                unsigned bit[4];
+#pragma unroll
+                for (int r = 0; r < 4; r++) bit[r] = ((q < 2 ? prx[r] : pry[r]) >> (16 * (q & 1) + l15)) & 1u;
+                const unsigned b01 = (bit[0] ? 0x3F80u : 0u) | (bit[1] ? 0x3F800000u : 0u);
+                const unsigned b23 = (bit[2] ? 0x3F80u : 0u) | (bit[3] ? 0x3F800000u : 0u);
                 union { uint4 u; bf16x8 v; } pb;
                 pb.u = make_uint4(b01, b23, b01, b23);
                 Pw[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa.v, pb.v, Pw[q], 0, 0, 0);
@@ -2113,47 +2096,47 @@ __global__ __launch_bounds__(256, FOLD_WG_PER_CU) void k_embed_fold(EmbedFoldArg
             }
         }
         __syncthreads();
-        // ---- output image: [head][0, T) token weights / L, [T, T+3) 1 / L (hi, lo, hi), [256, 320) pooled patch / L ----
+        // the next board is known to every thread now: its loads go out under this board's output phase
+        const int nxt = scan[10], nboard = (int)gridDim.x + nxt;
+        int ngame = 0;
+        if (SRC && nboard < nvalid) { ngame = gor[nboard]; if (fast) load_cells(ngame); }
+        if (tid == 0 && nxt == nvalid - 1) a.sched[0] = 0;        // exactly nvalid tickets are drawn per launch: the last one leaves the queue zero
+        // ---- output rows, straight to memory: [head][0, T) token weights / L, [T, T+3) 1 / L (hi, lo, hi), [256, 320) pooled patch / L ----
         {
             float inv[NH];
+            {
+                const f32x4 *lr = (const f32x4 *)lred;
+                f32x4 s0 = (lr[0] + lr[2]) + (lr[4] + lr[6]), s1 = (lr[1] + lr[3]) + (lr[5] + lr[7]);
+                const f32x4 *la = (const f32x4 *)lall_s;
+                s0 += la[0]; s1 += la[1];
 #pragma unroll
-            for (int h = 0; h < NH; h++) inv[h] = 1.0f / (lall_s[h] + ((lred[h] + lred[8 + h]) + (lred[16 + h] + lred[24 + h])));
+                for (int h = 0; h < NH; h++) inv[h] = 1.0f / (h < 4 ? s0[h & 3] : s1[h & 3]);
+            }
+            unsigned short *ob = a.out + (size_t)board * NH * FOLD_ROW;
             const bool isL = tid >= T && tid < T + 3;
+            f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
+            if (dirty) { b0 = *(const f32x4 *)(bw + dpos * 8); b1 = *(const f32x4 *)(bw + dpos * 8 + 4); }
 #pragma unroll
             for (int h = 0; h < NH; h++) {
-                float v = 0.f;
-                if (dirty) v = bw[dpos * 8 + h] * inv[h];
-                unsigned o = bf16_rne(v);
+                unsigned o = bf16_rne((h < 4 ? b0[h & 3] : b1[h & 3]) * inv[h]);
                 if (isL) {
                     const unsigned hi = bf16_rne(inv[h]);
                     o = tid == T + 1 ? bf16_rne(inv[h] - __uint_as_float(hi << 16)) : hi;
                 }
-                orow[h * FOLD_ROW + tid] = (unsigned short)o;
+                ob[h * FOLD_ROW + tid] = (unsigned short)o;
             }
 #pragma unroll
             for (int i = 0; i < 2; i++) {
-                const int e = 2 * tid + i, h = e >> 6, k = e & 63;
+                const int e = tid + 256 * i, h = e >> 6, k = e & 63;                      // (a wave writes 64 consecutive entries)
                 if (h < NH) {
                     const float v = ((pwred[(0 * 8 + h) * 64 + k] + pwred[(1 * 8 + h) * 64 + k]) + (pwred[(2 * 8 + h) * 64 + k] + pwred[(3 * 8 + h) * 64 + k])) * inv[h];
-                    orow[h * FOLD_ROW + 256 + k] = (unsigned short)bf16_rne(v);
-                    orow[h * FOLD_ROW + 320 + k] = 0;
+                    ob[h * FOLD_ROW + 256 + k] = (unsigned short)bf16_rne(v);
+                    ob[h * FOLD_ROW + 320 + k] = 0;
                 }
             }
         }
-        __syncthreads();
-        {
-            const uint4 *src4 = (const uint4 *)orow;
-            uint4 *dst4 = (uint4 *)(a.out + (size_t)board * NH * FOLD_ROW);
-            for (int i = tid; i < NH * FOLD_ROW / 8; i += 256) dst4[i] = src4[i];
-        }
-        if (tid == 0) {
-            nxt = scan[10];
-            if (nxt == nvalid - 1) a.sched[0] = 0;
-            scan[8] = (int)gridDim.x + nxt;
-        }
-        __syncthreads();
-        board = scan[8];
-        AZK_FSTAMP(4);                                            // sums, output image, store, next board known
+        board = nboard; game = ngame;
+        AZK_FSTAMP(4);                                            // sums, output rows, next board's loads issued
     }
     }
     if (a.wstats != nullptr && tid == 0 && ws_boards) { atomicAdd(a.wstats, (unsigned long long)ws_boards); atomicAdd(a.wstats + 1, (unsigned long long)ws_tiles); }
@@ -2171,13 +2154,13 @@ __global__ __launch_bounds__(256, FOLD_WG_PER_CU) void k_embed_fold(EmbedFoldArg
 template <int NC, int KSZ, int NH, bool SRC>
 int launch_embed_fold(const EmbedFoldArgs &a, hipStream_t st) {
     const int tp16 = ((a.T + 15) / 16) * 16;
-    const int lds = 256 * 16 + tp16 * 8 + tp16 * 4 + 128 + 128 + 32 + tp16 * 32 + 4 * 8 * 64 * 4 + 8 * FOLD_ROW * 2 + (SRC ? 256 * 16 : 0) + (FOLD_FRAG_REGS ? 0 : 20 * 64 * 16);   // 53.8 KB with the fragments: three workgroups per CU
+    const int lds = 256 * 16 + tp16 * 8 + tp16 * 4 + 128 + 128 + 32 + tp16 * 32 + 4 * 8 * 64 * 4 + (SRC ? ((a.src.n_games + 7) / 8) * 16 : 0);   // 29 KB at 2 048 games
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void *)k_embed_fold<NC, KSZ, NH, SRC>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return AZK_ERR_HIP;
+        if (hipFuncSetAttribute((const void *)k_embed_fold<NC, KSZ, NH, SRC>, hipFuncAttributeMaxDynamicSharedMemorySize, lds + 2 * FOLD_MAX_SLOTS) != hipSuccess) return AZK_ERR_HIP;
         attr_set = true;
     }
-    const int blocks = a.n < 256 * FOLD_WG_PER_CU ? a.n : 256 * FOLD_WG_PER_CU;    // every workgroup resident; each pulls boards until the queue is dry
+    const int blocks = a.n < 512 ? a.n : 512;                      // two resident workgroups per CU; each pulls boards until the queue is dry
     k_embed_fold<NC, KSZ, NH, SRC><<<blocks, 256, lds, st>>>(a);
     return hipGetLastError() == hipSuccess ? AZK_OK : AZK_ERR_HIP;
 }
@@ -2237,7 +2220,7 @@ extern "C" int32_t azk_nn_embed_fold_leaves(const azk_leaf_source *src, const az
                                             int32_t *sched_dev, void *stream) {
     if (!src || !src->leaf_flag || !src->leaf_cells || !src->to_move || !src->leaf_depth || !src->leaf_slot || !src->n_leaf) return AZK_ERR_ARG;
     if (src->n_games < 1 || src->rows * src->cols != src->rc || src->flag_bytes < src->n_games) return AZK_ERR_ARG;
-    if (src->n_games > AZK_EMBED_POOL_COMPACT_MAX_SLOTS) return AZK_ERR_ARG;
+    if (src->n_games > AZK_EMBED_FOLD_MAX_SLOTS) return AZK_ERR_ARG;        // the rank -> game table lives in LDS (2 bytes per slot)
     return embed_fold_impl(nullptr, 0, src, consts, rows_out_bf16_dev, src->n_games, src->planes, src->rows, src->cols, nullptr, sched_dev, stream);
 }
 

@@ -970,7 +970,8 @@ class PolicyValueNet:
                     if x.dtype not in (torch.bfloat16, torch.float32):
                         x = x.float()
                     compact_ok = self.leaf_source is None or self.leaf_source.n_games <= azk.EMBED_POOL_COMPACT_MAX_SLOTS
-                    if self._foldu is not None and self.use_fold_u and self.chain_tail and self.use_chain_tail and compact_ok:
+                    if (self._foldu is not None and self.use_fold_u and self.chain_tail and self.use_chain_tail
+                            and (self.leaf_source is None or self.leaf_source.n_games <= azk.EMBED_FOLD_MAX_SLOTS)):
                         # the token rows are never formed: per head the token weights, 1 / L and the pooled patch (k_embed_fold);
                         # the tail's first GEMM turns them into the value-projected row
                         if self.leaf_source is not None:

@@ -461,6 +461,9 @@ int32_t azk_nn_heads_finalize_sum(const float *partials_dev, int32_t nsplit, int
  *   l_all, score_ref f32 [16] (score_ref >= 1e30 beyond the heads)
  * Covered: embed_dim 512, head dim 64, 4 / 8 heads, channels ksize^2 <= 64, T + 3 <= 256. */
 #define AZK_EMBED_FOLD_ROW 384
+/* azk_nn_embed_fold_leaves keeps the rank -> game table of the launch in LDS: engines with more pending-leaf slots than this get
+ * AZK_ERR_ARG and keep azk_nn_embed_pool_compact_leaves */
+#define AZK_EMBED_FOLD_MAX_SLOTS 8192
 typedef struct azk_embed_fold_consts {
     const void *g_frag, *e_frag;
     const float *u2_tok, *score_tok, *wconst_tok, *l_all, *score_ref;
