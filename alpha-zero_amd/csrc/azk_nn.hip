@@ -1801,11 +1801,12 @@ __global__ __launch_bounds__(256, 2) void k_embed_fold(EmbedFoldArgs a) {
             t_lo += wtot[2 * w]; t_hi += wtot[2 * w + 1];
         }
         const unsigned long long e_lo = b_lo + i_lo - c_lo, e_hi = b_hi + i_hi - c_hi;   // exclusive prefix over lower threads, per class
-        unsigned cbase[8];                                        // rank of this thread's first game of each class
+        unsigned long long cb_lo = 0ull, cb_hi = 0ull;            // rank of this thread's next game of each class, 16 bits each (classes 0-3 / 4-7)
         unsigned start = 0;
 #pragma unroll
         for (int c = 7; c >= 0; c--) {                            // class 7 (most stones) first
-            cbase[c] = start + (unsigned)(((c < 4 ? e_lo : e_hi) >> (16 * (c & 3))) & 0xffffull);
+            const unsigned long long cb = (unsigned long long)(start + (unsigned)(((c < 4 ? e_lo : e_hi) >> (16 * (c & 3))) & 0xffffull)) << (16 * (c & 3));
+            if (c < 4) cb_lo |= cb; else cb_hi |= cb;
             start += (unsigned)(((c < 4 ? t_lo : t_hi) >> (16 * (c & 3))) & 0xffffull);
         }
         nvalid = (int)start;
@@ -1815,10 +1816,11 @@ __global__ __launch_bounds__(256, 2) void k_embed_fold(EmbedFoldArgs a) {
 #pragma unroll
                 for (int q = 0; q < 8; q++) {
                     const unsigned c = (unsigned)((f >> (8 * q)) & 0xffull);
-                    if (c) {
-#pragma unroll
-                        for (int cc = 0; cc < 8; cc++) if (c == (unsigned)cc + 1u) { gor[cbase[cc]] = (unsigned short)(my_lo + w + q); cbase[cc] += 1u; }
-                    }
+                    const bool lo = c <= 4;
+                    const int sh = 16 * ((c - 1) & 3);
+                    if (c) gor[(unsigned)(((lo ? cb_lo : cb_hi) >> sh) & 0xffffull)] = (unsigned short)(my_lo + w + q);
+                    const unsigned long long inc = c ? 1ull << sh : 0ull;
+                    cb_lo += lo ? inc : 0ull; cb_hi += lo ? 0ull : inc;
                 }
             }
         if (blockIdx.x == 0 && tid == 0) { *a.src.n_leaf = nvalid; if (a.src.cache_stamp) *a.src.cache_stamp += 1u; }
@@ -2116,14 +2118,27 @@ __global__ __launch_bounds__(256, 2) void k_embed_fold(EmbedFoldArgs a) {
             const bool isL = tid >= T && tid < T + 3;
             f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
             if (dirty) { b0 = *(const f32x4 *)(bw + dpos * 8); b1 = *(const f32x4 *)(bw + dpos * 8 + 4); }
+            float tinv[NH];                                        // the scale of this thread's token entries
 #pragma unroll
-            for (int h = 0; h < NH; h++) {
-                unsigned o = bf16_rne((h < 4 ? b0[h & 3] : b1[h & 3]) * inv[h]);
-                if (isL) {
+            for (int h = 0; h < NH; h++) tinv[h] = inv[h];
+            if (isL) {                                             // three threads: 1 / L as bf16 hi, remainder, hi
+#pragma unroll
+                for (int h = 0; h < NH; h++) {
                     const unsigned hi = bf16_rne(inv[h]);
-                    o = tid == T + 1 ? bf16_rne(inv[h] - __uint_as_float(hi << 16)) : hi;
+                    const float v = tid == T + 1 ? inv[h] - __uint_as_float(hi << 16) : __uint_as_float(hi << 16);
+                    if (h < 4) b0[h & 3] = v; else b1[h & 3] = v;
+                    tinv[h] = 1.0f;
                 }
-                ob[h * FOLD_ROW + tid] = (unsigned short)o;
+            }
+            {
+                const u32x2 p0 = __builtin_bit_cast(u32x2, pack4_bf16(f32x2{b0[0] * tinv[0], b0[1] * tinv[1]}, f32x2{b0[2] * tinv[2], b0[3] * tinv[3]}));
+                ob[0 * FOLD_ROW + tid] = (unsigned short)p0[0]; ob[1 * FOLD_ROW + tid] = (unsigned short)(p0[0] >> 16);
+                ob[2 * FOLD_ROW + tid] = (unsigned short)p0[1]; ob[3 * FOLD_ROW + tid] = (unsigned short)(p0[1] >> 16);
+                if (NH > 4) {
+                    const u32x2 p1 = __builtin_bit_cast(u32x2, pack4_bf16(f32x2{b1[0] * tinv[4 % NH], b1[1] * tinv[5 % NH]}, f32x2{b1[2] * tinv[6 % NH], b1[3] * tinv[7 % NH]}));
+                    ob[4 * FOLD_ROW + tid] = (unsigned short)p1[0]; ob[5 * FOLD_ROW + tid] = (unsigned short)(p1[0] >> 16);
+                    ob[6 * FOLD_ROW + tid] = (unsigned short)p1[1]; ob[7 * FOLD_ROW + tid] = (unsigned short)(p1[1] >> 16);
+                }
             }
 #pragma unroll
             for (int i = 0; i < 2; i++) {
