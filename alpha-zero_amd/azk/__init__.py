@@ -32,7 +32,7 @@ SYMBOLS = [
     "azk_vanilla_set_rng", "azk_vanilla_get_rng", "azk_vanilla_search", "azk_nn_embed_pool",
     "azk_nn_gemm_rows", "azk_nn_layernorm_sum", "azk_nn_heads_finalize_sum", "azk_nn_ln_heads",
     "azk_leaf_source_of", "azk_nn_embed_pool_leaves", "azk_nn_embed_pool_compact", "azk_nn_embed_pool_compact_leaves",
-    "azk_nn_embed_fold", "azk_nn_embed_fold_leaves",
+    "azk_nn_embed_fold", "azk_nn_embed_fold_leaves", "azk_nnx_embed_fold", "azk_nnx_embed_fold_leaves",
     "azk_nn_tail_gemm", "azk_begin_search_budget", "azk_search_unfinished",
     "azk_nnx_embed_pool", "azk_nnx_embed_pool_leaves", "azk_nnx_gemm", "azk_nnx_gemm_h",
     "azk_async_begin", "azk_async_step", "azk_async_drain", "azk_async_set_budget",
@@ -207,6 +207,8 @@ def lib():
     L.azk_nn_embed_pool_compact_leaves.argtypes = [C.POINTER(LeafSource), C.POINTER(EmbedPoolConsts), vp, vp, vp]
     L.azk_nn_embed_fold.argtypes = [vp, i32, C.POINTER(EmbedFoldConsts), vp, i32, i32, i32, i32, vp, vp, vp]
     L.azk_nn_embed_fold_leaves.argtypes = [C.POINTER(LeafSource), C.POINTER(EmbedFoldConsts), vp, vp, vp]
+    L.azk_nnx_embed_fold.argtypes = [vp, i32, C.POINTER(EmbedFoldConsts), vp, i32, i32, i32, i32, vp, vp, vp]
+    L.azk_nnx_embed_fold_leaves.argtypes = [C.POINTER(LeafSource), C.POINTER(EmbedFoldConsts), vp, vp, vp]
     L.azk_begin_search_budget.argtypes = [vp, vp, i32, i32, vp]
     L.azk_search_unfinished.argtypes = [vp, vp, vp]
     L.azk_nn_tail_gemm.argtypes = [C.POINTER(TailGemm), vp]
@@ -828,8 +830,10 @@ class EmbedFoldTables:
     (r: G [64, 64], ext [64, 16], U2 [T, 64], nt [T], sct [T, H], Dtab [T, 512], M [512, 64], rstdc [T], ref [H], wc [T, H], uall [512],
     lall [H]); kept alive with the ctypes descriptor.  `weight`: H blocks of [64][EMBED_FOLD_ROW] in azk_nn_tail_gemm's packing."""
 
-    def __init__(self, r, num_heads, ksize, embed_dim, device, eps=1e-5):
+    def __init__(self, r, num_heads, ksize, embed_dim, device, eps=1e-5, exact=False):
+        """exact: the tables of azk_nnx_embed_fold (float32 rows, 1 / L in one slot) and the weight in azk_nnx_gemm_h's (hi, lo) planes."""
         torch = _torch()
+        self.exact = bool(exact)
         assert embed_dim == 512 and embed_dim // num_heads == 64
         H, D = num_heads, embed_dim
         dev = torch.device(device)
@@ -875,10 +879,16 @@ class EmbedFoldTables:
         W[:, :, :T] = r["Dtab"].to(dev).view(T, H, 64).permute(1, 2, 0)
         ua = r["uall"].to(dev).view(H, 64)
         ua_hi = ua.to(torch.bfloat16).double()
-        W[:, :, T], W[:, :, T + 1], W[:, :, T + 2] = ua_hi, ua_hi, ua - ua_hi
+        if exact:
+            W[:, :, T] = ua                                                  # (float32 rows carry 1 / L in one slot, the planes U_all in full)
+        else:
+            W[:, :, T], W[:, :, T + 1], W[:, :, T + 2] = ua_hi, ua_hi, ua - ua_hi
         W[:, :, 256:320] = r["M"].to(dev).view(H, 64, 64)
         self.weight_f64 = W
-        t["weight"] = torch.cat([pack_linear_weight(W[h].float()).reshape(-1) for h in range(H)])      # (in .t: promoted in place with the tables)
+        if exact:
+            t["weight"] = torch.stack([pack_linear_weight_h(W[h])[0] for h in range(H)]).contiguous()
+        else:
+            t["weight"] = torch.cat([pack_linear_weight(W[h].float()).reshape(-1) for h in range(H)])  # (in .t: promoted in place with the tables)
         self.weight = t["weight"]
         self.tokens, self.num_heads, self.embed_dim = T, H, D
         self.c = EmbedFoldConsts(*[t[k].data_ptr() for k in ("g_frag", "e_frag", "u2_tok", "score_tok", "wconst_tok", "l_all", "score_ref",
@@ -923,6 +933,40 @@ def nn_embed_fold_leaves(src, tables, sched, timers=None):
         timers[0].stop()
     if rc != 0:
         raise AzkError(f"azk_nn_embed_fold_leaves failed ({rc})")
+    return out
+
+
+def nnx_embed_fold(boards, tables, rows, cols, sched, count=None, timers=None):
+    """azk_nnx_embed_fold: boards [n, C, R, Cc] bf16 / f32 -> float32 [n, H, EMBED_FOLD_ROW] (token weights / L, 1 / L, pooled patch / L)."""
+    torch = _torch()
+    assert tables.exact and boards.is_cuda and boards.is_contiguous() and boards.dtype in (torch.bfloat16, torch.float32)
+    assert rows * cols + 1 == tables.tokens and sched.dtype == torch.int32 and sched.numel() >= 2
+    n, Cc = boards.shape[0], boards.shape[1]
+    out = torch.empty((n, tables.num_heads, EMBED_FOLD_ROW), dtype=torch.float32, device=boards.device)
+    args = (_p(boards), 1 if boards.dtype == torch.float32 else 0, C.byref(tables.c), _p(out), n, Cc, rows, cols, _p(count), _p(sched), _stream())
+    if timers is not None:
+        timers[0].start()
+    rc = lib().azk_nnx_embed_fold(*args)
+    if timers is not None:
+        timers[0].stop()
+    if rc != 0:
+        raise AzkError(f"azk_nnx_embed_fold failed ({rc})")
+    return out
+
+
+def nnx_embed_fold_leaves(src, tables, sched, timers=None):
+    """azk_nnx_embed_fold over an engine's pending leaves (LeafSource): float32 [G, H, EMBED_FOLD_ROW], rows [0, n_leaf) valid."""
+    torch = _torch()
+    assert tables.exact and src.rows * src.cols + 1 == tables.tokens and sched.dtype == torch.int32 and sched.numel() >= 2
+    out = torch.empty((src.n_games, tables.num_heads, EMBED_FOLD_ROW), dtype=torch.float32, device=sched.device)
+    args = (C.byref(src), C.byref(tables.c), _p(out), _p(sched), _stream())
+    if timers is not None:
+        timers[0].start()
+    rc = lib().azk_nnx_embed_fold_leaves(*args)
+    if timers is not None:
+        timers[0].stop()
+    if rc != 0:
+        raise AzkError(f"azk_nnx_embed_fold_leaves failed ({rc})")
     return out
 
 

@@ -1724,7 +1724,7 @@ struct EmbedFoldArgs {
     const uint4 *gfrag;            // [2 (hi, lo)][4][2][64]
     const uint4 *efrag;            // [2][2][64]
     const float *u2T, *scoreT, *wcT, *lall, *sref, *inv_scales;
-    unsigned short *out;           // [n][NH][FOLD_ROW] bf16
+    void *out;                     // [n][NH][FOLD_ROW] bf16 (EX: float32)
     const int *count;
     int *sched;
     unsigned long long *wstats;
@@ -1742,7 +1742,18 @@ __device__ __forceinline__ unsigned bf16_rne(float v) {
 constexpr int FOLD_ROW = AZK_EMBED_FOLD_ROW;
 constexpr int FOLD_MAX_SLOTS = AZK_EMBED_FOLD_MAX_SLOTS;
 
-template <int NC, int KSZ, int NH, bool SRC>
+// exp(x) for x <= ~80 with float32 accuracy: x log2(e) carried as hi + lo, v_exp_f32 on hi, first-order correction for lo (as azk_nnx.hip)
+__device__ __forceinline__ float fold_exp_acc(float x) {
+    const float L2E_HI = 1.44269502162933349609375f, L2E_LO = 1.92596299112661746e-8f;
+    const float hi = x * L2E_HI;
+    const float lo = __builtin_fmaf(x, L2E_HI, -hi) + x * L2E_LO;
+    const float r = __builtin_amdgcn_exp2f(hi);
+    return __builtin_fmaf(r, lo * 0.693147180559945309f, r);
+}
+
+// EX: the float32-accurate form (azk_nnx_embed_fold, the fp32 line): correctly rounded rsqrt, exp with an extended-precision argument, the
+// pooled patch on v_mfma_f32_16x16x4_f32 (float32 weights against the 0 / 1 patch: exact products), float32 rows out (1 / L in one slot).
+template <int NC, int KSZ, int NH, bool SRC, bool EX>
 __global__ __launch_bounds__(256, 2) void k_embed_fold(EmbedFoldArgs a) {
     static_assert(NC * KSZ * KSZ <= 64, "the patch is one 64-bit word");
     constexpr int D = 512;
@@ -2054,31 +2065,45 @@ __global__ __launch_bounds__(256, 2) void k_embed_fold(EmbedFoldArgs a) {
                 qd = fmaf(qd, ginv, cross[r]);
                 qd = row16_sum(qd);
                 const float e = fmaf(E[r], einv, scn[r]);                        // head lanes: the raw score
-                const float rstd = __builtin_amdgcn_rsqf(fmaxf((qd + ntv[r]) * invD, 0.f) + a.eps);
-                const float w = __expf(rstd * e - sref);                           // (0 beyond the heads: their reference is +1e30)
+                const float var = fmaxf((qd + ntv[r]) * invD, 0.f) + a.eps;
+                const float rstd = EX ? 1.0f / sqrtf(var) : __builtin_amdgcn_rsqf(var);
+                const float w = EX ? fold_exp_acc(rstd * e - sref) : __expf(rstd * e - sref);   // (0 beyond the heads: their reference is +1e30)
                 av[r] = w * rstd;
                 L += w - wcn[r];
                 if (l15 < NH) bw[(base + 4 * l4 + r) * 8 + l15] = av[r] - wcn[r] * rcv[r];
             }
-            // ---- pooled patch: Pw[h][k] += a_t[h] p_tk, a as bf16 hi + remainder in the eight k-slots of the lane group ----
-            union { bf16x8 v; s16x4 h[2]; } wa;
-            wa.h[0] = pack4_bf16(f32x2{av[0], av[1]}, f32x2{av[2], av[3]});
-            {
-                const u32x2 hh = __builtin_bit_cast(u32x2, wa.h[0]);
-                const float r0 = av[0] - __uint_as_float(hh[0] << 16), r1 = av[1] - __uint_as_float(hh[0] & 0xffff0000u);
-                const float r2 = av[2] - __uint_as_float(hh[1] << 16), r3 = av[3] - __uint_as_float(hh[1] & 0xffff0000u);
-                wa.h[1] = pack4_bf16(f32x2{r0, r1}, f32x2{r2, r3});
-            }
+            // ---- pooled patch: Pw[h][k] += a_t[h] p_tk ----
+            if (EX) {
+                // float32: one v_mfma_f32_16x16x4_f32 per token of the lane group and column tile (A: a of token 4 l4 + r for head l15,
+                // B: that token's patch bit at column 16 q + l15; the k index of both is the lane group)
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                unsigned bit[4];
+                for (int r = 0; r < 4; r++)
 #pragma unroll
-                for (int r = 0; r < 4; r++) bit[r] = ((q < 2 ? prx[r] : pry[r]) >> (16 * (q & 1) + l15)) & 1u;
-                const unsigned b01 = (bit[0] ? 0x3F80u : 0u) | (bit[1] ? 0x3F800000u : 0u);
-                const unsigned b23 = (bit[2] ? 0x3F80u : 0u) | (bit[3] ? 0x3F800000u : 0u);
-                union { uint4 u; bf16x8 v; } pb;
-                pb.u = make_uint4(b01, b23, b01, b23);
-                Pw[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa.v, pb.v, Pw[q], 0, 0, 0);
+                    for (int q = 0; q < 4; q++) {
+                        const float bit = ((q < 2 ? prx[r] : pry[r]) >> (16 * (q & 1) + l15)) & 1u ? 1.0f : 0.0f;
+                        Pw[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r], bit, Pw[q], 0, 0, 0);
+                    }
+            } else {
+                // bf16: a as hi + remainder in the eight k-slots of the lane group (B: the patch bits twice)
+                union { bf16x8 v; s16x4 h[2]; } wa;
+                wa.h[0] = pack4_bf16(f32x2{av[0], av[1]}, f32x2{av[2], av[3]});
+                {
+                    const u32x2 hh = __builtin_bit_cast(u32x2, wa.h[0]);
+                    const float r0 = av[0] - __uint_as_float(hh[0] << 16), r1 = av[1] - __uint_as_float(hh[0] & 0xffff0000u);
+                    const float r2 = av[2] - __uint_as_float(hh[1] << 16), r3 = av[3] - __uint_as_float(hh[1] & 0xffff0000u);
+                    wa.h[1] = pack4_bf16(f32x2{r0, r1}, f32x2{r2, r3});
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    unsigned bit[4];
+#pragma unroll
+                    for (int r = 0; r < 4; r++) bit[r] = ((q < 2 ? prx[r] : pry[r]) >> (16 * (q & 1) + l15)) & 1u;
+                    const unsigned b01 = (bit[0] ? 0x3F80u : 0u) | (bit[1] ? 0x3F800000u : 0u);
+                    const unsigned b23 = (bit[2] ? 0x3F80u : 0u) | (bit[3] ? 0x3F800000u : 0u);
+                    union { uint4 u; bf16x8 v; } pb;
+                    pb.u = make_uint4(b01, b23, b01, b23);
+                    Pw[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa.v, pb.v, Pw[q], 0, 0, 0);
+                }
             }
         }
         // next board: one ticket per board, drawn by the wave with the fewest tiles behind its last one (a returning atomic is waited
@@ -2114,23 +2139,36 @@ __global__ __launch_bounds__(256, 2) void k_embed_fold(EmbedFoldArgs a) {
 #pragma unroll
                 for (int h = 0; h < NH; h++) inv[h] = 1.0f / (h < 4 ? s0[h & 3] : s1[h & 3]);
             }
-            unsigned short *ob = a.out + (size_t)board * NH * FOLD_ROW;
             const bool isL = tid >= T && tid < T + 3;
             f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
             if (dirty) { b0 = *(const f32x4 *)(bw + dpos * 8); b1 = *(const f32x4 *)(bw + dpos * 8 + 4); }
             float tinv[NH];                                        // the scale of this thread's token entries
 #pragma unroll
             for (int h = 0; h < NH; h++) tinv[h] = inv[h];
-            if (isL) {                                             // three threads: 1 / L as bf16 hi, remainder, hi
+            if (isL) {                                             // three threads: 1 / L (bf16 rows: as hi, remainder, hi; float32 rows: value, 0, 0)
 #pragma unroll
                 for (int h = 0; h < NH; h++) {
                     const unsigned hi = bf16_rne(inv[h]);
-                    const float v = tid == T + 1 ? inv[h] - __uint_as_float(hi << 16) : __uint_as_float(hi << 16);
+                    float v = tid == T + 1 ? inv[h] - __uint_as_float(hi << 16) : __uint_as_float(hi << 16);
+                    if (EX) v = tid == T ? inv[h] : 0.f;
                     if (h < 4) b0[h & 3] = v; else b1[h & 3] = v;
                     tinv[h] = 1.0f;
                 }
             }
-            {
+            if (EX) {
+                float *of = (float *)a.out + (size_t)board * NH * FOLD_ROW;
+#pragma unroll
+                for (int h = 0; h < NH; h++) of[h * FOLD_ROW + tid] = (h < 4 ? b0[h & 3] : b1[h & 3]) * tinv[h];
+#pragma unroll
+                for (int i = 0; i < 2; i++) {
+                    const int e = tid + 256 * i, h = e >> 6, k = e & 63;
+                    if (h < NH) {
+                        of[h * FOLD_ROW + 256 + k] = ((pwred[(0 * 8 + h) * 64 + k] + pwred[(1 * 8 + h) * 64 + k]) + (pwred[(2 * 8 + h) * 64 + k] + pwred[(3 * 8 + h) * 64 + k])) * inv[h];
+                        of[h * FOLD_ROW + 320 + k] = 0.f;
+                    }
+                }
+            } else {
+                unsigned short *ob = (unsigned short *)a.out + (size_t)board * NH * FOLD_ROW;
                 const u32x2 p0 = __builtin_bit_cast(u32x2, pack4_bf16(f32x2{b0[0] * tinv[0], b0[1] * tinv[1]}, f32x2{b0[2] * tinv[2], b0[3] * tinv[3]}));
                 ob[0 * FOLD_ROW + tid] = (unsigned short)p0[0]; ob[1 * FOLD_ROW + tid] = (unsigned short)(p0[0] >> 16);
                 ob[2 * FOLD_ROW + tid] = (unsigned short)p0[1]; ob[3 * FOLD_ROW + tid] = (unsigned short)(p0[1] >> 16);
@@ -2139,14 +2177,14 @@ __global__ __launch_bounds__(256, 2) void k_embed_fold(EmbedFoldArgs a) {
                     ob[4 * FOLD_ROW + tid] = (unsigned short)p1[0]; ob[5 * FOLD_ROW + tid] = (unsigned short)(p1[0] >> 16);
                     ob[6 * FOLD_ROW + tid] = (unsigned short)p1[1]; ob[7 * FOLD_ROW + tid] = (unsigned short)(p1[1] >> 16);
                 }
-            }
 #pragma unroll
-            for (int i = 0; i < 2; i++) {
-                const int e = tid + 256 * i, h = e >> 6, k = e & 63;                      // (a wave writes 64 consecutive entries)
-                if (h < NH) {
-                    const float v = ((pwred[(0 * 8 + h) * 64 + k] + pwred[(1 * 8 + h) * 64 + k]) + (pwred[(2 * 8 + h) * 64 + k] + pwred[(3 * 8 + h) * 64 + k])) * inv[h];
-                    ob[h * FOLD_ROW + 256 + k] = (unsigned short)bf16_rne(v);
-                    ob[h * FOLD_ROW + 320 + k] = 0;
+                for (int i = 0; i < 2; i++) {
+                    const int e = tid + 256 * i, h = e >> 6, k = e & 63;                      // (a wave writes 64 consecutive entries)
+                    if (h < NH) {
+                        const float v = ((pwred[(0 * 8 + h) * 64 + k] + pwred[(1 * 8 + h) * 64 + k]) + (pwred[(2 * 8 + h) * 64 + k] + pwred[(3 * 8 + h) * 64 + k])) * inv[h];
+                        ob[h * FOLD_ROW + 256 + k] = (unsigned short)bf16_rne(v);
+                        ob[h * FOLD_ROW + 320 + k] = 0;
+                    }
                 }
             }
         }
@@ -2166,24 +2204,24 @@ __global__ __launch_bounds__(256, 2) void k_embed_fold(EmbedFoldArgs a) {
 #endif
 }
 
-template <int NC, int KSZ, int NH, bool SRC>
+template <int NC, int KSZ, int NH, bool SRC, bool EX>
 int launch_embed_fold(const EmbedFoldArgs &a, hipStream_t st) {
     const int tp16 = ((a.T + 15) / 16) * 16;
     const int lds = 256 * 16 + tp16 * 8 + tp16 * 4 + 128 + 128 + 32 + tp16 * 32 + 4 * 8 * 64 * 4 + (SRC ? ((a.src.n_games + 7) / 8) * 16 : 0);   // 29 KB at 2 048 games
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void *)k_embed_fold<NC, KSZ, NH, SRC>, hipFuncAttributeMaxDynamicSharedMemorySize, lds + 2 * FOLD_MAX_SLOTS) != hipSuccess) return AZK_ERR_HIP;
+        if (hipFuncSetAttribute((const void *)k_embed_fold<NC, KSZ, NH, SRC, EX>, hipFuncAttributeMaxDynamicSharedMemorySize, lds + 2 * FOLD_MAX_SLOTS) != hipSuccess) return AZK_ERR_HIP;
         attr_set = true;
     }
     const int blocks = a.n < 512 ? a.n : 512;                      // two resident workgroups per CU; each pulls boards until the queue is dry
-    k_embed_fold<NC, KSZ, NH, SRC><<<blocks, 256, lds, st>>>(a);
+    k_embed_fold<NC, KSZ, NH, SRC, EX><<<blocks, 256, lds, st>>>(a);
     return hipGetLastError() == hipSuccess ? AZK_OK : AZK_ERR_HIP;
 }
 }  // namespace
 
 static int32_t embed_fold_impl(const void *boards_dev, int32_t boards_are_f32, const azk_leaf_source *src, const azk_embed_fold_consts *k,
                                void *rows_out, int32_t n, int32_t channels, int32_t rows, int32_t cols, const int32_t *n_valid_dev,
-                               int32_t *sched_dev, void *stream) {
+                               int32_t *sched_dev, void *stream, bool exact = false) {
     if ((!boards_dev && !src) || !k || !rows_out || !sched_dev) return AZK_ERR_ARG;
     if (!k->g_frag || !k->e_frag || !k->u2_tok || !k->score_tok || !k->wconst_tok || !k->l_all || !k->score_ref || !k->inv_scales) return AZK_ERR_ARG;
     const int ksize = k->ksize;
@@ -2196,7 +2234,7 @@ static int32_t embed_fold_impl(const void *boards_dev, int32_t boards_are_f32, c
     memset(&a, 0, sizeof a);
     a.boards = boards_dev; a.boards_f32 = boards_are_f32; a.gfrag = (const uint4 *)k->g_frag; a.efrag = (const uint4 *)k->e_frag;
     a.u2T = k->u2_tok; a.scoreT = k->score_tok; a.wcT = k->wconst_tok; a.lall = k->l_all; a.sref = k->score_ref; a.inv_scales = k->inv_scales;
-    a.out = (unsigned short *)rows_out; a.count = n_valid_dev; a.sched = sched_dev; a.wstats = (unsigned long long *)k->work_stats;
+    a.out = rows_out; a.count = n_valid_dev; a.sched = sched_dev; a.wstats = (unsigned long long *)k->work_stats;
     a.n = n; a.R = rows; a.Cc = cols; a.T = rows * cols + 1; a.eps = k->ln_eps;
     if (src) a.src = *src;
     {
@@ -2218,7 +2256,8 @@ static int32_t embed_fold_impl(const void *boards_dev, int32_t boards_are_f32, c
     hipStream_t st = (hipStream_t)stream;
     const int nh = k->num_heads;
 #define CASE(NC_, KSZ_, NH_) if (channels == NC_ && ksize == KSZ_ && nh == NH_) \
-        return src ? launch_embed_fold<NC_, KSZ_, NH_, true>(a, st) : launch_embed_fold<NC_, KSZ_, NH_, false>(a, st)
+        return exact ? (src ? launch_embed_fold<NC_, KSZ_, NH_, true, true>(a, st) : launch_embed_fold<NC_, KSZ_, NH_, false, true>(a, st)) \
+                     : (src ? launch_embed_fold<NC_, KSZ_, NH_, true, false>(a, st) : launch_embed_fold<NC_, KSZ_, NH_, false, false>(a, st))
     CASE(2, 5, 8); CASE(2, 5, 4); CASE(2, 3, 8); CASE(2, 3, 4); CASE(3, 3, 8); CASE(3, 3, 4);
 #undef CASE
     return AZK_ERR_ARG;
@@ -2231,12 +2270,30 @@ extern "C" int32_t azk_nn_embed_fold(const void *boards_dev, int32_t boards_are_
     return embed_fold_impl(boards_dev, boards_are_f32, nullptr, consts, rows_out_bf16_dev, n, channels, rows, cols, n_valid_dev, sched_dev, stream);
 }
 
-extern "C" int32_t azk_nn_embed_fold_leaves(const azk_leaf_source *src, const azk_embed_fold_consts *consts, void *rows_out_bf16_dev,
-                                            int32_t *sched_dev, void *stream) {
+static int32_t embed_fold_leaves_impl(const azk_leaf_source *src, const azk_embed_fold_consts *consts, void *rows_out, int32_t *sched_dev,
+                                      void *stream, bool exact) {
     if (!src || !src->leaf_flag || !src->leaf_cells || !src->to_move || !src->leaf_depth || !src->leaf_slot || !src->n_leaf) return AZK_ERR_ARG;
     if (src->n_games < 1 || src->rows * src->cols != src->rc || src->flag_bytes < src->n_games) return AZK_ERR_ARG;
     if (src->n_games > AZK_EMBED_FOLD_MAX_SLOTS) return AZK_ERR_ARG;        // the rank -> game table lives in LDS (2 bytes per slot)
-    return embed_fold_impl(nullptr, 0, src, consts, rows_out_bf16_dev, src->n_games, src->planes, src->rows, src->cols, nullptr, sched_dev, stream);
+    return embed_fold_impl(nullptr, 0, src, consts, rows_out, src->n_games, src->planes, src->rows, src->cols, nullptr, sched_dev, stream, exact);
+}
+
+extern "C" int32_t azk_nn_embed_fold_leaves(const azk_leaf_source *src, const azk_embed_fold_consts *consts, void *rows_out_bf16_dev,
+                                            int32_t *sched_dev, void *stream) {
+    return embed_fold_leaves_impl(src, consts, rows_out_bf16_dev, sched_dev, stream, false);
+}
+
+// the float32-accurate form (the fp32 line, include/azk.h): float32 rows for azk_nnx_gemm_h's float32-A first link
+extern "C" int32_t azk_nnx_embed_fold(const void *boards_dev, int32_t boards_are_f32, const azk_embed_fold_consts *consts, float *rows_out_f32_dev,
+                                      int32_t n, int32_t channels, int32_t rows, int32_t cols, const int32_t *n_valid_dev, int32_t *sched_dev,
+                                      void *stream) {
+    if (!boards_dev) return AZK_ERR_ARG;
+    return embed_fold_impl(boards_dev, boards_are_f32, nullptr, consts, rows_out_f32_dev, n, channels, rows, cols, n_valid_dev, sched_dev, stream, true);
+}
+
+extern "C" int32_t azk_nnx_embed_fold_leaves(const azk_leaf_source *src, const azk_embed_fold_consts *consts, float *rows_out_f32_dev,
+                                             int32_t *sched_dev, void *stream) {
+    return embed_fold_leaves_impl(src, consts, rows_out_f32_dev, sched_dev, stream, true);
 }
 
 // =====================================================================================================

@@ -1028,7 +1028,7 @@ int launch_gemm_h(const GemmHArgs &a, hipStream_t st) {
 
 extern "C" int32_t azk_nnx_gemm_h(const azk_gemm_h *t, void *stream) {
     if (!t || !t->w_packed || t->m < 0 || t->n_out < 64 || (t->n_out & 63) || t->nbatch < 1) return AZK_ERR_ARG;
-    if ((t->k != 512 && t->k != 2048) || t->lda < t->k || (t->lda & 7) || (t->a_batch_stride & 7)) return AZK_ERR_ARG;
+    if ((t->k != 512 && t->k != 2048 && t->k != 384) || t->lda < t->k || (t->lda & 7) || (t->a_batch_stride & 7)) return AZK_ERR_ARG;
     const bool af32 = t->a_f32 != nullptr;
     if (!af32 && (!t->a_hi || !t->a_lo)) return AZK_ERR_ARG;
     if (t->epilogue < 0 || t->epilogue > 3 || (t->layernorm_a && (t->k != 512 || !t->a_stats || !t->col_sums))) return AZK_ERR_ARG;
@@ -1054,6 +1054,8 @@ extern "C" int32_t azk_nnx_gemm_h(const azk_gemm_h *t, void *stream) {
         if (t->epilogue == X_EPI_PLAIN) return launch_gemm_h<X_EPI_PLAIN, 0, 0, 4, 512>(a, st);
         return AZK_ERR_ARG;
     }
+    if (t->k == 384)                                                   // azk_nnx_embed_fold's float32 rows (AZK_EMBED_FOLD_ROW) against [D_t; U_all; M_h]
+        return af32 && !ln && t->epilogue == X_EPI_PLAIN ? launch_gemm_h<X_EPI_PLAIN, 0, 1, 4, 96>(a, st) : AZK_ERR_ARG;
     const bool wide = t->n_out % 128 == 0 && t->n_out >= 1024;
     if (af32) {                                                        // the first link: float32 z, split on the fly
         if (ln || t->epilogue != X_EPI_PLAIN) return AZK_ERR_ARG;

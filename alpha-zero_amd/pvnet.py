@@ -300,6 +300,10 @@ class PolicyValueNet:
         H = cfg.num_heads
         e = dict(tables=azk.EmbedPoolXTables({k_: r[k_] for k_ in ("wt_ext", "cpos_tok", "score_tok", "wconst_tok", "xnconst_tok", "z_all", "l_all",
                                                                    "score_msum", "score_ref")}, H, cfg.patch_size, cfg.embed_dim, 1e-5))
+        # the patch-pooling form of embedding + pooling + value projection in float32-accurate arithmetic (k_embed_fold<EX> + one batched
+        # link of the (hi, lo)-plane tail); tables in float64 from the master weights
+        rf = self.fold_u()
+        e["foldu"] = azk.EmbedFoldTables(rf, H, cfg.patch_size, cfg.embed_dim, self.device, exact=True) if rf is not None else None
         e["WvX"] = torch.cat([azk.pack_linear_weight_x(r["Wvn"][h]).reshape(-1) for h in range(H)])
         for k_ in ("Wo", "W0G", "W3", "WhG"):
             e[k_ + "X"] = azk.pack_linear_weight_x(r[k_])
@@ -428,7 +432,17 @@ class PolicyValueNet:
         """The fp32-accurate folded cls path: boards (or the engine's pending leaves) -> z float32 [n, H, D] -> logits, tanh(value)."""
         import azk
         cfg, e = self.cfg, self._exact
-        if self.leaf_source is not None:
+        if (e.get("foldu") is not None and self.use_fold_u and getattr(self, "exact_tail", "f32") == "h16"
+                and (self.leaf_source is None or self.leaf_source.n_games <= azk.EMBED_FOLD_MAX_SLOTS)):
+            # the token rows are never formed (k_embed_fold<EX>): float32 rows of token weights / L, 1 / L, pooled patch / L per head
+            if self.leaf_source is not None:
+                z = azk.nnx_embed_fold_leaves(self.leaf_source, e["foldu"], self._sched_for(self.leaf_source), timers=self.kernel_timers)
+            else:
+                if x.dtype not in (torch.bfloat16, torch.float32):
+                    x = x.float()
+                z = azk.nnx_embed_fold(x.contiguous(), e["foldu"], cfg.rows, cfg.cols, self._sched_for(None), count=self.live_count,
+                                       timers=self.kernel_timers)
+        elif self.leaf_source is not None:
             z = azk.nnx_embed_pool_leaves(self.leaf_source, e["tables"], self._sched_for(self.leaf_source), timers=self.kernel_timers)
         else:
             if x.dtype not in (torch.bfloat16, torch.float32):
@@ -458,7 +472,11 @@ class PolicyValueNet:
             self._tail_ws[key] = ws
         pl = lambda k_: (ws[k_][0, :n], ws[k_][1, :n])
         G = azk.nnx_gemm_h
-        self._launch(G, z.view(n, H * D), e["WvH"], D // H, D, azk.TAIL_BF16, nbatch=H, a_batch_stride=D, out=pl("u"), count=cnt)
+        if z.shape[-1] == azk.EMBED_FOLD_ROW:      # k_embed_fold's float32 rows against [D_t; U_all; M_h]: the value-projected row directly
+            kf = azk.EMBED_FOLD_ROW
+            self._launch(G, z.view(n, H * kf), e["foldu"].weight, D // H, kf, azk.TAIL_BF16, nbatch=H, a_batch_stride=kf, out=pl("u"), count=cnt)
+        else:
+            self._launch(G, z.view(n, H * D), e["WvH"], D // H, D, azk.TAIL_BF16, nbatch=H, a_batch_stride=D, out=pl("u"), count=cnt)
         self._launch(G, pl("u"), e["WoH"], D, D, azk.TAIL_BF16, bias=e["bias1"], out=pl("x1"), out_f32=ws["x1f"][:n], stats_out=ws["st1"][:n], count=cnt)
         self._launch(G, pl("x1"), e["W0GH"], 4 * D, D, azk.TAIL_GELU, bias=e["b0G"], col_sums=e["W0GH_csum"], out=pl("hh"), a_stats=ws["st1"][:n], count=cnt)
         self._launch(G, pl("hh"), e["W3H"], D, 4 * D, azk.TAIL_RESID, bias=e["b3"], resid=ws["x1f"][:n], out=pl("x2"), stats_out=ws["st2"][:n], count=cnt)

@@ -199,7 +199,7 @@ def main():
                     help="default: clsfold (hand-written kernels: azk_nn.hip for bf16, the fp32-accurate azk_nnx.hip for fp32); cls / full = torch library forward")
     ap.add_argument("--nn-dtype", default="bf16", choices=["bf16", "fp32"],
                     help="bf16 (default, north_star's MFMA bf16): the hand-written bf16 kernels; fp32: the hand-written fp32-accurate kernels "
-                         "(fp16 hi/lo conv on the 0/1 board, v_mfma_f32_16x16x4_f32 elsewhere) - the evaluator whose visit-count policies "
+                         "(exact products of the 0/1 board with fp16 hi/lo terms, float32 elsewhere) - the evaluator whose visit-count policies "
                          "equal the reference's float32 network's to the last visit")
     ap.add_argument("--tail", default="chain", choices=["chain", "library"],
                     help="cls-row tail: the all-hand-written GEMM chain (azk_nn_tail_gemm: honours the live leaf count; default) or "
@@ -292,7 +292,9 @@ def main():
         net.use_fold_u = args.embed == "fold"
         fold = (not exact and getattr(net, "_foldu", None) is not None and net.use_fold_u and args.tail == "chain" and getattr(net, "chain_tail", False)
                 and args.nn_path == "clsfold")         # k_embed_fold: patch-pooling form, token rows never formed
-        ep_tables = net._exact["tables"] if exact else (net._foldu if fold else getattr(net, "_compact", None))
+        xfold = (exact and net._exact.get("foldu") is not None and net.use_fold_u and getattr(net, "exact_tail", "f32") == "h16")   # k_embed_fold<EX>
+        fold = fold or xfold
+        ep_tables = (net._exact["foldu"] if xfold else net._exact["tables"]) if exact else (net._foldu if fold else getattr(net, "_compact", None))
         ep_stats = ep_tables.enable_work_stats() if ep_tables is not None else None   # device counters: boards / 16-token tiles evaluated
         if args.train_step:
             from azk import DeviceReplay
@@ -450,7 +452,7 @@ def main():
             ep_traffic = None
             try:
                 # the counters were collected on the bf16 build's kernel: no figure for k_embed_pool_x unless the file holds one
-                ep_traffic = next(v["bytes_per_launch"] for k_, v in pmc.items() if k_.startswith("k_embed_pool_x" if exact else ("k_embed_fold" if fold else "k_embed_pool_c")))
+                ep_traffic = next(v["bytes_per_launch"] for k_, v in pmc.items() if k_ == ("k_embed_fold" if fold and not exact else ("k_embed_pool_x" if exact and not fold else ("k_embed_pool_c" if not exact else "-"))))
             except Exception:
                 pass
             compact = exact or fold or (getattr(net, "_compact", None) is not None and getattr(net, "use_compact", False))
@@ -463,12 +465,12 @@ def main():
                     # k_embed_fold issues 24 MFMAs of 16 x 16 x 32 per evaluated tile (quadratic form 16, score columns 4, pooled patch 4)
                     executed_share = et * 24 * 2 * 16 * 16 * 32 / max(1, eb) / per_board
             ep_peak = MFMA_BF16_PEAK_TFLOPS
-            if exact:
+            if exact and not fold:
                 # two matrix pipes rates in one kernel: conv / score columns on the fp16 pipe (weights as hi + lo: two MFMAs per product),
                 # the weighted token sum on v_mfma_f32_16x16x4_f32.  peak = the blended rate at which the algorithmic flops could issue
                 pool_fl = 2 * T_tok * cfg.num_heads * Dm
                 ep_peak = per_board / ((per_board - pool_fl) / MFMA_BF16_PEAK_TFLOPS + pool_fl / MFMA_F32_PEAK_TFLOPS)
-            kernels.append({"kernel": "k_embed_pool_x" if exact else ("k_embed_fold" if fold else ("k_embed_pool_c" if compact else "k_embed_pool")), "bound": "mfma", "achieved": fl / (ms * 1e-3) / 1e12,
+            kernels.append({"kernel": ("k_embed_fold<EX>" if fold else "k_embed_pool_x") if exact else ("k_embed_fold" if fold else ("k_embed_pool_c" if compact else "k_embed_pool")), "bound": "mfma", "achieved": fl / (ms * 1e-3) / 1e12,
                             "peak": ep_peak, "unit": "TFLOP/s", "frac": fl / (ms * 1e-3) / 1e12 / ep_peak, "avg_launch_us": ms * 1e3,
                             "median_launch_us": ch.spread_us()[0], "max_launch_us": ch.spread_us()[1],
                             "algorithmic_flops_per_launch": fl, "traffic": ep_traffic,
@@ -553,7 +555,7 @@ def main():
                              "command": "python bench.py --nn-dtype fp32", "source": "profiles/r03_bench_fp32.json"}
             except Exception:
                 pass
-            exact_par = {"evaluator": "hand-written fp32-accurate kernels (csrc/azk_nnx.hip: fp16 hi/lo conv on the 0/1 board, f32-input MFMA for the stone-touched pooling, fp16 hi/lo planes for the constant-token pooling and the cls-row tail)",
+            exact_par = {"evaluator": "hand-written fp32-accurate kernels (k_embed_fold<EX>: LayerNorm statistics and scores from the patch bits on fp16 hi/lo terms with float32 accumulation, float32 weights; cls-row tail on fp16 hi/lo planes, csrc/azk_nnx.hip k_gemm_h)",
                          "logits_vs_reference_seed0": par["kat_vs_reference_seed0"].get("fp32_clsfold"),
                          "visit_policy_vs_fp32_full": par["search_vs_fp32_full"].get("fp32_clsfold"), "bench_line": fp32_line}
             if args.nn_dtype == "bf16":

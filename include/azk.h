@@ -477,6 +477,14 @@ int32_t azk_nn_embed_fold(const void *boards_dev, int32_t boards_are_f32, const 
                           void *stream);
 int32_t azk_nn_embed_fold_leaves(const azk_leaf_source *src, const azk_embed_fold_consts *consts, void *rows_out_bf16_dev,
                                  int32_t *sched_dev, void *stream);
+/* azk_nnx_embed_fold(_leaves): the same function in float32-accurate arithmetic for the fp32 line (ai/nn.py:74-84 at ai/mcts.py:46 in the
+ * reference's own precision): correctly rounded rsqrt, exp with an extended-precision argument, the pooled patch on v_mfma_f32_16x16x4_f32,
+ * float32 rows out ([T] = 1 / L, [T+1], [T+2] = 0) for azk_nnx_gemm_h's float32-A link (k = AZK_EMBED_FOLD_ROW). */
+int32_t azk_nnx_embed_fold(const void *boards_dev, int32_t boards_are_f32, const azk_embed_fold_consts *consts, float *rows_out_f32_dev,
+                           int32_t n, int32_t channels, int32_t rows, int32_t cols, const int32_t *n_valid_dev, int32_t *sched_dev,
+                           void *stream);
+int32_t azk_nnx_embed_fold_leaves(const azk_leaf_source *src, const azk_embed_fold_consts *consts, float *rows_out_f32_dev,
+                                  int32_t *sched_dev, void *stream);
 
 /* ---- fp32-accurate network path (csrc/azk_nnx.hip): the reference evaluates its network in float32 (ai/nn.py:74-84 called at
  * ai/mcts.py:46), and north_star asks for visit-count policies within 1e-5 of it.  The same two stages as above - boards -> pooled

@@ -149,14 +149,46 @@ def test_embed_pool_x_against_float64():
     assert int(net._sched_for(None)[0]) == 0              # the board queue is left zero
 
 
-@pytest.mark.parametrize("tail", ["h16", "f32"])
+def test_embed_fold_exact_rows_against_float64():
+    """k_embed_fold<EX> (azk_nnx_embed_fold: embedding + pooling from the patch bits, float32 rows) against the float64 evaluation of
+    its formulas, entry by entry, and through the batched (hi, lo)-plane link against the float64 value-projected row.  Budget: the
+    quadratic form and the score columns on two fp16 terms (2.4e-7 relative), float32 statistics / exp / sums: asserted at 3e-6 of
+    the largest entry.  Engine-leaf variant: the same rows, bit for bit, handed out from the stone-heavy classes down."""
+    import azk
+    net = PolicyValueNet(CFG, seed=0, device="cuda", dtype=torch.float32, path="clsfold")
+    ft = net._exact["foldu"]
+    assert ft is not None and ft.exact
+    T, H, ROW = CFG.tokens, CFG.num_heads, azk.EMBED_FOLD_ROW
+    x = random_boards(600, 5, max_stones=100)
+    x[0] = 0
+    x = x.cuda()
+    sched = net._sched_for(None)
+    rows = azk.nnx_embed_fold(x, ft, 15, 15, sched)
+    torch.cuda.synchronize()
+    assert rows.dtype == torch.float32 and rows.shape == (600, H, ROW) and int(sched[0]) == 0
+    u64, bw, inv_l, pw = net.forward_fold_u_emulated(x)
+    got = rows.double()
+    for a_, b_ in ((got[:, :, :T], bw), (got[:, :, T], inv_l), (got[:, :, 256:320], pw)):
+        assert (a_ - b_).abs().max().item() < 3e-6 * b_.abs().max().item(), ((a_ - b_).abs().max().item(), b_.abs().max().item())
+    assert bool((rows[:, :, T + 1:256] == 0).all()) and bool((rows[:, :, 320:] == 0).all()) and bool((rows[0, :, :T] == 0).all())
+    u = (torch.empty(600, 512, dtype=torch.float16, device="cuda"), torch.empty(600, 512, dtype=torch.float16, device="cuda"))
+    uf = torch.empty(600, 512, dtype=torch.float32, device="cuda")
+    azk.nnx_gemm_h(rows.view(600, H * ROW), ft.weight, 64, ROW, azk.TAIL_BF16, nbatch=H, a_batch_stride=ROW, out=u, out_f32=uf)
+    assert (uf.double() - u64).abs().max().item() < 3e-6 * u64.abs().max().item(), (uf.double() - u64).abs().max().item()
+    assert torch.equal(azk.nnx_embed_fold(x.to(torch.bfloat16), ft, 15, 15, sched), rows)
+    cnt = torch.tensor([33], dtype=torch.int32, device="cuda")
+    r2 = azk.nnx_embed_fold(x.flip(0).contiguous(), ft, 15, 15, sched, count=cnt)
+    assert torch.equal(r2[:33], rows.flip(0)[:33])
+
+
+@pytest.mark.parametrize("tail", ["h16", "h16-conv", "f32"])
 def test_exact_evaluator_against_reference_known_answers(tail):
     """The whole fp32-accurate evaluator against the reference's seed-0 outputs (nn_small.npz full_*): north_star's float32 bar,
     logits 1e-5 / value 1e-6 (measured ~1e-6 / 1e-7) - the tolerance the torch float32 paths are held to.  Both tails: fp16 (hi, lo)
     planes on the fp16 matrix pipe (the default) and the float32-input MFMA."""
     z = load_golden("nn_small.npz")
     net = PolicyValueNet(CFG, seed=0, device="cuda", dtype=torch.float32, path="clsfold")
-    net.exact_tail = tail
+    net.exact_tail, net.use_fold_u = tail.split("-")[0], tail == "h16"      # h16: k_embed_fold<EX>; h16-conv / f32: k_embed_pool_x
     logits, v = net(torch.from_numpy(z["full_x"]).cuda())
     np.testing.assert_allclose(logits.cpu().numpy(), z["full_logits"], rtol=0, atol=1e-5)
     np.testing.assert_allclose(v.cpu().numpy().reshape(-1), z["full_value"].reshape(-1), rtol=0, atol=1e-6)
@@ -179,9 +211,9 @@ def test_search_policies_identical_under_the_exact_evaluator():
     assert len(positions) == 92
     noise = torch.from_numpy(np.random.RandomState(7).dirichlet([0.03] * 225, size=len(positions))).cuda()
     ref_pi, ref_q = search_pis(PolicyValueNet(CFG, seed=0, device="cuda", dtype=torch.float32, path="full"), "float32", positions, 800, noise)
-    for tail in ("h16", "f32"):
+    for tail in ("h16", "h16-conv", "f32"):
         net = PolicyValueNet(CFG, seed=0, device="cuda", dtype=torch.float32, path="clsfold")
-        net.exact_tail = tail
+        net.exact_tail, net.use_fold_u = tail.split("-")[0], tail == "h16"  # h16: k_embed_fold<EX>; h16-conv / f32: k_embed_pool_x
         pi, q = search_pis(net, "float32", positions, 800, noise)
         d = np.abs(pi - ref_pi)
         print(f"exact clsfold ({tail} tail) vs fp32 full: {(d.max(1) == 0).sum()}/{len(positions)} identical, max |dpi| {d.max():.2e}, max |dq| {np.abs(q - ref_q).max():.2e}")
