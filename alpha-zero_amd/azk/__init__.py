@@ -115,7 +115,7 @@ class GemmH(C.Structure):
 class AsyncConfig(C.Structure):
     """azk_async_config (include/azk.h)."""
     _fields_ = [("n_sims", C.c_int32), ("max_sims_per_launch", C.c_int32), ("sample_until_move", C.c_int32), ("dirichlet", C.c_int32),
-                ("recycle", C.c_int32), ("reserved0", C.c_int32), ("seed", C.c_uint64), ("first_global_game", C.c_int64), ("alpha", C.c_double),
+                ("recycle", C.c_int32), ("young_launch_us", C.c_int32), ("seed", C.c_uint64), ("first_global_game", C.c_int64), ("alpha", C.c_double),
                 ("stats_dev", C.c_void_p), ("record_capacity", C.c_int64), ("rec_meta_dev", C.c_void_p), ("rec_q_dev", C.c_void_p),
                 ("rec_pi_dev", C.c_void_p)]
 
@@ -449,7 +449,8 @@ class Engine:
         return launches
 
     # ---- asynchronous self-play (azk_async_*) -----------------------------------------------------
-    def async_begin(self, n_sims, per_launch, sample_until, seed, first_global_game, alpha=0.03, dirichlet=True, recycle=True, record_capacity=0):
+    def async_begin(self, n_sims, per_launch, sample_until, seed, first_global_game, alpha=0.03, dirichlet=True, recycle=True, record_capacity=0,
+                    young_launch_us=0):
         """Every game starts its first search; from now on azk_async_step moves each game as soon as its own search is done.
         Returns (stats int64 [16] CUDA, records dict or None) - caller-visible tensors the engine writes (include/azk.h)."""
         torch = self.torch
@@ -464,6 +465,7 @@ class Engine:
         c.n_sims, c.max_sims_per_launch, c.sample_until_move = int(n_sims), int(per_launch), int(min(sample_until, 1 << 30))
         c.dirichlet, c.recycle, c.seed, c.first_global_game, c.alpha = int(bool(dirichlet)), int(bool(recycle)), int(seed), int(first_global_game), float(alpha)
         c.stats_dev, c.record_capacity = self.async_stats.data_ptr(), int(record_capacity)
+        c.young_launch_us = int(young_launch_us)      # > 0: another simulation inside a launch only while the launch is younger than this
         if rec is not None:
             c.rec_meta_dev, c.rec_q_dev, c.rec_pi_dev = rec["meta"].data_ptr(), rec["q"].data_ptr(), rec["pi"].data_ptr()
         self._chk(self.L.azk_async_begin(self.h, C.byref(c), _stream()))

@@ -66,7 +66,8 @@ struct Dev {               // device view of the engine, passed to kernels by va
     double *traj_pi;       // [G][state_dim][A] visit distribution recorded at each ply
     long long *emit_base;  // [G] first tuple index (64-bit: the stream never wraps) of a game being emitted, -1 = not emitting
     int *sims_done;        // [G] simulations of the current search already run (budget stepping, azk_begin_search_budget)
-    int *budget;           // [2] simulations per search, most simulations per game and launch
+    int *budget;           // [4] simulations per search, most simulations per game and launch, launch age (wall-clock ticks) up to which a
+                           //     game may start another simulation (0: no limit), reserved
     long long *counters;   // [CNT_N][G]
     int *err;              // sticky error word
     int ablate;            // debug only (AZK_TREE_ABLATE): timing experiments that break parity on purpose
@@ -181,6 +182,13 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev dd, const float *__restri
     long long t0 = stamp ? clock64() : 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
     int done_sims = MULTI ? d.sims_done[g] : 0;
     const int sim_target = MULTI ? d.budget[0] : 0, max_iter = MULTI ? d.budget[1] : 1;
+    // a launch lasts as long as its slowest wave: a game whose simulation needed no evaluator starts another one only while the launch is
+    // YOUNG (budget[2] ticks of the constant-rate clock; scalar, so the decision is wave-uniform) - a cheap simulation (terminal leaf) then
+    // makes room for a second one, an expensive one does not push the wave past the launch's slowest.  Scheduling only: a game's
+    // simulations stay in order, the trees do not change.
+    const int young = MULTI ? d.budget[2] : 0;
+    const long long t_launch = MULTI && young > 0 ? (long long)wall_clock64() : 0;
+    auto still_young = [&]() { return young <= 0 || (long long)wall_clock64() - t_launch < (long long)young; };
     for (int it = 0; it < max_iter; it++) {
     // MULTI: the lane index is made opaque per iteration - left alone, the compiler hoists every lane-dependent address of the loop
     // body (the ~40 per-lane loads of a simulation) out of the loop and keeps them live across it: 294 VGPRs, one wave per SIMD,
@@ -586,7 +594,7 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev dd, const float *__restri
                 count_add(d, CNT_TERMINAL, g, 1);
                 count_add(d, CNT_TRACE, g, depth + 1);
             }
-            if (MULTI) continue;                                      // no evaluation needed: the next simulation starts at once
+            if (MULTI && (vl || still_young())) continue;             // no evaluation needed: the next simulation starts at once
             break;
         }
         if (stamp) t3 = clock64();
@@ -663,7 +671,7 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev dd, const float *__restri
                 if (!(ablate & 64) && tend - t0 > q[7]) q[7] = tend - t0;   // slowest simulation of this game
             }
         }
-        if (MULTI && (cached || vl)) continue;                        // served by the cache: expand it and go on, in this launch (vl: next slot)
+        if (MULTI && (vl || (cached && still_young()))) continue;     // served by the cache: expand it and go on, in this launch (vl: next slot)
     }
     if (vl) continue;
     break;
@@ -1452,7 +1460,8 @@ struct azk_engine {
     double *lntab = nullptr;             // [lntab_n] math.log(N), from the host libm (the reference's math.log)
     int lntab_n = 0;
     bool multi = false;                  // budget stepping (azk_begin_search_budget): the MULTI instantiation of k_tree
-    int budget_host[2] = {0, 1};
+    int budget_host[4] = {0, 1, 0, 0};
+    int ticks_per_us = 100;              // constant-rate clock of wall_clock64()
     AsyncDev ad;                         // asynchronous self-play (azk_async_begin); ad.slot_moves == nullptr: not set up
     bool async_on = false;
     int async_recycle = 1;
@@ -1503,6 +1512,7 @@ int32_t azk_create(const azk_config *cfg, azk_engine **out) {
         return fail(AZK_ERR_HIP, "no HIP device visible: libazk needs an MI355X (there is no CPU fallback)");
     if (cfg->device < 0 || cfg->device >= ndev) return fail(AZK_ERR_ARG, "bad device ordinal");
     if (hipSetDevice(cfg->device) != hipSuccess) return fail(AZK_ERR_HIP, "hipSetDevice failed");
+    { int khz = 0; if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, cfg->device) == hipSuccess && khz >= 1000) e->ticks_per_us = khz / 1000; }
     const GameDesc &g = d.g;
     const int maxch = g.kind == AZK_CONNECT4 ? g.cols : g.rc;
     long long cap = cfg->arena_nodes > 0 ? cfg->arena_nodes : 1 + (long long)cfg->max_sims * maxch;
@@ -1523,7 +1533,7 @@ int32_t azk_create(const azk_config *cfg, azk_engine **out) {
     DA(d.leaf_node, GV); DA(d.leaf_depth, GV); DA(d.leaf_nmoves, GV); DA(d.leaf_slot, GV); DA(d.to_move_v, GV);
     DA(d.path, GV * d.path_cap); DA(d.leaf_cells, GV * d.rc_pad); DA(d.leaf_moves, GV * g.rc);
     DA(d.leaf_flag, ((GV + 511) / 512) * 512 + 512);
-    DA(d.counters, (size_t)CNT_N * G); DA(d.err, 1); DA(d.dbg, G * 8); DA(d.emit_base, G); DA(d.sims_done, G); DA(d.budget, 2);
+    DA(d.counters, (size_t)CNT_N * G); DA(d.err, 1); DA(d.dbg, G * 8); DA(d.emit_base, G); DA(d.sims_done, G); DA(d.budget, 4);
     d.cache_entries = cfg->cache_entries;
     d.key_words = 2 * ((g.rc + 64) / 64);                         // one spare bit (63 of the last own-plane word) for the side to move
     d.cache_shared = (d.cache_entries && cfg->cache_shared) ? 1 : 0;
@@ -1629,7 +1639,7 @@ int32_t azk_begin_search_budget(azk_engine *e, const double *noise_dev, int32_t 
     e->multi = true;
     if (e->budget_host[0] != n_sims || e->budget_host[1] != (e->d.K > 1 ? e->d.K : max_sims_per_launch)) {
         // the budget lives in device memory so that a captured step graph keeps working when it changes
-        e->budget_host[0] = n_sims; e->budget_host[1] = max_sims_per_launch;
+        e->budget_host[0] = n_sims; e->budget_host[1] = max_sims_per_launch; e->budget_host[2] = 0;
         if (e->d.K > 1) e->budget_host[1] = e->d.K;               // virtual-loss mode: one iteration per slot
         HIPCHK(e, hipMemcpyAsync(e->d.budget, e->budget_host, sizeof e->budget_host, hipMemcpyHostToDevice, (hipStream_t)stream));
         HIPCHK(e, hipStreamSynchronize((hipStream_t)stream));
@@ -1664,6 +1674,7 @@ int32_t azk_async_begin(azk_engine *e, const azk_async_config *c, void *stream) 
     HIPCHK(e, hipMemsetAsync(a.stats, 0, sizeof(long long) * 16, st));
     // the simulation budget lives in device memory (a captured step graph keeps working when it changes)
     e->budget_host[0] = c->n_sims; e->budget_host[1] = c->max_sims_per_launch;
+    e->budget_host[2] = c->young_launch_us > 0 ? c->young_launch_us * e->ticks_per_us : 0;
     HIPCHK(e, hipMemcpyAsync(d.budget, e->budget_host, sizeof e->budget_host, hipMemcpyHostToDevice, st));
     HIPCHK(e, hipStreamSynchronize(st));
     d.noise = a.dirichlet ? a.noise : nullptr;

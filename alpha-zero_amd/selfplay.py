@@ -479,7 +479,7 @@ class AsyncSelfPlayRunner:
 
     def __init__(self, game, evaluator, n_games, n_sims, size=None, seed=0, first_global_game=0, dirichlet=True, alpha=0.03, device=0,
                  leaf_dtype="float32", recycle=True, on_records=None, kernel_timer=None, replay=None, cache_entries=0, cache_shared=False,
-                 per_launch=2, steps_per_graph=32, record_capacity=None, use_graph=True):
+                 per_launch=2, steps_per_graph=32, record_capacity=None, use_graph=True, young_launch_us=0):
         import torch
         self.torch, self.replay, self.evaluator = torch, replay, evaluator
         self.eng = Engine(game, n_games, n_sims, size=size, device=device, leaf_dtype=leaf_dtype, cache_entries=cache_entries, cache_shared=cache_shared)
@@ -492,7 +492,8 @@ class AsyncSelfPlayRunner:
         self.leaf_source_ok = True
         e.reset_games()
         cap = (4 * n_games if record_capacity is None else record_capacity) if (on_records is not None or record_capacity) else 0
-        self.stats, self.records = e.async_begin(n_sims, self.per_launch, SAMPLE_UNTIL[game], seed, first_global_game, alpha, dirichlet, recycle, cap)
+        self.stats, self.records = e.async_begin(n_sims, self.per_launch, SAMPLE_UNTIL[game], seed, first_global_game, alpha, dirichlet, recycle, cap,
+                                                 young_launch_us=young_launch_us)
         self.rec_cap, self.rec_read, self.copy_stream = cap, 0, None
         self.h_stats = [torch.zeros(16, dtype=torch.int64, pin_memory=True) for _ in range(2)]
         self.events = [None, None]

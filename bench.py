@@ -224,6 +224,7 @@ def main():
                     help="1: asynchronous per-game moves (a game moves as soon as ITS search is done: azk_async_*) with budget stepping - the same "
                          "trees, moves and games as lock-step (tests/test_gpu_async.py); a step is then G moves of the batch in total")
     ap.add_argument("--per-launch", type=int, default=2, help="with --async-moves: most simulations a game runs inside one tree launch")
+    ap.add_argument("--young-us", type=int, default=0, help="with --async-moves: a game starts another simulation inside a launch only while the launch is younger than this many microseconds (0: no limit)")
     ap.add_argument("--virtual-loss", type=int, default=1, metavar="K",
                     help="OPT-IN, NOT the headline: K > 1 leaves in flight per game with a virtual loss on their paths (north_star's 'virtual-loss "
                          "expansion').  Changes search results (the reference's search is sequential), so the line is reported under its own metric key")
@@ -307,7 +308,8 @@ def main():
                                          first_global_game=shard_range(args.games, rank)[0], device=local_rank,
                                          leaf_dtype="bfloat16" if args.nn_dtype == "bf16" else "float32", recycle=True, kernel_timer=kt,
                                          cache_entries=args.cache_entries, cache_shared=args.cache == "shared", replay=replay,
-                                         per_launch=args.per_launch, steps_per_graph=args.steps_per_graph, use_graph=not args.no_graph)
+                                         per_launch=args.per_launch, steps_per_graph=args.steps_per_graph, use_graph=not args.no_graph,
+                                         young_launch_us=args.young_us)
         else:
             runner = SelfPlayRunner("gomoku", net, args.games, args.sims, size=args.size, seed=args.seed,
                                     first_global_game=shard_range(args.games, rank)[0], device=local_rank,
@@ -539,7 +541,7 @@ def main():
             "nn_tflops_algorithmic": nn_flop_alg / dt_max / 1e12, "nn_tflops_issued": nn_flop_issued / dt_max / 1e12,
             "nn_flops_per_board": flops, "nn_boards_evaluated": evals,
             "moves": ("asynchronous: every game moves as soon as its own search is complete (k_move_async), at most "
-                      f"{args.per_launch} simulation(s) per game and tree launch; a step = {args.games} moves of the batch in total") if args.async_moves
+                      f"{args.per_launch} simulation(s) per game and tree launch" + (f" while the launch is younger than {args.young_us} us" if args.young_us else "") + f"; a step = {args.games} moves of the batch in total") if args.async_moves
                      else "lock-step: all games of the batch move together",
             "stepping": "eager+sync" if args.no_graph else f"hipGraph replay, {runner.steps_per_graph} simulation step(s) per graph, {runner.n_split} game group(s) (per simulation: k_tree, the network kernels taking the pending leaves straight from the engine, no host sync)",
             "value_definition": value_src, "games_per_sec_renewal_estimate": est_games_per_s,

@@ -134,7 +134,9 @@ int32_t azk_search_unfinished(azk_engine *e, int32_t *count_host, void *stream);
  *   record ring (optional, record_capacity entries; entry r % capacity): rec_meta int32 [cap][4] = slot, the slot's move counter,
  *              chosen cell, winner (-2 running, -1 draw, 0 / 1); rec_q float64 [cap] = root.value / root.visit; rec_pi float64 [cap][A] */
 typedef struct azk_async_config {
-    int32_t n_sims, max_sims_per_launch, sample_until_move, dirichlet, recycle, reserved0;
+    int32_t n_sims, max_sims_per_launch, sample_until_move, dirichlet, recycle;
+    int32_t young_launch_us;   /* > 0: a game starts another simulation inside a launch only while the launch is younger than this
+                                * (a launch lasts as long as its slowest wave); 0: up to max_sims_per_launch whatever the time */
     uint64_t seed;
     int64_t first_global_game;
     double alpha;

@@ -72,11 +72,14 @@ def test_async_graph_runner_real_network():
     net = PolicyValueNet(cfg, seed=6, device="cuda", dtype=torch.bfloat16, path="clsfold")
     G, sims, moves = 96, 64, 5
     want, _ = lockstep_records("gomoku", net, G, sims, moves, 15, 9, "bfloat16", use_graph=True, cache_entries=256, cache_shared=True, steps_per_graph=8)
-    for per_launch in (1, 2, 4):
-        got, r = async_records("gomoku", net, G, sims, moves, 15, 9, "bfloat16", cache_entries=256, cache_shared=True, per_launch=per_launch, steps_per_graph=8)
+    # (young: a game starts another simulation inside a launch only while the launch is younger than that many microseconds -
+    #  scheduling by the clock, the games must not notice)
+    for per_launch, young in ((1, 0), (2, 0), (4, 0), (4, 6), (3, 1)):
+        got, r = async_records("gomoku", net, G, sims, moves, 15, 9, "bfloat16", cache_entries=256, cache_shared=True, per_launch=per_launch, steps_per_graph=8,
+                               young_launch_us=young)
         for g in range(G):
             for mv in range(moves):
-                assert got[(g, mv)] == want[(g, mv)], (per_launch, g, mv)
+                assert got[(g, mv)] == want[(g, mv)], (per_launch, young, g, mv)
         assert r.counters()["sims"] >= G * sims * moves
 
 
