@@ -173,6 +173,9 @@ def concurrent_streams(torch, device, n, spin_cycles=600_000):
         if all(min(spins(st, c) for _ in range(2)) < 0.75 * serial for c in chosen):
             chosen.append(st)
     if len(chosen) < n:
+        if n == 2:
+            # a noisy probe (another tenant on the box): a normal- and a high-priority stream never share a queue
+            return [cand[0], cand[-1]]
         raise RuntimeError(f"only {len(chosen)} of {n} streams found that run concurrently on this device")
     return chosen
 
