@@ -32,7 +32,7 @@ SYMBOLS = [
     "azk_vanilla_set_rng", "azk_vanilla_get_rng", "azk_vanilla_search", "azk_nn_embed_pool",
     "azk_nn_gemm_rows", "azk_nn_layernorm_sum", "azk_nn_heads_finalize_sum", "azk_nn_ln_heads",
     "azk_leaf_source_of", "azk_nn_embed_pool_leaves", "azk_nn_embed_pool_compact", "azk_nn_embed_pool_compact_leaves",
-    "azk_nn_embed_fold", "azk_nn_embed_fold_leaves", "azk_nnx_embed_fold", "azk_nnx_embed_fold_leaves", "azk_nn_tail_fold12",
+    "azk_nn_embed_fold", "azk_nn_embed_fold_leaves", "azk_nnx_embed_fold", "azk_nnx_embed_fold_leaves",
     "azk_nn_tail_gemm", "azk_begin_search_budget", "azk_search_unfinished",
     "azk_nnx_embed_pool", "azk_nnx_embed_pool_leaves", "azk_nnx_gemm", "azk_nnx_gemm_h",
     "azk_async_begin", "azk_async_step", "azk_async_drain", "azk_async_set_budget",
@@ -71,12 +71,6 @@ class EmbedFoldConsts(C.Structure):
                 ("wconst_tok", C.c_void_p), ("l_all", C.c_void_p), ("score_ref", C.c_void_p), ("inv_scales", C.c_void_p),
                 ("num_heads", C.c_int32), ("ksize", C.c_int32), ("embed_dim", C.c_int32), ("ln_eps", C.c_float),
                 ("work_stats", C.c_void_p)]
-
-
-class TailFold12(C.Structure):
-    """azk_tail_fold12 (include/azk.h): the tail's first two links in one launch for azk_nn_embed_fold's rows."""
-    _fields_ = [("rows_bf16", C.c_void_p), ("lda", C.c_int32), ("w1_packed", C.c_void_p), ("wo_packed", C.c_void_p), ("bias", C.c_void_p),
-                ("out_bf16", C.c_void_p), ("ldo", C.c_int32), ("stats_out", C.c_void_p), ("n_valid", C.c_void_p), ("m", C.c_int32)]
 
 
 class TailGemm(C.Structure):
@@ -215,7 +209,6 @@ def lib():
     L.azk_nn_embed_fold_leaves.argtypes = [C.POINTER(LeafSource), C.POINTER(EmbedFoldConsts), vp, vp, vp]
     L.azk_nnx_embed_fold.argtypes = [vp, i32, C.POINTER(EmbedFoldConsts), vp, i32, i32, i32, i32, vp, vp, vp]
     L.azk_nnx_embed_fold_leaves.argtypes = [C.POINTER(LeafSource), C.POINTER(EmbedFoldConsts), vp, vp, vp]
-    L.azk_nn_tail_fold12.argtypes = [C.POINTER(TailFold12), vp]
     L.azk_begin_search_budget.argtypes = [vp, vp, i32, i32, vp]
     L.azk_search_unfinished.argtypes = [vp, vp, vp]
     L.azk_nn_tail_gemm.argtypes = [C.POINTER(TailGemm), vp]
@@ -980,24 +973,6 @@ def nnx_embed_fold_leaves(src, tables, sched, timers=None):
 
 
 TAIL_BF16, TAIL_GELU, TAIL_RESID, TAIL_HEADS = 0, 1, 2, 3
-
-
-def nn_tail_fold12(rows, w1_packed, wo_packed, bias, out, stats_out=None, count=None):
-    """azk_nn_tail_fold12: k_embed_fold's rows bf16 [m, 8 * EMBED_FOLD_ROW] -> x1 = (blockdiag_h(rows_h W1_h^T)) Wo^T + bias, bf16 [m, 512]
-    (+ row statistics [m, 8, 2]): the first two links of the tail chain in one launch, bit for bit."""
-    torch = _torch()
-    assert rows.dtype == torch.bfloat16 and rows.dim() == 2 and rows.stride(1) == 1 and rows.shape[1] == 8 * EMBED_FOLD_ROW
-    assert out.dtype == torch.bfloat16 and out.stride(1) == 1 and out.shape[1] == 512 and bias.dtype == torch.float32 and bias.numel() == 512
-    d = TailFold12()
-    d.rows_bf16, d.lda, d.w1_packed, d.wo_packed, d.bias = rows.data_ptr(), rows.stride(0), w1_packed.data_ptr(), wo_packed.data_ptr(), bias.data_ptr()
-    d.out_bf16, d.ldo, d.m = out.data_ptr(), out.stride(0), rows.shape[0]
-    if stats_out is not None:
-        assert stats_out.dtype == torch.float32 and tuple(stats_out.shape) == (rows.shape[0], 8, 2) and stats_out.is_contiguous()
-        d.stats_out = stats_out.data_ptr()
-    d.n_valid = count.data_ptr() if count is not None else None
-    rc = lib().azk_nn_tail_fold12(C.byref(d), _stream())
-    if rc != 0:
-        raise AzkError(f"azk_nn_tail_fold12 failed ({rc})")
 
 
 def nn_tail_gemm(a, w_packed, n_out, k, epilogue=TAIL_BF16, nbatch=1, a_batch_stride=0, bias=None, out=None, resid=None,

@@ -2961,164 +2961,6 @@ int launch_tail(TailArgs &a, hipStream_t st) {
 }
 }  // namespace
 
-// =====================================================================================================
-// k_tail_fold12: the tail's first two links in one launch, for k_embed_fold's rows (include/azk.h azk_nn_tail_fold12):
-//     u  = blockdiag_h(rows_h W1_h^T)         8 heads x [64 x 384]     (azk_nn_tail_gemm, k = 384, nbatch = 8)
-//     x1 = u Wo^T + bias1 (+ row statistics)   [512 x 512]              (azk_nn_tail_gemm, k = 512)
-// A workgroup of eight waves owns a tile of 16 RT rows.  Phase 1: wave h computes head h's 64 columns of u and leaves them in LDS
-// as bf16 (the rounding the two-launch chain has between its links); phase 2: wave g computes columns 64 g .. 64 g + 63 of x1 from
-// that tile.  One stream of weight fragments per wave - 12 k-steps of W1_h, then 16 of Wo, DEPTH k-steps in flight - so the second
-// link's weights are on their way before the first link's MFMAs start, and the launch has ONE memory round trip on its chain where
-// the two launches had two plus a kernel boundary.  Bit for bit the chain's x1: both links add their K range as four partial
-// accumulators in the order the split-K workgroups of k_tail_gemm do.
-// =====================================================================================================
-namespace {
-struct TailFoldArgs {
-    const unsigned short *A; int lda;            // rows bf16 [M][8 * 384]
-    const uint4 *W1;                             // 8 blocks of packed [64][384]
-    const uint4 *Wo;                             // packed [512][512]
-    const float *bias;                           // [512]
-    unsigned short *out; int ldo;                // x1 bf16 [M][512]
-    float *stats_out;                            // [M][8][2]
-    const int *count;
-    int M;
-};
-
-template <int RT>
-__global__ __launch_bounds__(512, 1) void k_tail_fold12(TailFoldArgs a) {
-    constexpr int USTR = 1040;                                    // LDS bytes per row of u: 512 bf16 + 16 (rows 260 words apart: no bank lines shared)
-    constexpr int K1S = 12, K2S = 16, NT = K1S + K2S, DEPTH = RT == 1 ? 8 : 5;  // k-steps of the two links; weight k-steps in flight
-    __shared__ __attribute__((aligned(16))) unsigned char ulds[16 * RT * USTR];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, l4 = lane >> 4;
-    asm volatile("" :: "s"(a.A), "s"(a.W1), "s"(a.Wo), "s"(a.bias), "s"(a.out), "s"(a.stats_out), "s"(a.lda), "s"(a.ldo), "s"(a.M));
-    const int nvalid = a.count ? min(a.M, *a.count) : a.M;
-    const int rtiles = (nvalid + 16 * RT - 1) / (16 * RT);
-    union BF { uint4 u; bf16x8 v; };
-    for (int item = blockIdx.x; item < rtiles; item += gridDim.x) {
-        if (item != (int)blockIdx.x) __syncthreads();            // every wave is done reading the previous tile of u
-        const int row0 = item * 16 * RT;
-        // (the lane index is made opaque per tile: left alone, the compiler hoists a 64-bit address per weight fragment out of this loop -
-        //  a hundred live registers, spilled)
-        int lv = lane;
-        asm volatile("" : "+v"(lv));
-        const uint4 *w1 = a.W1 + (size_t)wave * (K1S * 4 * 64) + lv, *w2 = a.Wo + (size_t)wave * (K2S * 4 * 64) + lv;
-        BF ring[DEPTH][4], af[RT][K1S];
-        auto wload = [&](int t) {                                 // weight k-step t of the wave's stream (t compile-time: the loops are unrolled)
-            const uint4 *p = t < K1S ? w1 + t * 4 * 64 : w2 + (t - K1S) * 4 * 64;
-#pragma unroll
-            for (int c = 0; c < 4; c++) ring[t % DEPTH][c].u = p[c * 64];
-        };
-#pragma unroll
-        for (int i = 0; i < RT; i++) {
-            const unsigned short *ap = a.A + (size_t)min(row0 + 16 * i + l15, a.M - 1) * a.lda + wave * 384 + 8 * l4;
-#pragma unroll
-            for (int s = 0; s < K1S; s++) af[i][s].u = *(const uint4 *)(ap + 32 * s);
-        }
-#pragma unroll
-        for (int t = 0; t < DEPTH; t++) wload(t);
-        const f32x4 bv = *(const f32x4 *)(a.bias + 64 * wave + 4 * l15);
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- phase 1: head `wave`: u[:, 64 wave .. +63] over K = 384 as four partial sums of three k-steps ----
-        f32x4 acc[RT][4];
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            f32x4 pa[RT][4];
-#pragma unroll
-            for (int i = 0; i < RT; i++)
-#pragma unroll
-                for (int c = 0; c < 4; c++) pa[i][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int s = 0; s < 3; s++) {
-                const int t = 3 * q + s;
-#pragma unroll
-                for (int i = 0; i < RT; i++)
-#pragma unroll
-                    for (int c = 0; c < 4; c++) pa[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][t].v, ring[t % DEPTH][c].v, pa[i][c], 0, 0, 0);
-                if (t + DEPTH < NT) { wload(t + DEPTH); __builtin_amdgcn_sched_barrier(0); }
-            }
-#pragma unroll
-            for (int i = 0; i < RT; i++)
-#pragma unroll
-                for (int c = 0; c < 4; c++) acc[i][c] = q == 0 ? pa[i][c] : acc[i][c] + pa[i][c];
-        }
-#pragma unroll
-        for (int i = 0; i < RT; i++)
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const f32x4 v = {acc[i][0][j], acc[i][1][j], acc[i][2][j], acc[i][3][j]};
-                union { bf16x4 b4; uint2 u; } ob;
-                ob.b4 = __builtin_convertvector(v, bf16x4);
-                *(uint2 *)(ulds + (16 * i + 4 * l4 + j) * USTR + (64 * wave + 4 * l15) * 2) = ob.u;
-            }
-        __syncthreads();
-        // ---- phase 2: column group `wave` of x1 over K = 512 as four partial sums of four k-steps ----
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            f32x4 pa[RT][4];
-            BF au[RT][4];
-#pragma unroll
-            for (int i = 0; i < RT; i++)
-#pragma unroll
-                for (int c = 0; c < 4; c++) pa[i][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-            __builtin_amdgcn_sched_barrier(0);                    // (one quarter's fragments of u at a time: left alone, all sixteen reads are hoisted)
-#pragma unroll
-            for (int i = 0; i < RT; i++)
-#pragma unroll
-                for (int s = 0; s < 4; s++) au[i][s].u = *(const uint4 *)(ulds + (16 * i + l15) * USTR + (32 * (4 * q + s) + 8 * l4) * 2);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int s = 0; s < 4; s++) {
-                const int t = K1S + 4 * q + s;
-#pragma unroll
-                for (int i = 0; i < RT; i++)
-#pragma unroll
-                    for (int c = 0; c < 4; c++) pa[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(au[i][s].v, ring[t % DEPTH][c].v, pa[i][c], 0, 0, 0);
-                if (t + DEPTH < NT) { wload(t + DEPTH); __builtin_amdgcn_sched_barrier(0); }
-            }
-#pragma unroll
-            for (int i = 0; i < RT; i++)
-#pragma unroll
-                for (int c = 0; c < 4; c++) acc[i][c] = q == 0 ? pa[i][c] : acc[i][c] + pa[i][c];
-        }
-        // ---- epilogue (k_tail_gemm's: bias, bf16, row statistics of the rounded values over this wave's 64 columns) ----
-        uint2 o[RT][4];
-        f32x2 ps[RT][4];
-#pragma unroll
-        for (int i = 0; i < RT; i++)
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const f32x4 v = {acc[i][0][j] + bv[0], acc[i][1][j] + bv[1], acc[i][2][j] + bv[2], acc[i][3][j] + bv[3]};
-                union { bf16x4 b4; uint2 u; } ob;
-                ob.b4 = __builtin_convertvector(v, bf16x4);
-                o[i][j] = ob.u;
-                const f32x4 vr = __builtin_convertvector(ob.b4, f32x4);
-                ps[i][j] = f32x2{row16_sum((vr[0] + vr[1]) + (vr[2] + vr[3])), row16_sum((vr[0] * vr[0] + vr[1] * vr[1]) + (vr[2] * vr[2] + vr[3] * vr[3]))};
-            }
-#pragma unroll
-        for (int i = 0; i < RT; i++)
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int row = row0 + 16 * i + 4 * l4 + j;
-                if (row < nvalid) *(uint2 *)(a.out + (size_t)row * a.ldo + 64 * wave + 4 * l15) = o[i][j];
-                if (a.stats_out && l15 == 0 && row < nvalid) *(f32x2 *)(a.stats_out + ((size_t)row * 8 + wave) * 2) = ps[i][j];
-            }
-    }
-}
-}  // namespace
-
-extern "C" int32_t azk_nn_tail_fold12(const azk_tail_fold12 *t, void *stream) {
-    if (!t || !t->rows_bf16 || !t->w1_packed || !t->wo_packed || !t->bias || !t->out_bf16 || t->m < 0) return AZK_ERR_ARG;
-    if (t->lda < 8 * AZK_EMBED_FOLD_ROW || (t->lda & 7) || t->ldo < 512 || (t->ldo & 3)) return AZK_ERR_ARG;
-    if (t->m == 0) return AZK_OK;
-    TailFoldArgs a;
-    a.A = (const unsigned short *)t->rows_bf16; a.lda = t->lda; a.W1 = (const uint4 *)t->w1_packed; a.Wo = (const uint4 *)t->wo_packed;
-    a.bias = t->bias; a.out = (unsigned short *)t->out_bf16; a.ldo = t->ldo; a.stats_out = t->stats_out; a.count = t->n_valid; a.M = t->m;
-    hipStream_t st = (hipStream_t)stream;
-    if (t->m <= 4096) k_tail_fold12<1><<<(unsigned)((t->m + 15) / 16), 512, 0, st>>>(a);     // one 16-row tile per workgroup: every tile on its own CU
-    else k_tail_fold12<2><<<(unsigned)((t->m + 31) / 32), 512, 0, st>>>(a);
-    return hipGetLastError() == hipSuccess ? AZK_OK : AZK_ERR_HIP;
-}
-
 extern "C" int32_t azk_nn_tail_gemm(const azk_tail_gemm *t, void *stream) {
     if (!t || !t->a_bf16 || !t->w_packed || t->m < 0 || t->n_out < 64 || (t->n_out & 63) || t->nbatch < 1) return AZK_ERR_ARG;
     if ((t->k != 512 && t->k != 2048 && t->k != 384) || t->lda < t->k || (t->lda & 7) || (t->a_batch_stride & 7)) return AZK_ERR_ARG;

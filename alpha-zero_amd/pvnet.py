@@ -155,7 +155,6 @@ class PolicyValueNet:
         self.use_compact = True
         self._foldu = None              # azk.EmbedFoldTables when the patch-pooling kernel (k_embed_fold) covers this configuration
         self.use_fold_u = True
-        self.use_tail_fold12 = True     # the tail's first two links in one launch when they take k_embed_fold's rows (k_tail_fold12)
         self._scheds = {}               # work-queue words of the compacting kernel, one buffer per board source (= per stepping stream)
         self.kernel_timers = None   # optional timers with start()/stop() (HIP events): (embed+pool, tail) on the fused path, (embed, pool, tail) otherwise
         self.live_count = None      # optional int32 CUDA tensor: number of valid rows at the head of the batch (graph stepping)
@@ -747,16 +746,12 @@ class PolicyValueNet:
                       st2=torch.empty((rows, D // 64, 2), dtype=torch.float32, device=dev))
             self._tail_ws[key] = ws
         ws = {k_: (v[:n] if k_ != "rows" else v) for k_, v in ws.items()}
-        if z.shape[-1] == azk.EMBED_FOLD_ROW and H == 8 and self.use_tail_fold12:
-            # k_embed_fold's rows through the value projection AND the output projection in one launch (k_tail_fold12: bit for bit the two below)
-            self._launch(azk.nn_tail_fold12, z.view(n, H * azk.EMBED_FOLD_ROW), self._foldu.weight, f["WoP"], f["bias1_f"], ws["x1"], stats_out=ws["st1"], count=cnt)
+        if z.shape[-1] == azk.EMBED_FOLD_ROW:      # k_embed_fold's rows against [D_t; U_all; M_h]: the value-projected row directly
+            kf = azk.EMBED_FOLD_ROW
+            self._launch(azk.nn_tail_gemm, z.view(n, H * kf), self._foldu.weight, D // H, kf, azk.TAIL_BF16, nbatch=H, a_batch_stride=kf, out=ws["u"], count=cnt)
         else:
-            if z.shape[-1] == azk.EMBED_FOLD_ROW:      # k_embed_fold's rows against [D_t; U_all; M_h]: the value-projected row directly
-                kf = azk.EMBED_FOLD_ROW
-                self._launch(azk.nn_tail_gemm, z.view(n, H * kf), self._foldu.weight, D // H, kf, azk.TAIL_BF16, nbatch=H, a_batch_stride=kf, out=ws["u"], count=cnt)
-            else:
-                self._launch(azk.nn_tail_gemm, z.view(n, H * D), f["WvHP"], D // H, D, azk.TAIL_BF16, nbatch=H, a_batch_stride=D, out=ws["u"], count=cnt)
-            self._launch(azk.nn_tail_gemm, ws["u"], f["WoP"], D, D, azk.TAIL_BF16, bias=f["bias1_f"], out=ws["x1"], stats_out=ws["st1"], count=cnt)
+            self._launch(azk.nn_tail_gemm, z.view(n, H * D), f["WvHP"], D // H, D, azk.TAIL_BF16, nbatch=H, a_batch_stride=D, out=ws["u"], count=cnt)
+        self._launch(azk.nn_tail_gemm, ws["u"], f["WoP"], D, D, azk.TAIL_BF16, bias=f["bias1_f"], out=ws["x1"], stats_out=ws["st1"], count=cnt)
         self._launch(azk.nn_tail_gemm, ws["x1"], f["W0GP"], 4 * D, D, azk.TAIL_GELU, bias=f["b0G_f"], out=ws["hh"], a_stats=ws["st1"], count=cnt)
         self._launch(azk.nn_tail_gemm, ws["hh"], f["W3P"], D, 4 * D, azk.TAIL_RESID, bias=f["b3_f"], resid=ws["x1"], out=ws["x2"], stats_out=ws["st2"], count=cnt)
         if self.out_buffers is not None:

@@ -423,20 +423,6 @@ typedef struct azk_tail_gemm {
     float *logits_out, *values_out; int32_t action_dim;
 } azk_tail_gemm;
 int32_t azk_nn_tail_gemm(const azk_tail_gemm *desc, void *stream);
-/* azk_nn_tail_fold12 - the tail's first two links in ONE launch for azk_nn_embed_fold's rows (8 heads, embed_dim 512):
- *     u = blockdiag_h(rows_h W1_h^T)  (w1_packed: 8 blocks [64][AZK_EMBED_FOLD_ROW] in azk_nn_tail_gemm's packing = azk.EmbedFoldTables.weight)
- *     x1 = u Wo^T + bias (wo_packed: [512][512]); out_bf16 [m][ldo]; stats_out (optional) [m][8][2] as azk_nn_tail_gemm's.
- * Results are bit for bit those of the two azk_nn_tail_gemm launches it replaces (k = 384, nbatch = 8; then k = 512). */
-typedef struct azk_tail_fold12 {
-    const void *rows_bf16; int32_t lda;
-    const void *w1_packed, *wo_packed;
-    const float *bias;
-    void *out_bf16; int32_t ldo;
-    float *stats_out;
-    const int32_t *n_valid;
-    int32_t m;
-} azk_tail_fold12;
-int32_t azk_nn_tail_fold12(const azk_tail_fold12 *desc, void *stream);
 
 /* azk_nn_ln_heads: final LayerNorm + merged policy/value head + finalize in one launch (nn.py:78-83 for the cls row):
  *   logits[n][A] = LN(x) Wh^T + bh (float32), values[n] = tanh(column A).  w_packed_dev: the merged head weight

@@ -123,32 +123,3 @@ def test_evaluator_on_the_fold_kernel_vs_float32_forward():
     e1, e0 = (l1.float() - lr).abs().max().item(), (l0.float() - lr).abs().max().item()
     assert e1 < 2e-2 and (v1.float().reshape(-1) - vr.reshape(-1)).abs().max().item() < 5e-3, (e1, e0)
     assert e1 <= 1.5 * e0 + 1e-3, (e1, e0)
-
-
-def test_tail_fold12_is_the_two_links_bit_for_bit():
-    """k_tail_fold12 (the tail's first two links in one launch, u handed over through LDS as bf16) against the two azk_nn_tail_gemm
-    launches it replaces: x1 and its row statistics bit for bit (both add their K ranges as the split-K workgroups do), rows past the
-    device-side count untouched; and the evaluator's outputs do not change a bit with it."""
-    import azk
-    cfg, net = _net()
-    H, ROW, f = cfg.num_heads, azk.EMBED_FOLD_ROW, net._fold
-    for n, live in ((700, None), (700, 301), (37, None), (2048, 914)):
-        x = _stone_boards(max(n, 8), 11)[:n].cuda().to(torch.bfloat16).contiguous()
-        rows = azk.nn_embed_fold(x, net._foldu, 15, 15, azk.new_sched("cuda")).view(n, H * ROW)
-        cnt = None if live is None else torch.tensor([live], dtype=torch.int32, device="cuda")
-        u = torch.zeros(n, 512, dtype=torch.bfloat16, device="cuda")
-        x1a, x1b = torch.full((n, 512), 7.0, dtype=torch.bfloat16, device="cuda"), torch.full((n, 512), 7.0, dtype=torch.bfloat16, device="cuda")
-        sta, stb = torch.full((n, 8, 2), 7.0, device="cuda"), torch.full((n, 8, 2), 7.0, device="cuda")
-        azk.nn_tail_gemm(rows, net._foldu.weight, 64, ROW, azk.TAIL_BF16, nbatch=H, a_batch_stride=ROW, out=u, count=cnt)
-        azk.nn_tail_gemm(u, f["WoP"], 512, 512, azk.TAIL_BF16, bias=f["bias1_f"], out=x1a, stats_out=sta, count=cnt)
-        azk.nn_tail_fold12(rows, net._foldu.weight, f["WoP"], f["bias1_f"], x1b, stats_out=stb, count=cnt)
-        torch.cuda.synchronize()
-        assert torch.equal(x1a, x1b) and torch.equal(sta, stb), (n, live, (x1a.float() - x1b.float()).abs().max().item())
-        if live is not None:
-            assert bool((x1b[live:] == 7.0).all()) and bool((stb[live:] == 7.0).all())
-    xb = _stone_boards(300, 3).cuda().to(torch.bfloat16)
-    la, va = net(xb)
-    net.use_tail_fold12 = False
-    lb, vb = net(xb)
-    net.use_tail_fold12 = True
-    assert torch.equal(la, lb) and torch.equal(va, vb)
