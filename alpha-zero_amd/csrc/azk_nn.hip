@@ -2022,10 +2022,10 @@ __global__ __launch_bounds__(256, 2) void k_embed_fold(EmbedFoldArgs a) {
             float cross[4], scn[4], wcn[4], ntv[4], rcv[4];
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                const unsigned nib = ((l15 < 8 ? prx[r] : pry[r]) >> (4 * (l15 & 7))) & 0xfu;           // patch bits 4 l15 .. 4 l15 + 3
+                const unsigned nib = (l15 < 8 ? prx[r] : pry[r]) >> (4 * (l15 & 7));                   // patch bits 4 l15 .. 4 l15 + 3
                 float c = 0.f;
 #pragma unroll
-                for (int cidx = 0; cidx < 4; cidx++) c += (nib >> cidx) & 1u ? utn[r][cidx] : 0.f;
+                for (int cidx = 0; cidx < 4; cidx++) c = fmaf((float)((nib >> cidx) & 1u), utn[r][cidx], c);
                 cross[r] = c; scn[r] = scnn[r]; wcn[r] = wcnn[r]; ntv[r] = ntn[r]; rcv[r] = rcn[r];
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -2056,12 +2056,19 @@ __global__ __launch_bounds__(256, 2) void k_embed_fold(EmbedFoldArgs a) {
                     }
             }
             // ---- per token (row 4 l4 + r): variance from the quadratic form, scores, weights ----
+            // patch bit of token r at column 16 q + l15 as a float (0 / 1): multiplies the quadratic form's column and, as its upper half, IS the
+            // bf16 B operand of the pooled patch (one v_perm per pair of tokens instead of compare / select chains)
+            float bitf[4][4];
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) bitf[r][q] = (float)(((q < 2 ? prx[r] : pry[r]) >> (16 * (q & 1) + l15)) & 1u);
             float av[4];
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 float qd = 0.f;
 #pragma unroll
-                for (int q = 0; q < 4; q++) qd += ((q < 2 ? prx[r] : pry[r]) >> (16 * (q & 1) + l15)) & 1u ? Y[q][r] : 0.f;
+                for (int q = 0; q < 4; q++) qd = fmaf(bitf[r][q], Y[q][r], qd);
                 qd = fmaf(qd, ginv, cross[r]);
                 qd = row16_sum(qd);
                 const float e = fmaf(E[r], einv, scn[r]);                        // head lanes: the raw score
@@ -2080,8 +2087,7 @@ __global__ __launch_bounds__(256, 2) void k_embed_fold(EmbedFoldArgs a) {
                 for (int r = 0; r < 4; r++)
 #pragma unroll
                     for (int q = 0; q < 4; q++) {
-                        const float bit = ((q < 2 ? prx[r] : pry[r]) >> (16 * (q & 1) + l15)) & 1u ? 1.0f : 0.0f;
-                        Pw[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r], bit, Pw[q], 0, 0, 0);
+                        Pw[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r], bitf[r][q], Pw[q], 0, 0, 0);
                     }
             } else {
                 // bf16: a as hi + remainder in the eight k-slots of the lane group (B: the patch bits twice)
@@ -2095,11 +2101,9 @@ __global__ __launch_bounds__(256, 2) void k_embed_fold(EmbedFoldArgs a) {
                 }
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
-                    unsigned bit[4];
-#pragma unroll
-                    for (int r = 0; r < 4; r++) bit[r] = ((q < 2 ? prx[r] : pry[r]) >> (16 * (q & 1) + l15)) & 1u;
-                    const unsigned b01 = (bit[0] ? 0x3F80u : 0u) | (bit[1] ? 0x3F800000u : 0u);
-                    const unsigned b23 = (bit[2] ? 0x3F80u : 0u) | (bit[3] ? 0x3F800000u : 0u);
+                    // (bf16 of a float is its upper half: 1.0f -> 0x3F80)
+                    const unsigned b01 = __builtin_amdgcn_perm(__float_as_uint(bitf[1][q]), __float_as_uint(bitf[0][q]), 0x07060302u);
+                    const unsigned b23 = __builtin_amdgcn_perm(__float_as_uint(bitf[3][q]), __float_as_uint(bitf[2][q]), 0x07060302u);
                     union { uint4 u; bf16x8 v; } pb;
                     pb.u = make_uint4(b01, b23, b01, b23);
                     Pw[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa.v, pb.v, Pw[q], 0, 0, 0);
