@@ -1889,9 +1889,6 @@ __global__ __launch_bounds__(256, 2) void k_embed_fold(EmbedFoldArgs a) {
         const int lane_b = tv & 63;
         const int tj = tv - 1, tr = tj / a.Cc, tc = tj - tr * a.Cc;
         const bool tlive = tv >= 1 && tv < T;
-        unsigned colmask = 0;
-#pragma unroll
-        for (int kx = 0; kx < ksz; kx++) { const int cc = tc + kx - pad; if (cc >= 0 && cc < a.Cc) colmask |= 1u << kx; }
         int player = 0;
         if (SRC && tid == 0) a.src.leaf_slot[game] = board;       // the slot the next expansion reads this game's outputs from
         unsigned wbits = 0;                             // lane i holds bits [32 (i-1), 32 i) of the board bit string (lane 0: zeros)
@@ -1945,26 +1942,29 @@ __global__ __launch_bounds__(256, 2) void k_embed_fold(EmbedFoldArgs a) {
         }
         AZK_FSTAMP(1);                                            // board loaded, bit string built
         // ---- patch bits of this thread's token; dirty = some stone in the patch ----
+        // Row words first: lane L < NC R holds plane L / R, row L % R of the board with two zero bits on either side (two cross-lane reads
+        // of the bit string + a funnel shift, once); a token then takes its KSZ bits of each of its NC KSZ rows with ONE cross-lane read
+        // and a shift - no column mask, the margins are zero.
         unsigned long long plo = 0;
         {
-            unsigned lo[NC * KSZ], hi[NC * KSZ];
+            const int chL = lane_b / a.R, rL = lane_b - chL * a.R;
+            const int offL = 32 + chL * RC + rL * a.Cc - 2;
+            const unsigned loL = __shfl(wbits, offL >> 5), hiL = __shfl(wbits, (offL >> 5) + 1);
+            const unsigned roww = lane_b < NC * a.R ? (__funnelshift_r(loL, hiL, offL & 31) & (((1u << a.Cc) - 1u) << 2)) : 0u;
+            unsigned rw[NC * KSZ];
 #pragma unroll
             for (int ch = 0; ch < NC; ch++)
 #pragma unroll
                 for (int ky = 0; ky < KSZ; ky++) {
                     const int rr = tr + ky - pad;
-                    int off = 32 + ch * RC + (rr < 0 ? 0 : (rr >= a.R ? a.R - 1 : rr)) * a.Cc + (tc - pad);
-                    if (!tlive) off = 32;
-                    lo[ch * KSZ + ky] = __shfl(wbits, off >> 5); hi[ch * KSZ + ky] = __shfl(wbits, (off >> 5) + 1);
+                    rw[ch * KSZ + ky] = __shfl(roww, ch * a.R + (rr < 0 ? 0 : (rr >= a.R ? a.R - 1 : rr)));
                 }
 #pragma unroll
             for (int ch = 0; ch < NC; ch++)
 #pragma unroll
                 for (int ky = 0; ky < KSZ; ky++) {
                     const int rr = tr + ky - pad;
-                    int off = 32 + ch * RC + (rr < 0 ? 0 : (rr >= a.R ? a.R - 1 : rr)) * a.Cc + (tc - pad);
-                    if (!tlive) off = 32;
-                    unsigned bits = __funnelshift_r(lo[ch * KSZ + ky], hi[ch * KSZ + ky], off & 31) & colmask;
+                    unsigned bits = (rw[ch * KSZ + ky] >> (tc + 2 - pad)) & ((1u << KSZ) - 1u);
                     if (!tlive || rr < 0 || rr >= a.R) bits = 0;
                     plo |= (unsigned long long)bits << (ch * kk + ky * ksz);
                 }
@@ -2141,7 +2141,7 @@ __global__ __launch_bounds__(256, 2) void k_embed_fold(EmbedFoldArgs a) {
                 const f32x4 *la = (const f32x4 *)lall_s;
                 s0 += la[0]; s1 += la[1];
 #pragma unroll
-                for (int h = 0; h < NH; h++) inv[h] = 1.0f / (h < 4 ? s0[h & 3] : s1[h & 3]);
+                for (int h = 0; h < NH; h++) inv[h] = EX ? 1.0f / (h < 4 ? s0[h & 3] : s1[h & 3]) : __builtin_amdgcn_rcpf(h < 4 ? s0[h & 3] : s1[h & 3]);   // (bf16 rows: 1 ulp is below their rounding)
             }
             const bool isL = tid >= T && tid < T + 3;
             f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
@@ -2232,6 +2232,7 @@ static int32_t embed_fold_impl(const void *boards_dev, int32_t boards_are_f32, c
     if (n < 0 || channels < 1 || rows < 1 || cols < 1 || ksize < 1 || (ksize & 1) == 0 || channels * ksize * ksize > 64) return AZK_ERR_ARG;
     if (channels * rows * cols > 62 * 32 || k->embed_dim != 512) return AZK_ERR_ARG;
     if (rows * cols + 1 + 3 > 256) return AZK_ERR_ARG;             // one thread per token, three more for 1 / L
+    if (channels * rows > 64 || cols > 28 || ksize > 5) return AZK_ERR_ARG;   // one lane per (plane, row) word: the row + two margin bits a side in 32 bits
     if (k->num_heads != 8 && k->num_heads != 4) return AZK_ERR_ARG;
     if (n == 0) return AZK_OK;
     EmbedFoldArgs a;
