@@ -11,7 +11,7 @@ echo "stats default done"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_fp32 -- python3 bench.py --nn-dtype fp32 --steps 6 --warmup 2 --preroll-full 8 --cpu-seconds 0 > $O/bench_under_rocprof_fp32.json 2> $O/stats_fp32.err || exit 1
 echo "stats fp32 done"
 find $O -name "*kernel_trace.csv" -delete
-RX='k_tree|k_embed_pool|k_tail_gemm'
+RX='k_tree|k_embed_pool|k_embed_fold|k_tail_gemm'
 for pass in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_INSTS_MFMA SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_SCA"; do
   tag=$(echo $pass | cut -d' ' -f1)
   timeout -k 10 400 rocprofv3 --kernel-trace --pmc $pass --kernel-include-regex "$RX" --output-format csv -d $O/pmc_$tag -- $B > /dev/null 2> $O/pmc_$tag.err || { echo "pass $tag failed"; tail -3 $O/pmc_$tag.err; continue; }
