@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(os.path.dirname(_HERE), "csrc")
 LIB_PATH = os.path.join(_HERE, "libazk.so")
 
-ABI_VERSION = 3           # include/azk.h AZK_ABI_VERSION the structure layouts below were written for
+ABI_VERSION = 4           # include/azk.h AZK_ABI_VERSION the structure layouts below were written for
 GAME_ID = {"tictactoe": 0, "connect4": 1, "gomoku": 2}
 LEAF_F32, LEAF_BF16 = 0, 1
 EMBED_POOL_COMPACT_MAX_SLOTS = 65279       # AZK_EMBED_POOL_COMPACT_MAX_SLOTS (include/azk.h)
@@ -33,7 +33,7 @@ SYMBOLS = [
     "azk_nn_gemm_rows", "azk_nn_layernorm_sum", "azk_nn_heads_finalize_sum", "azk_nn_ln_heads",
     "azk_leaf_source_of", "azk_nn_embed_pool_leaves", "azk_nn_embed_pool_compact", "azk_nn_embed_pool_compact_leaves",
     "azk_nn_embed_fold", "azk_nn_embed_fold_leaves", "azk_nnx_embed_fold", "azk_nnx_embed_fold_leaves",
-    "azk_nn_tail_gemm", "azk_begin_search_budget", "azk_search_unfinished",
+    "azk_nn_tail_gemm", "azk_nn_tail_gemm_lds", "azk_begin_search_budget", "azk_search_unfinished",
     "azk_nnx_embed_pool", "azk_nnx_embed_pool_leaves", "azk_nnx_gemm", "azk_nnx_gemm_h",
     "azk_async_begin", "azk_async_step", "azk_async_drain", "azk_async_set_budget",
 ]
@@ -80,7 +80,7 @@ class TailGemm(C.Structure):
                 ("bias", C.c_void_p), ("layernorm_a", C.c_int32), ("epilogue", C.c_int32), ("ln_eps", C.c_float),
                 ("a_stats", C.c_void_p), ("a_stats_groups", C.c_int32), ("stats_out", C.c_void_p),
                 ("out_bf16", C.c_void_p), ("ldo", C.c_int32), ("resid_bf16", C.c_void_p), ("ldr", C.c_int32),
-                ("logits_out", C.c_void_p), ("values_out", C.c_void_p), ("action_dim", C.c_int32)]
+                ("logits_out", C.c_void_p), ("values_out", C.c_void_p), ("action_dim", C.c_int32), ("a_col_sums", C.c_void_p)]
 
 
 class EmbedPoolXConsts(C.Structure):
@@ -212,6 +212,7 @@ def lib():
     L.azk_begin_search_budget.argtypes = [vp, vp, i32, i32, vp]
     L.azk_search_unfinished.argtypes = [vp, vp, vp]
     L.azk_nn_tail_gemm.argtypes = [C.POINTER(TailGemm), vp]
+    L.azk_nn_tail_gemm_lds.argtypes = [C.POINTER(TailGemm), vp]
     L.azk_nnx_embed_pool.argtypes = [vp, i32, C.POINTER(EmbedPoolXConsts), vp, i32, i32, i32, i32, vp, vp, vp]
     L.azk_nnx_embed_pool_leaves.argtypes = [C.POINTER(LeafSource), C.POINTER(EmbedPoolXConsts), vp, vp, vp]
     L.azk_nnx_gemm.argtypes = [C.POINTER(GemmX), vp]
@@ -976,7 +977,7 @@ TAIL_BF16, TAIL_GELU, TAIL_RESID, TAIL_HEADS = 0, 1, 2, 3
 
 
 def nn_tail_gemm(a, w_packed, n_out, k, epilogue=TAIL_BF16, nbatch=1, a_batch_stride=0, bias=None, out=None, resid=None,
-                 a_stats=None, stats_out=None, logits=None, values=None, action_dim=0, count=None, eps=1e-5):
+                 a_stats=None, stats_out=None, logits=None, values=None, action_dim=0, count=None, eps=1e-5, col_sums=None, lds=False):
     """One link of the cls-row tail (azk_nn_tail_gemm): a bf16 [m, lda] x packed weights -> out bf16 [m, nbatch * n_out] (or the
     heads' float32 logits / values).  a_stats [m, groups, 2]: A is LayerNorm(a) (affine folded by the caller), its row statistics
     coming from the producer's stats_out."""
@@ -1002,9 +1003,22 @@ def nn_tail_gemm(a, w_packed, n_out, k, epilogue=TAIL_BF16, nbatch=1, a_batch_st
     if logits is not None:
         assert logits.dtype == torch.float32 and values.dtype == torch.float32 and logits.is_contiguous()
         d.logits_out, d.values_out, d.action_dim = logits.data_ptr(), values.data_ptr(), int(action_dim)
-    rc = lib().azk_nn_tail_gemm(C.byref(d), _stream())
+    if col_sums is not None:
+        assert col_sums.dtype == torch.float32 and col_sums.is_contiguous() and col_sums.numel() >= nbatch * n_out
+        d.a_col_sums = col_sums.data_ptr()
+    rc = (lib().azk_nn_tail_gemm_lds if lds else lib().azk_nn_tail_gemm)(C.byref(d), _stream())
     if rc != 0:
-        raise AzkError(f"azk_nn_tail_gemm failed ({rc})")
+        raise AzkError(f"azk_nn_tail_gemm{'_lds' if lds else ''} failed ({rc})")
+
+
+def packed_weight_col_sums(w_packed, n_out, k):
+    """Column sums sum_k W[j][k] of a pack_linear_weight() tensor's bf16 values (float64 sum, rounded once): the
+    a_col_sums operand of azk_nn_tail_gemm_lds (LayerNorm applied in the epilogue)."""
+    torch = _torch()
+    npad = (n_out + 63) // 64 * 64
+    # [g, s, c, l4, l15, i] -> [g, l15, c, s, l4, i]: column 64 g + 4 l15 + c, k = 32 s + 8 l4 + i
+    w = w_packed.view(npad // 64, k // 32, 4, 4, 16, 8).permute(0, 4, 2, 1, 3, 5).reshape(npad, k)
+    return w.double().sum(1).float().contiguous()
 
 
 class _ReplayUnpickler(__import__("pickle").Unpickler):

@@ -22,6 +22,7 @@
 #include <type_traits>
 
 #include "azk.h"
+#include "azk_tail_common.h"
 
 namespace {
 
@@ -2712,32 +2713,12 @@ extern "C" int32_t azk_nn_heads_finalize_sum(const float *partials_dev, int32_t 
 // =====================================================================================================
 namespace {
 
-struct TailArgs {
-    const unsigned short *A; int lda, a_batch;
-    const uint4 *Wp; long long w_batch;          // uint4 elements between batches
-    int M, N, nbatch;                            // N = output columns per batch (multiple of 64 * NWC)
-    const int *count;
-    const float *bias;                           // [nbatch * N] or null
-    unsigned short *out; int ldo;
-    const unsigned short *resid; int ldr;
-    float ln_eps;
-    const float *stats_in; int stats_groups;     // AMODE 1: [M][stats_groups][2] partial (sum, sum of squares) of every A row, written by the producer
-    float *stats_out;                            // optional: this GEMM's own partials [M][nbatch * N / 64][2] of the bf16-rounded output rows
-    float *logits, *values; int action_dim;
-    int wave_slots;                              // waves of the launched instantiation the device holds at once (set by launch_tail)
-};
-
-enum { TAIL_EPI_BF16 = 0, TAIL_EPI_GELU = 1, TAIL_EPI_RESID = 2, TAIL_EPI_HEADS = 3 };
-
-// nn.GELU (erf form) with erf from Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below the bf16 result's resolution):
-// a dozen instructions instead of libm's erff.
-__device__ __forceinline__ float gelu_erf(float x) {
-    const float z = fabsf(x) * 0.70710678118654752f;
-    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
-    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-    const float erf_abs = 1.0f - poly * __expf(-z * z);
-    return 0.5f * x * (1.0f + copysignf(erf_abs, x));
-}
+using azk_tail::TailArgs;                         // the argument block, the epilogue selectors and the GELU arithmetic are shared with the
+using azk_tail::gelu_erf;                         // LDS-staged form of the wide links (azk_tail.hip)
+using azk_tail::TAIL_EPI_BF16;
+using azk_tail::TAIL_EPI_GELU;
+using azk_tail::TAIL_EPI_RESID;
+using azk_tail::TAIL_EPI_HEADS;
 
 // NWK > 1: the K range is split over NWK waves of the workgroup (every load of the whole K in flight at once, one round trip),
 // their partial accumulators meet in LDS and wave 0 runs the epilogue.
@@ -2974,7 +2955,7 @@ extern "C" int32_t azk_nn_tail_gemm(const azk_tail_gemm *t, void *stream) {
         return AZK_ERR_ARG;
     if (t->epilogue == TAIL_EPI_RESID && (!t->resid_bf16 || (t->ldr & 3))) return AZK_ERR_ARG;
     if (t->m == 0) return AZK_OK;
-    TailArgs a;
+    TailArgs a = {};
     a.A = (const unsigned short *)t->a_bf16; a.lda = t->lda; a.a_batch = t->a_batch_stride; a.Wp = (const uint4 *)t->w_packed;
     a.w_batch = (long long)(t->n_out / 64) * (t->k / 32) * 4 * 64;
     a.M = t->m; a.N = t->n_out; a.nbatch = t->nbatch; a.count = t->n_valid; a.bias = t->bias; a.out = (unsigned short *)t->out_bf16; a.ldo = t->ldo;

@@ -1,0 +1,294 @@
+// azk_tail.hip - the two WIDE links of the cls-row tail (ai/nn.py:58-60 for the one row the heads read: LayerNorm2 -> Linear(D, 4D)
+// -> GELU, and Linear(4D, D) + residual) as LDS-staged MFMA GEMMs for M ~ 256-2048 live rows.
+//
+// What the register-only form of these links (azk_nn.hip k_tail_gemm) pays for: every wave pulls its own A rows as fragment-shaped
+// loads (16 rows x 64 B per instruction, half cache lines) and its own weight fragments, ~100 KB per wave through the CU's vector
+// memory path, with 442-466 registers per wave (one wave per SIMD).  Here a workgroup of eight waves shares one tile:
+//   * the activation tile AND the weight tile go to LDS by LDS-DMA (global_load_lds_dwordx4: no registers, no ds_write pass), the
+//     activations in full 128-byte lines: one wave instruction fills 8 rows x 128 B of an XOR-swizzled [rows][8 x 16 B] image
+//     (the swizzle is applied to the per-lane SOURCE address, the LDS image stays lane-linear), so the A fragments come back as
+//     conflict-free ds_read_b128;  the weights are already stored in fragment order (pack_linear_weight: 1 KiB per fragment tile),
+//     so their image is a plain copy and a B fragment is a lane-linear ds_read_b128;
+//   * K runs in 64-column stages through a ring of NS buffers filled NS-1 stages ahead; a stage is retired by a COUNTED
+//     s_waitcnt vmcnt(N) (never 0 inside the loop) followed by ONE raw s_barrier per stage - the barrier that publishes stage t also
+//     frees the buffer of stage t-1 for the next fill;
+//   * ~60 registers per wave: two waves per SIMD, so one wave's LDS reads and epilogue arithmetic run under the other's MFMAs.
+// K = 2048 splits K over four wave groups of the workgroup (each an independent accumulation chain over its 512 columns, the
+// chains added in LDS in the fixed order 0,1,2,3: bit for bit k_tail_gemm's result for the same inputs).
+// LayerNorm of the A rows (link 3) is applied in the EPILOGUE: LN(x) W'^T = rstd (x W'^T - mean colsum(W')) - the matrix pipe
+// multiplies the stored bf16 rows as they are (no per-fragment normalise + re-round pass), the row statistics come from the
+// producing GEMM's partial sums as before.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include "azk.h"
+#include "azk_tail_common.h"
+
+namespace {
+
+using namespace azk_tail;
+
+template <int N> __device__ __forceinline__ void wait_vmcnt_c() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+// (the count is a compile-time constant after unrolling; the asm immediate wants an integer constant expression)
+__device__ __forceinline__ void wait_vmcnt(int n) {
+    switch (n) {
+#define AZK_W(N_) case N_: wait_vmcnt_c<N_>(); break;
+        AZK_W(0) AZK_W(1) AZK_W(2) AZK_W(3) AZK_W(4) AZK_W(5) AZK_W(6) AZK_W(7) AZK_W(8) AZK_W(9) AZK_W(10) AZK_W(11) AZK_W(12)
+        AZK_W(13) AZK_W(14) AZK_W(15) AZK_W(16) AZK_W(17) AZK_W(18) AZK_W(19) AZK_W(20) AZK_W(21) AZK_W(22) AZK_W(23) AZK_W(24)
+#undef AZK_W
+        default: wait_vmcnt_c<0>(); break;
+    }
+}
+
+// One LDS-DMA piece: 64 lanes x 16 bytes from per-lane global addresses to 1 KiB of LDS at the wave-uniform byte address lds_dst.
+// As inline assembly on purpose: hipcc treats the builtin form as a pending LDS write and drains it with s_waitcnt vmcnt(0) in front of
+// the next ds_read - every stage of the ring would be waited for at once.  The statement saves and restores M0 (the destination base);
+// the loads are invisible to the compiler's own counters, so every wait for them below is explicit.
+__device__ __forceinline__ void glds16(const void *gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+// One tiling of a link.  WM x WN x WK waves; a wave owns 16 rows x 64 columns (one A fragment, four B fragments per 32-wide k-step)
+// and runs NCH accumulation chains one after the other, each over KTC stages of 64 columns: wave group wk covers the chains
+// wk NCH .. wk NCH + NCH - 1 of the K range.  Block tile: 16 WM rows x 64 WN columns, K = 64 KTC NCH WK.  The chains are added in
+// the order 0, 1, 2, ... whatever the tiling (first a wave's own, then the other groups' through LDS).
+template <int WM_, int WN_, int WK_, int NCH_, int KTC_, int NS_>
+struct TailTiling {
+    static constexpr int WM = WM_, WN = WN_, WK = WK_, NCH = NCH_, KTC = KTC_, NS = NS_;
+    static constexpr int NW = WM * WN * WK, BM = 16 * WM, BN = 64 * WN, KT = NCH * KTC, KS = 2 * KT * WK;   // KT: stages per wave; KS: 32-wide k-steps of the whole K
+    static constexpr int XB = WK * BM * 128, WB = WK * WN * 8192, SB = XB + WB;              // bytes per stage
+    static constexpr int LDS_BYTES = NS * SB;
+};
+
+template <class T, int AMODE, int EPI>
+__device__ __forceinline__ void tail_lds_body(const TailArgs &a, const int nvalid, char *const lds) {
+    constexpr int WM = T::WM, WN = T::WN, WK = T::WK, NCH = T::NCH, KTC = T::KTC, NS = T::NS;
+    constexpr int NW = T::NW, BM = T::BM, BN = T::BN, KT = T::KT, KS = T::KS, XB = T::XB, SB = T::SB;
+    constexpr int NXI = XB / 1024, NI = SB / 1024, LPS = NI / NW;                            // LDS-DMA wave instructions per stage (x part / all / per wave)
+    static_assert(XB % 1024 == 0 && NI % NW == 0 && BM % 8 == 0 && NXI % NW == 0, "whole 1 KiB wave pieces, evenly over the waves");
+    constexpr int LPX = NXI / NW;                                                            // a wave's first LPX pieces of a stage are x pieces
+    static_assert(NS >= 2 && NS - 1 <= KT && (NS - 1) * LPS <= 24, "ring depth");
+    static_assert(WK == 1 || (WK - 1) * WM * WN * NCH * 4096 <= NS * SB, "the split-K partials reuse the stage ring");
+    const int ctiles = a.N / BN;
+    const int ct = blockIdx.x % ctiles, rt = blockIdx.x / ctiles;
+    const int row0 = rt * BM;
+    if (row0 >= nvalid) return;                                          // (uniform per workgroup; nothing has been issued yet)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+    const int wk = wave / (WM * WN), wmn = wave - wk * (WM * WN), wm = wmn / WN, wn = wmn - wm * WN;
+    const int g0 = ct * WN;                                              // first 64-column group of the block
+
+    // ---- epilogue operands that do not depend on the product: requested first, consumed last ----
+    const int colg = 64 * (g0 + wn) + 4 * l15;                           // a lane's four accumulators of a row are four consecutive output columns
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f}, cs = {0.f, 0.f, 0.f, 0.f};
+    f32x4 st = {0.f, 0.f, 0.f, 0.f};
+    uint2 rr[EPI == TAIL_EPI_RESID ? 4 : 1];
+    if (wk == 0) {
+        if (a.bias) bv = *(const f32x4 *)(a.bias + colg);
+        if (AMODE == 2) {
+            cs = *(const f32x4 *)(a.csum + colg);
+            // the statistics of the lane group's four rows: lane l15 fetches quarter l15 & 3 (two column groups) of row l15 >> 2
+            st = *((const f32x4 *)(a.stats_in + (size_t)min(row0 + 16 * wm + 4 * l4 + (l15 >> 2), a.M - 1) * 16) + (l15 & 3));
+        }
+        if (EPI == TAIL_EPI_RESID) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) rr[j] = *(const uint2 *)(a.resid + (size_t)min(row0 + 16 * wm + 4 * l4 + j, a.M - 1) * a.ldr + colg);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- the wave's LDS-DMA pieces: piece j = wave + NW i of a stage lands at byte 1024 j of the stage buffer ----
+    // x pieces (j < NXI): wave group kq = j / (BM / 8), rows 8 (j % (BM / 8)) .. + 8; lane l fills physical 16-byte chunk l & 7 of
+    //   row l >> 3 with the row's LOGICAL chunk (l & 7) ^ (l >> 3)  (rows are 128 B; the read applies the same XOR)
+    // w pieces: j' = j - NXI = ((kq WN + g) 8 + q): the q-th KiB of column group g0 + g's 8 KiB for this stage (two k-steps x four tiles)
+    const char *gp[LPS];
+    const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)lds + (unsigned)wave * 1024u);
+#pragma unroll
+    for (int i = 0; i < LPS; i++) {
+        const int j = wave + NW * i;
+        if (i < LPX) {
+            const int kq = j / (BM / 8), r = 8 * (j % (BM / 8)) + (lane >> 3);
+            gp[i] = (const char *)(a.A + (size_t)min(row0 + r, a.M - 1) * a.lda + (size_t)kq * (64 * KT) + 8 * ((lane & 7) ^ (lane >> 3)));
+        } else {
+            const int jw = j - NXI, kq = jw / (8 * WN), g = (jw >> 3) % WN, q = jw & 7;
+            gp[i] = (const char *)(a.Wp + ((size_t)(g0 + g) * KS + (size_t)kq * 2 * KT) * 256 + q * 64 + lane);
+        }
+    }
+    auto stage = [&](int t) {                                            // stage t of every wave group -> ring buffer t % NS
+        const unsigned dst = lds_base + (t % NS) * SB;
+#pragma unroll
+        for (int i = 0; i < LPS; i++) glds16(gp[i] + (size_t)t * (i < LPX ? 128 : 8192), dst + NW * 1024 * i);
+    };
+#pragma unroll
+    for (int t = 0; t < NS - 1; t++) stage(t);
+
+    // fragment addresses inside a stage buffer
+    const int arow = 16 * wm + l15;
+    const int a_off = (wk * BM + arow) * 128;                            // + ((kk * 4 + l4) ^ (arow & 7)) * 16
+    const int b_off = XB + (wk * WN + wn) * 8192 + lane * 16;           // + (kk * 4 + c) * 1024
+    union BF { uint4 u; bf16x8 v; };
+    f32x4 accs[NCH][4];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ch++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) accs[ch][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int t = 0; t < KT; t++) {
+        // stages t+1 .. min(t+NS-2, KT-1) may stay in flight; stage t of THIS wave is complete after the wait, of every wave after the barrier
+        const int younger = (t + NS - 2 < KT - 1 ? t + NS - 2 : KT - 1) - t;
+        wait_vmcnt(younger * LPS);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // this wave's fragment reads of stage t-1 have left the buffer the barrier frees
+        __builtin_amdgcn_s_barrier();
+        if (t + NS - 1 < KT) stage(t + NS - 1);                          // into the buffer stage t-1 was read from: every wave is past those reads
+        const char *const sb = lds + (t % NS) * SB;
+        BF af[2], bf[2][4];
+#pragma unroll
+        for (int kk = 0; kk < 2; kk++) {
+            af[kk].u = *(const uint4 *)(sb + a_off + (((kk * 4 + l4) ^ (arow & 7)) << 4));
+#pragma unroll
+            for (int c = 0; c < 4; c++) bf[kk][c].u = *(const uint4 *)(sb + b_off + (kk * 4 + c) * 1024);
+        }
+        __builtin_amdgcn_sched_barrier(0);                               // all ten fragment reads of the stage in flight before its first MFMA
+#pragma unroll
+        for (int kk = 0; kk < 2; kk++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) accs[t / KTC][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kk].v, bf[kk][c].v, accs[t / KTC][c], 0, 0, 0);
+    }
+
+    f32x4 acc[4];                                                        // the chains added in the order 0, 1, 2, ...
+#pragma unroll
+    for (int c = 0; c < 4; c++) acc[c] = accs[0][c];
+    if (wk == 0) {
+#pragma unroll
+        for (int ch = 1; ch < NCH; ch++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) acc[c] += accs[ch][c];
+    }
+    if (WK > 1) {                                                        // the other wave groups' chains meet wave group 0's in LDS
+        __builtin_amdgcn_s_barrier();                                    // every wave has read its last stage; no LDS-DMA is outstanding (vmcnt(0) above)
+        f32x4 *const kred = (f32x4 *)lds;
+        if (wk > 0) {
+#pragma unroll
+            for (int ch = 0; ch < NCH; ch++)
+#pragma unroll
+                for (int c = 0; c < 4; c++) kred[((((wk - 1) * WM * WN + wmn) * NCH + ch) * 4 + c) * 64 + lane] = accs[ch][c];
+        }
+        __syncthreads();
+        if (wk > 0) return;
+#pragma unroll
+        for (int w = 1; w < WK; w++)
+#pragma unroll
+            for (int ch = 0; ch < NCH; ch++)
+#pragma unroll
+                for (int c = 0; c < 4; c++) acc[c] += kred[((((w - 1) * WM * WN + wmn) * NCH + ch) * 4 + c) * 64 + lane];
+    }
+
+    // ---- epilogue (the arithmetic of k_tail_gemm's, RT = 1) ----
+    const int rbase = row0 + 16 * wm + 4 * l4;
+    float rstd[4], mrs[4];
+    if (AMODE == 2) {
+        // eight (sum, sum of squares) pairs per row, added in a fixed order: the lane's two groups, then the quad's four lanes
+        const float q1 = quad_sum(st[0] + st[2]), q2 = quad_sum(st[1] + st[3]);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const float s1 = __shfl(q1, (lane & 48) + 4 * j), s2 = __shfl(q2, (lane & 48) + 4 * j);
+            constexpr float invk = 1.0f / (64 * KT * WK);
+            const float mean = s1 * invk;
+            rstd[j] = rsqrtf(fmaxf(s2 * invk - mean * mean, 0.f) + a.ln_eps);
+            mrs[j] = mean * rstd[j];
+        }
+    }
+    uint2 o[4];
+    f32x2 ps[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        f32x4 v;
+        if (AMODE == 2) v = f32x4{acc[0][j] * rstd[j] - mrs[j] * cs[0] + bv[0], acc[1][j] * rstd[j] - mrs[j] * cs[1] + bv[1],
+                                  acc[2][j] * rstd[j] - mrs[j] * cs[2] + bv[2], acc[3][j] * rstd[j] - mrs[j] * cs[3] + bv[3]};
+        else v = f32x4{acc[0][j] + bv[0], acc[1][j] + bv[1], acc[2][j] + bv[2], acc[3][j] + bv[3]};
+        if (EPI == TAIL_EPI_GELU) {
+#pragma unroll
+            for (int c = 0; c < 4; c++) v[c] = gelu_erf(v[c]);                                      // nn.GELU (erf form)
+        }
+        if (EPI == TAIL_EPI_RESID) {
+            v[0] += __uint_as_float(rr[j].x << 16); v[1] += __uint_as_float(rr[j].x & 0xffff0000u);
+            v[2] += __uint_as_float(rr[j].y << 16); v[3] += __uint_as_float(rr[j].y & 0xffff0000u);
+        }
+        union { bf16x4 b4; uint2 u; } ob;
+        ob.b4 = __builtin_convertvector(v, bf16x4);
+        o[j] = ob.u;
+        if (a.stats_out) {
+            const f32x4 vr = __builtin_convertvector(ob.b4, f32x4);
+            ps[j] = f32x2{row16_sum((vr[0] + vr[1]) + (vr[2] + vr[3])),
+                          row16_sum((vr[0] * vr[0] + vr[1] * vr[1]) + (vr[2] * vr[2] + vr[3] * vr[3]))};
+        }
+    }
+    const int ngr = a.N >> 6, gr = g0 + wn;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int row = rbase + j;
+        if (row < nvalid) *(uint2 *)(a.out + (size_t)row * a.ldo + colg) = o[j];
+        if (a.stats_out && l15 == 0 && row < nvalid) *(f32x2 *)(a.stats_out + ((size_t)row * ngr + gr) * 2) = ps[j];
+    }
+}
+
+// Two tilings in one kernel: T1 while the live rows fit one round of workgroups (rows <= SWITCH), T2 (taller tiles, fewer workgroups)
+// above - the choice is made in the kernel from the device-side live count, so a captured launch serves every step.  SWITCH = 0: T1 only.
+template <class T1, class T2, int SWITCH, int AMODE, int EPI>
+__global__ __launch_bounds__(64 * T1::NW, 2) void k_tail_lds(TailArgs a) {
+    static_assert(T1::NW == T2::NW, "one workgroup shape");
+    extern __shared__ uint4 smem[];
+    // (every kernel argument is wanted in SGPRs here, before the count's own round trip: see k_tail_gemm)
+    asm volatile("" :: "s"(a.A), "s"(a.Wp), "s"(a.out), "s"(a.bias), "s"(a.resid), "s"(a.stats_in), "s"(a.stats_out), "s"(a.csum),
+                 "s"(a.lda), "s"(a.ldo), "s"(a.N), "s"(a.M), "s"(a.ldr), "s"(a.ln_eps));
+    const int nvalid = a.count ? min(a.M, *a.count) : a.M;
+    if (SWITCH > 0 && nvalid > SWITCH) tail_lds_body<T2, AMODE, EPI>(a, nvalid, (char *)smem);
+    else tail_lds_body<T1, AMODE, EPI>(a, nvalid, (char *)smem);
+}
+
+template <class T1, class T2, int SWITCH, int AMODE, int EPI>
+int launch_lds(TailArgs &a, hipStream_t st) {
+    constexpr size_t lds_bytes = T1::LDS_BYTES > T2::LDS_BYTES ? T1::LDS_BYTES : T2::LDS_BYTES;
+    auto kern = k_tail_lds<T1, T2, SWITCH, AMODE, EPI>;
+    static bool attr_set[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return AZK_ERR_HIP;
+    if (!attr_set[dev]) {                                                // per device: the attribute belongs to the device's copy of the function
+        if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return AZK_ERR_HIP;
+        attr_set[dev] = true;
+    }
+    const unsigned b1 = (unsigned)(((a.M + T1::BM - 1) / T1::BM) * (a.N / T1::BN)), b2 = (unsigned)(((a.M + T2::BM - 1) / T2::BM) * (a.N / T2::BN));
+    kern<<<b1 > b2 ? b1 : b2, 64 * T1::NW, lds_bytes, st>>>(a);
+    return hipGetLastError() == hipSuccess ? AZK_OK : AZK_ERR_HIP;
+}
+
+}  // namespace
+
+// azk_nn_tail_gemm_lds: the LDS-staged form of azk_nn_tail_gemm for its two wide links (include/azk.h).
+extern "C" int32_t azk_nn_tail_gemm_lds(const azk_tail_gemm *t, void *stream) {
+    if (!t || !t->a_bf16 || !t->w_packed || t->m < 0 || t->nbatch != 1 || !t->out_bf16) return AZK_ERR_ARG;
+    if ((t->lda & 7) || t->lda < t->k || ((uintptr_t)t->a_bf16 & 15) || (t->ldo & 3) || t->ldo < t->n_out) return AZK_ERR_ARG;
+    if (t->m == 0) return AZK_OK;
+    TailArgs a = {};
+    a.A = (const unsigned short *)t->a_bf16; a.lda = t->lda; a.a_batch = 0; a.Wp = (const uint4 *)t->w_packed; a.w_batch = 0;
+    a.M = t->m; a.N = t->n_out; a.nbatch = 1; a.count = t->n_valid; a.bias = t->bias; a.out = (unsigned short *)t->out_bf16; a.ldo = t->ldo;
+    a.resid = (const unsigned short *)t->resid_bf16; a.ldr = t->ldr; a.ln_eps = t->ln_eps; a.stats_in = t->a_stats; a.stats_groups = t->a_stats_groups;
+    a.stats_out = t->stats_out; a.csum = t->a_col_sums;
+    hipStream_t st = (hipStream_t)stream;
+    if (t->k == 512 && t->epilogue == TAIL_EPI_GELU && t->layernorm_a && t->n_out % 128 == 0) {
+        if (!t->a_stats || t->a_stats_groups != 8 || !t->a_col_sums || t->stats_out) return AZK_ERR_ARG;
+        // 64 x 128 tiles, three stages of 24 KB: two workgroups per CU, so one round of workgroups up to 2048 live rows
+        using T = TailTiling<4, 2, 1, 1, 8, 3>;
+        return launch_lds<T, T, 0, 2, TAIL_EPI_GELU>(a, st);
+    }
+    if (t->k == 2048 && t->epilogue == TAIL_EPI_RESID && !t->layernorm_a && t->n_out % 64 == 0) {
+        if (!t->resid_bf16 || (t->ldr & 3)) return AZK_ERR_ARG;
+        // up to 1024 live rows: 32 x 64 tiles, four wave groups x one chain (144 KB of LDS: one workgroup per CU, 8 x rows / 32 of them);
+        // above: 64 x 64 tiles, two wave groups x two chains, so that the launch stays one round of workgroups
+        return launch_lds<TailTiling<2, 1, 4, 1, 8, 3>, TailTiling<4, 1, 2, 2, 8, 3>, 1024, 0, TAIL_EPI_RESID>(a, st);
+    }
+    return AZK_ERR_ARG;
+}

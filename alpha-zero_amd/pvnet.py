@@ -149,6 +149,7 @@ class PolicyValueNet:
         self.fused_embed_pool = False   # set by _prepare_folded when azk_nn_embed_pool covers this configuration
         self.chain_tail = False         # set by _prepare_folded when azk_nn_tail_gemm covers this configuration
         self.use_chain_tail = True
+        self.use_lds_tail = True          # the two wide links of the chain tail LDS-staged (csrc/azk_tail.hip); False: k_tail_gemm for all five
         self._tail_ws = {}              # workspaces of the tail chain, one per board source, sized for the largest batch seen
         self._tail_ws_retired = []      # outgrown workspaces, kept alive (captured graphs may hold their addresses)
         self._compact = None            # azk.EmbedPoolTables when the compacting kernel covers this configuration (static softmax reference)
@@ -639,6 +640,9 @@ class PolicyValueNet:
                 f["WvHP"] = torch.cat([azk.pack_linear_weight(Wvn[h]).reshape(-1) for h in range(H)])       # H blocks of [dh=64][D]
                 f["WoP"] = azk.pack_linear_weight(Wo)
                 f["W0GP"] = azk.pack_linear_weight(W0 * g2[None, :])
+                # LDS-staged wide links (azk_nn_tail_gemm_lds): LayerNorm2 is applied in the epilogue, which needs the column sums of the
+                # weight the matrix pipe really multiplies with (the bf16 values of W0GP)
+                f["W0GP_csum"] = azk.packed_weight_col_sums(f["W0GP"], 4 * D, D)
                 f["b0G_f"] = (W0 @ b2 + b0_).float().contiguous()
                 f["b3_f"] = m[b + "mlp.3.bias"].to(dev, torch.float32).contiguous()
                 if self.fused_embed_pool:
@@ -752,8 +756,11 @@ class PolicyValueNet:
         else:
             self._launch(azk.nn_tail_gemm, z.view(n, H * D), f["WvHP"], D // H, D, azk.TAIL_BF16, nbatch=H, a_batch_stride=D, out=ws["u"], count=cnt)
         self._launch(azk.nn_tail_gemm, ws["u"], f["WoP"], D, D, azk.TAIL_BF16, bias=f["bias1_f"], out=ws["x1"], stats_out=ws["st1"], count=cnt)
-        self._launch(azk.nn_tail_gemm, ws["x1"], f["W0GP"], 4 * D, D, azk.TAIL_GELU, bias=f["b0G_f"], out=ws["hh"], a_stats=ws["st1"], count=cnt)
-        self._launch(azk.nn_tail_gemm, ws["hh"], f["W3P"], D, 4 * D, azk.TAIL_RESID, bias=f["b3_f"], resid=ws["x1"], out=ws["x2"], stats_out=ws["st2"], count=cnt)
+        lds = getattr(self, "use_lds_tail", True)        # the two wide links LDS-staged (csrc/azk_tail.hip) or whole-K-in-registers (k_tail_gemm)
+        self._launch(azk.nn_tail_gemm, ws["x1"], f["W0GP"], 4 * D, D, azk.TAIL_GELU, bias=f["b0G_f"], out=ws["hh"], a_stats=ws["st1"], count=cnt,
+                     col_sums=f["W0GP_csum"] if lds else None, lds=lds)
+        self._launch(azk.nn_tail_gemm, ws["hh"], f["W3P"], D, 4 * D, azk.TAIL_RESID, bias=f["b3_f"], resid=ws["x1"], out=ws["x2"], stats_out=ws["st2"], count=cnt,
+                     lds=lds)
         if self.out_buffers is not None:
             lb, vb = self.out_buffers
         else:

@@ -29,7 +29,7 @@ extern "C" {
 
 /* 2: azk_emit_finished's game_base_dev became int64*, azk_leaf_source gained cache_stamp, azk_config gained cache_shared /
  * leaves_per_step (round 2); callers compare azk_abi_version() with the header they were built against */
-#define AZK_ABI_VERSION 3
+#define AZK_ABI_VERSION 4
 
 /* games (games/tictactoe.py, games/connect4.py, games/gomoku.py) */
 #define AZK_TICTACTOE 0
@@ -421,8 +421,19 @@ typedef struct azk_tail_gemm {
     void *out_bf16; int32_t ldo;
     const void *resid_bf16; int32_t ldr;
     float *logits_out, *values_out; int32_t action_dim;
+    const float *a_col_sums;          /* azk_nn_tail_gemm_lds with layernorm_a: float32 [n_out] column sums of the bf16 weight (ABI 4) */
 } azk_tail_gemm;
 int32_t azk_nn_tail_gemm(const azk_tail_gemm *desc, void *stream);
+/* azk_nn_tail_gemm_lds - the same descriptor, the two WIDE links of the tail (nn.py:58-60) as LDS-staged GEMMs (csrc/azk_tail.hip:
+ * activation and weight tiles to LDS by LDS-DMA in full 128-byte lines, a ring of K stages retired by counted waits, eight waves per
+ * workgroup at two waves per SIMD):
+ *   k = 512,  epilogue 1 (GELU), layernorm_a = 1, n_out a multiple of 128: LayerNorm applied in the epilogue,
+ *             out = GELU(rstd (A W^T - mean a_col_sums) + bias) - A enters the matrix pipe as stored (no re-rounded normalised copy);
+ *             a_stats as for azk_nn_tail_gemm, a_col_sums required, no stats_out;
+ *   k = 2048, epilogue 2 (residual), layernorm_a = 0, n_out a multiple of 64: K split over four wave groups whose chains are added in
+ *             the fixed order 0..3 - bit for bit azk_nn_tail_gemm's result on the same inputs; optional stats_out.
+ * Anything else: AZK_ERR_ARG (use azk_nn_tail_gemm). */
+int32_t azk_nn_tail_gemm_lds(const azk_tail_gemm *desc, void *stream);
 
 /* azk_nn_ln_heads: final LayerNorm + merged policy/value head + finalize in one launch (nn.py:78-83 for the cls row):
  *   logits[n][A] = LN(x) Wh^T + bh (float32), values[n] = tanh(column A).  w_packed_dev: the merged head weight

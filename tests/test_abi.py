@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, name), f"{name} declared in include/azk.h but not exported"
     assert sorted(azk.SYMBOLS) == declared, "azk.SYMBOLS (python binding) and include/azk.h disagree"
     L.azk_abi_version.restype = ctypes.c_int32
-    assert L.azk_abi_version() == azk.ABI_VERSION == 3
+    assert L.azk_abi_version() == azk.ABI_VERSION == 4
 
 
 def test_no_torch_types_in_the_abi():
@@ -81,6 +81,6 @@ def test_binding_refuses_a_library_of_another_abi_version(monkeypatch):
     monkeypatch.setattr(azk, "ABI_VERSION", 999)
     with pytest.raises(azk.AzkError, match="ABI version"):
         azk.lib()
-    monkeypatch.setattr(azk, "ABI_VERSION", 3)
+    monkeypatch.setattr(azk, "ABI_VERSION", 4)
     monkeypatch.setattr(azk, "_LIB", None)
-    assert azk.lib().azk_abi_version() == 3
+    assert azk.lib().azk_abi_version() == 4

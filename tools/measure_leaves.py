@@ -71,6 +71,10 @@ u_arr = np.array([x[1] for x in nonlocal_stats], float)
 dirty = np.concatenate(dirty_hist) if dirty_hist else np.zeros(1)
 out = {"games": G, "sims": sims, "measured_moves": moves, "sampled_steps": len(nonlocal_stats),
        "mean_leaves_per_step": float(n_arr.mean()), "mean_unique_per_step": float(u_arr.mean()),
+       "leaves_per_step_percentiles": {f"p{q}": float(np.percentile(n_arr, q)) for q in (0, 1, 5, 25, 50, 75, 95, 99, 100)},
+       "share_of_steps_above": {str(th): float((n_arr > th).mean()) for th in (512, 768, 1024, 1280, 1536)},
+       "leaves_by_simulation_index": {f"{lo}-{lo + len(c) * stride - 1}": float(np.mean(c)) for lo, c in
+                                      ((i * stride, n_arr[i:i + max(1, 100 // stride)]) for i in range(0, min(len(n_arr), sims // stride), max(1, 100 // stride)))},
        "duplicate_fraction": float(1.0 - u_arr.sum() / n_arr.sum()),
        "dirty_tokens_per_leaf": {"mean": float(dirty.mean()), "p50": float(np.median(dirty)), "p90": float(np.percentile(dirty, 90)),
                                  "max": float(dirty.max()), "mean_tiles_of_16": float(np.ceil(dirty / 16).mean())},
