@@ -441,6 +441,8 @@ def main():
         ep_stats.zero_()
     plies0, fin0, finp0 = runner.plies_played, runner.games_finished, runner.finished_plies
     launches0 = getattr(runner, "launches", 0)
+    if os.environ.get("AZK_DUMP_MAPS"):     # diagnosis of a profiler crash: the process's mappings, to turn a stack trace's addresses into library offsets
+        open(os.environ["AZK_DUMP_MAPS"], "w").write(open("/proc/self/maps").read())
     kt.enabled = True
     sync_all()
     t0 = time.perf_counter()
