@@ -22,6 +22,7 @@
 #include <type_traits>
 
 #include "azk.h"
+#include "azk_launch.h"
 #include "azk_tail_common.h"
 
 namespace {
@@ -260,11 +261,7 @@ int launch_embed2(const EmbedArgs &a, hipStream_t st) {
     const int tiles = (a.T + 15) >> 4, groups = tiles >= 6 ? 3 : 1;
     long long blocks = ((long long)a.n * groups + 3) / 4;       // one wavefront per (board, tile group); idle workgroups exit at once
     if (blocks > 4096) blocks = 4096;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void *)k_embed<NG, KS, WX, WH, NH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return AZK_ERR_HIP;
-        attr_set = true;
-    }
+    if (azk_set_max_lds((const void *)k_embed<NG, KS, WX, WH, NH>, lds) != hipSuccess) return AZK_ERR_HIP;
     k_embed<NG, KS, WX, WH, NH><<<(unsigned)blocks, 256, lds, st>>>(a);
     return hipGetLastError() == hipSuccess ? AZK_OK : AZK_ERR_HIP;
 }
@@ -443,11 +440,7 @@ template <int CPL, int NH>
 int launch_cls_attn(const ClsAttnArgs &a, hipStream_t st) {
     constexpr int D = 64 * CPL;
     const int lds = 4 * NH * D * 4 + 8 * NH * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void *)k_cls_attn<CPL, NH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return AZK_ERR_HIP;
-        attr_set = true;
-    }
+    if (azk_set_max_lds((const void *)k_cls_attn<CPL, NH>, lds) != hipSuccess) return AZK_ERR_HIP;
     k_cls_attn<CPL, NH><<<a.n, 256, lds, st>>>(a);
     return hipGetLastError() == hipSuccess ? AZK_OK : AZK_ERR_HIP;
 }
@@ -636,11 +629,7 @@ __global__ __launch_bounds__(256) void k_cls_pool(ClsPoolArgs a) {
 template <int CPL, int NH>
 int launch_cls_pool(const ClsPoolArgs &a, hipStream_t st) {
     const int lds = (a.Tp * NH + 2 * NH * 64 * CPL) * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void *)k_cls_pool<CPL, NH>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess) return AZK_ERR_HIP;
-        attr_set = true;
-    }
+    if (azk_set_max_lds((const void *)k_cls_pool<CPL, NH>, 64 * 1024) != hipSuccess) return AZK_ERR_HIP;
     if (lds > 64 * 1024) return AZK_ERR_ARG;
     k_cls_pool<CPL, NH><<<a.n, 256, lds, st>>>(a);
     return hipGetLastError() == hipSuccess ? AZK_OK : AZK_ERR_HIP;
@@ -1077,11 +1066,7 @@ __global__ __launch_bounds__(256, 2) void k_embed_pool(EmbedPoolArgs a) {
 template <int KS, int NH, bool SR, bool SRC>
 int launch_embed_pool2(const EmbedPoolArgs &a, hipStream_t st) {
     const int lds = 256 * 16 + 512 + ((a.T + 15) / 16) * 16 * 16 + 96;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void *)k_embed_pool<KS, NH, SR, SRC>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return AZK_ERR_HIP;
-        attr_set = true;
-    }
+    if (azk_set_max_lds((const void *)k_embed_pool<KS, NH, SR, SRC>, lds) != hipSuccess) return AZK_ERR_HIP;
     const int blocks = a.n < 512 ? a.n : 512;                      // two resident workgroups per CU, each walks its boards
     k_embed_pool<KS, NH, SR, SRC><<<blocks, 256, lds, st>>>(a);
     return hipGetLastError() == hipSuccess ? AZK_OK : AZK_ERR_HIP;
@@ -1626,11 +1611,7 @@ int launch_embed_pool_c2(const EmbedPoolCArgs &a, hipStream_t st) {
     constexpr int KS = (NC * KSZ * KSZ + 31) / 32;
     const int tp16 = ((a.T + 15) / 16) * 16;
     const int lds = 256 * 16 + 512 + tp16 * 16 + tp16 * 4 + 128 + (SRC ? 256 * 16 : 0) + 33 * KS * 64 * 16;      // 77 KB at KS = 2: two workgroups per CU
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void *)k_embed_pool_c<NC, KSZ, NH, SRC>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return AZK_ERR_HIP;
-        attr_set = true;
-    }
+    if (azk_set_max_lds((const void *)k_embed_pool_c<NC, KSZ, NH, SRC>, lds) != hipSuccess) return AZK_ERR_HIP;
     const int blocks = a.n < 512 ? a.n : 512;                      // two resident workgroups per CU; each pulls boards until the queue is dry
     k_embed_pool_c<NC, KSZ, NH, SRC><<<blocks, 256, lds, st>>>(a);
     return hipGetLastError() == hipSuccess ? AZK_OK : AZK_ERR_HIP;
@@ -2213,11 +2194,7 @@ template <int NC, int KSZ, int NH, bool SRC, bool EX>
 int launch_embed_fold(const EmbedFoldArgs &a, hipStream_t st) {
     const int tp16 = ((a.T + 15) / 16) * 16;
     const int lds = 256 * 16 + tp16 * 8 + tp16 * 4 + 128 + 128 + 32 + tp16 * 32 + 4 * 8 * 64 * 4 + (SRC ? ((a.src.n_games + 7) / 8) * 16 : 0);   // 29 KB at 2 048 games
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void *)k_embed_fold<NC, KSZ, NH, SRC, EX>, hipFuncAttributeMaxDynamicSharedMemorySize, lds + 2 * FOLD_MAX_SLOTS) != hipSuccess) return AZK_ERR_HIP;
-        attr_set = true;
-    }
+    if (azk_set_max_lds((const void *)k_embed_fold<NC, KSZ, NH, SRC, EX>, lds + 2 * FOLD_MAX_SLOTS) != hipSuccess) return AZK_ERR_HIP;
     const int blocks = a.n < 512 ? a.n : 512;                      // two resident workgroups per CU; each pulls boards until the queue is dry
     k_embed_fold<NC, KSZ, NH, SRC, EX><<<blocks, 256, lds, st>>>(a);
     return hipGetLastError() == hipSuccess ? AZK_OK : AZK_ERR_HIP;

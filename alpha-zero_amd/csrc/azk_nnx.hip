@@ -23,6 +23,7 @@
 #include <string.h>
 
 #include "azk.h"
+#include "azk_launch.h"
 
 namespace {
 
@@ -535,11 +536,7 @@ int launch_embed_pool_x(const EmbedPoolXArgs &a, hipStream_t st) {
     const int tp16 = ((a.T + 15) / 16) * 16;
     const int lds = 256 * 16 + tp16 * 16 + tp16 * 4 + 128 + 256 + 3 * 8 * 32 * 16 + (SRC ? 256 * 16 : 0) + 33 * KS * 2 * 64 * 16;     // 156 KB at KS = 2: one workgroup per CU
     if (lds > 160 * 1024) return AZK_ERR_ARG;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void *)k_embed_pool_x<NC, KSZ, NH, SRC>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return AZK_ERR_HIP;
-        attr_set = true;
-    }
+    if (azk_set_max_lds((const void *)k_embed_pool_x<NC, KSZ, NH, SRC>, lds) != hipSuccess) return AZK_ERR_HIP;
     static int cus = 0;
     if (!cus) {
         int dev = 0;

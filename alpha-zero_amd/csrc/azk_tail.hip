@@ -23,6 +23,7 @@
 #include <stdlib.h>
 
 #include "azk.h"
+#include "azk_launch.h"
 #include "azk_tail_common.h"
 
 namespace {
@@ -253,13 +254,7 @@ template <class T1, class T2, int SWITCH, int AMODE, int EPI>
 int launch_lds(TailArgs &a, hipStream_t st) {
     constexpr size_t lds_bytes = T1::LDS_BYTES > T2::LDS_BYTES ? T1::LDS_BYTES : T2::LDS_BYTES;
     auto kern = k_tail_lds<T1, T2, SWITCH, AMODE, EPI>;
-    static bool attr_set[64] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return AZK_ERR_HIP;
-    if (!attr_set[dev]) {                                                // per device: the attribute belongs to the device's copy of the function
-        if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return AZK_ERR_HIP;
-        attr_set[dev] = true;
-    }
+    if (azk_set_max_lds((const void *)kern, (int)lds_bytes) != hipSuccess) return AZK_ERR_HIP;
     const unsigned b1 = (unsigned)(((a.M + T1::BM - 1) / T1::BM) * (a.N / T1::BN)), b2 = (unsigned)(((a.M + T2::BM - 1) / T2::BM) * (a.N / T2::BN));
     kern<<<b1 > b2 ? b1 : b2, 64 * T1::NW, lds_bytes, st>>>(a);
     return hipGetLastError() == hipSuccess ? AZK_OK : AZK_ERR_HIP;

@@ -292,6 +292,15 @@ class PolicyValueNet:
         return r
 
     def _prepare_exact(self):
+        """The fp32-accurate kernels' tables, or nothing: weights outside the fixed fp16 (hi, lo) scales of those tables (conv weight
+        x 4096, tail weights x 256, constant-token softmax weights <= 1: the packers' range assertions) leave `_exact` None, exactly as a
+        configuration exact_fold() does not cover - the torch float32 forward then runs, and an in-place promotion reports False."""
+        try:
+            self._prepare_exact_tables()
+        except AssertionError:
+            self._exact, self.fused_embed_pool = None, False
+
+    def _prepare_exact_tables(self):
         import azk
         cfg = self.cfg
         self.fused_embed_pool = False

@@ -239,3 +239,26 @@ def test_runner_exact_evaluator_graph_stepping():
     a, b = play(True), play(False)
     for (pa, ca), (pb, cb) in zip(a, b):
         assert np.array_equal(ca, cb) and pa.tobytes() == pb.tobytes()
+
+
+def test_weights_outside_the_fp16_plane_scales_fall_back_to_the_torch_forward():
+    """The fp32-accurate tables carry weights as fp16 (hi, lo) terms at fixed scales (x 256 for the tail, x 4096 for the conv weight):
+    trained weights beyond those ranges must not raise in the middle of a promotion (PolicyValueNet.load_state_dict -> to()) - the
+    hand-written path steps aside (as for an uncovered configuration), the torch float32 forward answers, and the in-place
+    promotion reports False so that the owner of a captured graph re-captures."""
+    from pvnet import NetConfig, PolicyValueNet
+    cfg = NetConfig(15, 15, 2, 225, 5, 512, 8, 1)
+    net = PolicyValueNet(cfg, seed=0, device="cuda", dtype=torch.float32, path="clsfold")
+    assert net._exact is not None
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    sd["blocks.0.mlp.3.weight"] *= 4000.0                       # |w| x 256 no longer fits fp16
+    big = PolicyValueNet(cfg, weights=sd, device="cuda", dtype=torch.float32, path="clsfold")
+    assert big._exact is None
+    x = (torch.rand(4, 2, 15, 15, device="cuda") < 0.1).float()
+    ref = PolicyValueNet(cfg, weights=sd, device="cuda", dtype=torch.float32, path="full")
+    lb, vb = big(x)
+    lr, vr = ref(x)
+    assert torch.isfinite(lb).all() and (lb - lr).abs().max().item() <= 1e-3 * max(1.0, lr.abs().max().item())
+    assert net.load_state_dict(sd) is False and net._exact is None
+    l2, _ = net(x)
+    assert torch.equal(l2, lb)
