@@ -45,7 +45,8 @@ struct Dev {               // device view of the engine, passed to kernels by va
     int16_t *leaf_moves;   // [G][rc] valid moves at the leaf, reference list order
     uint8_t *leaf_flag;    // [G * K] 1 = this slot contributes a leaf to the evaluator batch this step
     int *to_move_v;        // [G * K] to_move of the slot's game (K > 1: what the leaf hand-off kernels index by slot)
-    const double *noise;   // [G][A] or nullptr
+    const double *noise;   // [G][A] or nullptr (asynchronous moves: [G][2][A], see noise_sel)
+    const long long *noise_sel;   // asynchronous moves: [G] the slot's move counter - its low bit selects the row of the game's CURRENT search; else nullptr
     // eval cache (MCTS.cache, ai/mcts.py:7,38-51): per-game direct-mapped table keyed by the exact canonical position
     int cache_entries, key_words;          // entries per game (power of two, 0 = off); 64-bit words per key
     unsigned long long *cache_key;         // [G][E][key_words] own-stone bit plane, opponent bit plane (+ side bit)
@@ -178,8 +179,10 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev dd, const float *__restri
     const int A = gd.action_dim, rc = gd.rc;
     const size_t base = (size_t)g * (size_t)d.cap;
     LdsView L = carve(gd, d.path_cap, d.table_size);
-    const bool stamp = (ablate & 16) != 0;
+    const bool wrec = DBG && (ablate & 8192) != 0;      // debug only: ONE record per wave and launch (overwritten), for the distribution of wave times
+    const bool stamp = (ablate & 16) != 0 || wrec;
     long long t0 = stamp ? clock64() : 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+    int rec_type = -1, rec_depth = 0, rec_nv = 0, rec_env = 0;   // wrec: -1 idle game, 0 terminal leaf, 1 eval-cache hit, 2 leaf for the evaluator
     int done_sims = MULTI ? d.sims_done[g] : 0;
     const int sim_target = MULTI ? d.budget[0] : 0, max_iter = MULTI ? d.budget[1] : 1;
     // a launch lasts as long as its slowest wave: a game whose simulation needed no evaluator starts another one only while the launch is
@@ -278,6 +281,7 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev dd, const float *__restri
             const int slot = uniform_i32(e_slot);
             const int depth = uniform_i32(e_depth);
             const int nv = uniform_i32(e_nv);
+            if (wrec) rec_env = nv;
             const int centry = d.cache_entries ? uniform_i32(e_centry) : -1;
             const bool hit = d.cache_entries && centry >= 0;
             const size_t crow = shared ? (size_t)(hit ? centry : -(centry + 1)) : ((size_t)g * d.cache_entries + (hit ? centry : -(centry + 1)));
@@ -300,10 +304,13 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev dd, const float *__restri
             const bool mix = depth == 0 && d.noise != nullptr;        // mcts.py:42-43,52-53
             double nzv[KSL] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
             if (mix) {
+                // asynchronous moves keep two rows per game - the current search's and the next one's, generated a whole search ahead
+                // (k_noise_ahead) - and the slot's move counter says which is which
+                const size_t nrow = (MULTI && d.noise_sel != nullptr) ? (size_t)g * 2 + (size_t)(uniform_i32((int)d.noise_sel[g]) & 1) : (size_t)g;
 #pragma unroll
                 for (int k4 = 0; k4 < KSL; k4++) {
                     const int i = lane + AZK_WAVE * k4;
-                    nzv[k4] = d.noise[(size_t)g * A + azk_action_idx(gd, i < nv ? e_mv[k4] : 0)];   // (a lane's e_mv beyond nv is stale memory)
+                    nzv[k4] = d.noise[nrow * A + azk_action_idx(gd, i < nv ? e_mv[k4] : 0)];   // (a lane's e_mv beyond nv is stale memory)
                 }
             }
             bool cache_write = d.cache_entries && !hit;               // MCTS.cache[board_key] = (...)  (mcts.py:51)
@@ -587,7 +594,9 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev dd, const float *__restri
             count_add(d, CNT_SIMS, g, 1);
             count_add(d, CNT_SCANNED, g, scanned);
         }
+        if (wrec) rec_depth = depth;
         if (term >= 0) {
+            if (wrec) { rec_type = 0; t3 = t4 = clock64(); }
             backup_path(d, base, L.path, depth, (double)term);
             if (lane == 0) {
                 d.leaf_flag[vi] = 0;
@@ -664,7 +673,8 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev dd, const float *__restri
             d.leaf_flag[vi] = cached ? 0 : (uint8_t)(1 + min(7, node_mc / 6));
             if (cached) count_add(d, CNT_CACHE_HITS, g, 1);
             count_add(d, CNT_LEAVES, g, cached ? 0 : 1);
-            if (stamp) {
+            if (wrec) { rec_type = cached ? 1 : 2; rec_nv = nv; }
+            if (stamp && !wrec) {
                 long long *q = d.dbg + (size_t)g * 8;
                 const long long tend = clock64();
                 q[0] += t1 - t0; q[1] += t2 - t1; q[2] += t3 - t2; q[3] += t4 - t3; q[4] += tend - t4; q[5] += depth; q[6] += 1;
@@ -677,6 +687,16 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev dd, const float *__restri
     break;
     }
     if (MULTI && lane0 == 0) d.sims_done[g] = done_sims;
+    if (wrec) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the wave's own stores are out: the record covers its whole life
+        if (lane0 == 0) {
+            long long *q = d.dbg + (size_t)g * 8;
+            const long long tend = clock64();
+            if (rec_type < 0) { t1 = t2 = t3 = t4 = tend; }
+            q[0] = t1 - t0; q[1] = t2 - t1; q[2] = t3 - t2; q[3] = t4 - t3; q[4] = tend - t4; q[5] = rec_depth;
+            q[6] = (long long)(rec_type + 1) | ((long long)rec_nv << 8) | ((long long)rec_env << 20); q[7] = tend - t0;
+        }
+    }
 }
 
 // Leaf compaction: slot = number of leaf games with a lower index (deterministic order); writes the
@@ -1237,13 +1257,13 @@ __device__ __forceinline__ void noise_row(int A, unsigned long long seed, unsign
 }
 
 __global__ __launch_bounds__(AZK_WAVE) void k_gen_noise(int A, unsigned long long seed, long long first_game, int move,
-                                                         double alpha, double *noise, double *uniforms) {
+                                                         double alpha, double *noise, double *uniforms, long long row_stride) {
     const int g = blockIdx.x, lane = azk_lane();
     const unsigned long long gg = (unsigned long long)(first_game + g);
     __shared__ double red[AZK_WAVE];
     if (uniforms && lane == 0) uniforms[g] = noise_uniform(seed, gg, move);
     if (!noise) return;
-    noise_row(A, seed, gg, move, alpha, noise + (size_t)g * A, red);
+    noise_row(A, seed, gg, move, alpha, noise + (size_t)g * (size_t)row_stride, red);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1261,14 +1281,20 @@ struct AsyncDev {
     long long first_game;
     double alpha;
     long long *slot_moves;     // [G] moves this slot has played since azk_async_begin (all its games): the RNG's move key
-    double *noise;             // [G][A] engine-owned: the Dirichlet row of each game's CURRENT search
+    double *noise;             // [G][2][A] engine-owned: row (k & 1) of game g is the Dirichlet row of its search with move key k, for the
+                               //   current key (slot_moves[g]) and the next one - generated a whole search ahead of its use
+    int *noise_key;            // [G] the highest move key whose row exists
+    int *todo_list, *todo_count;   // games that moved since the last drain: their row for key slot_moves[g] + 1 is due (k_noise_ahead)
     long long *stats;          // caller's int64 [16]: games, plies, wins 0 / 1, draws, moves, record cursor, searches begun
     long long rec_cap;
     int *rec_meta; double *rec_q; double *rec_pi;
     int *fin_list, *fin_count; // games found finished by the drain
 };
 
-// Node(None, None, player, move_count) + this search's noise row, for one game (one wave)
+// Node(None, None, player, move_count) for one game (one wave).  The search's Dirichlet row is NOT made here: a row's key (seed, global
+// game, slot move counter) is known a whole search before its use, so the rows are generated one search ahead, off the step's chain
+// (k_noise_ahead in the drain) - in this function the Marsaglia-Tsang chain (float64 log / cos / pow, two Philox blocks per try) cost a
+// moving game's wave ~30 us inside a launch every other wave had left after 1 us.
 __device__ __forceinline__ void begin_search_one(const Dev &d, const AsyncDev &p, int g, double *red) {
     const int lane = azk_lane();
     if (lane == 0) {
@@ -1280,7 +1306,27 @@ __device__ __forceinline__ void begin_search_one(const Dev &d, const AsyncDev &p
         d.sims_done[g] = 0;
         atomicAdd((unsigned long long *)&p.stats[7], 1ull);
     }
-    if (p.dirichlet) noise_row(d.g.action_dim, p.seed, (unsigned long long)(p.first_game + g), (int)p.slot_moves[g], p.alpha, p.noise + (size_t)g * d.g.action_dim, red);
+    (void)red;
+}
+
+// drain: the Dirichlet rows that fell due since the last drain - for every game that moved, the row of the search AFTER the one it has
+// just begun (key slot_moves[g] + 1, into the buffer the finished search read from)
+__global__ __launch_bounds__(AZK_WAVE) void k_noise_ahead(Dev d, AsyncDev p) {
+    __shared__ double red[AZK_WAVE];
+    const int n = *p.todo_count, A = d.g.action_dim;
+    for (int f = blockIdx.x; f < n; f += gridDim.x) {
+        const int g = p.todo_list[f];
+        const int key = (int)p.slot_moves[g] + 1;
+        if (uniform_i32(p.noise_key[g]) >= key) continue;
+        noise_row(A, p.seed, (unsigned long long)(p.first_game + g), key, p.alpha, p.noise + ((size_t)g * 2 + (size_t)(key & 1)) * A, red);
+        if (azk_lane() == 0) p.noise_key[g] = key;
+        __syncthreads();
+    }
+}
+
+__global__ void k_fill_i32(int *p, int n, int v) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
 }
 
 __global__ __launch_bounds__(AZK_WAVE) void k_move_async(Dev d, AsyncDev p) {
@@ -1290,8 +1336,13 @@ __global__ __launch_bounds__(AZK_WAVE) void k_move_async(Dev d, AsyncDev p) {
     up = lane == 1 ? d.sims_done + g : up;
     up = lane == 2 ? d.leaf_node + g : up;
     up = lane == 3 ? d.budget : up;                                // (the simulation budget lives in device memory: azk_async_set_budget)
+    up = (lane == 4 && p.dirichlet) ? p.noise_key + g : up;
+    up = lane == 5 ? (const int *)(p.slot_moves + g) : up;         // (low word: a slot plays far fewer than 2^31 moves)
     const int uw = *up;
     if (__builtin_amdgcn_readlane(uw, 0) != 0 || __builtin_amdgcn_readlane(uw, 1) < __builtin_amdgcn_readlane(uw, 3) || __builtin_amdgcn_readlane(uw, 2) >= 0) return;
+    // the next search's Dirichlet row is made a search ahead (k_noise_ahead, every drain); a game whose whole search fitted between two
+    // drains (tiny budgets only) waits for it - a scheduling delay, the game's moves do not change
+    if (p.dirichlet && __builtin_amdgcn_readlane(uw, 4) < __builtin_amdgcn_readlane(uw, 5) + 1) return;
     LdsView L = carve(d.g, d.path_cap, d.table_size);
     const int A = d.g.action_dim;
     const size_t base = (size_t)g * d.cap;
@@ -1314,11 +1365,12 @@ __global__ __launch_bounds__(AZK_WAVE) void k_move_async(Dev d, AsyncDev p) {
     }
     __syncthreads();
     if (lane == 0) {
-        p.slot_moves[g] = mv + 1;
+        p.slot_moves[g] = mv + 1;                                  // the NEW search's key: its row (mv + 1) & 1 has been waiting since the last move
         atomicAdd((unsigned long long *)&p.stats[5], 1ull);
+        if (p.dirichlet) p.todo_list[atomicAdd(p.todo_count, 1)] = g;          // row mv + 2 is due
     }
     __syncthreads();
-    if (!dn) begin_search_one(d, p, g, L.cdf);                      // (slot_moves[g] is the NEW search's key; re-read inside)
+    if (!dn) begin_search_one(d, p, g, L.cdf);
 }
 
 // drain, step 1: list the finished games (done == 1) - the emission and restart kernels work through the list only
@@ -1626,7 +1678,7 @@ int32_t azk_set_positions(azk_engine *e, int32_t first, int32_t count, const int
 
 int32_t azk_begin_search(azk_engine *e, const double *noise_dev, void *stream) {
     if (!e) return AZK_ERR_ARG;
-    e->d.noise = noise_dev;
+    e->d.noise = noise_dev; e->d.noise_sel = nullptr;
     e->multi = false;
     k_begin_search<<<(unsigned)((e->d.G + 255) / 256), 256, 0, (hipStream_t)stream>>>(e->d);
     HIPCHK(e, hipGetLastError());
@@ -1635,7 +1687,7 @@ int32_t azk_begin_search(azk_engine *e, const double *noise_dev, void *stream) {
 
 int32_t azk_begin_search_budget(azk_engine *e, const double *noise_dev, int32_t n_sims, int32_t max_sims_per_launch, void *stream) {
     if (!e || n_sims < 1 || n_sims > e->cfg.max_sims || max_sims_per_launch < 1) { if (e) e->err = "azk_begin_search_budget: bad argument"; return AZK_ERR_ARG; }
-    e->d.noise = noise_dev;
+    e->d.noise = noise_dev; e->d.noise_sel = nullptr;
     e->multi = true;
     if (e->budget_host[0] != n_sims || e->budget_host[1] != (e->d.K > 1 ? e->d.K : max_sims_per_launch)) {
         // the budget lives in device memory so that a captured step graph keeps working when it changes
@@ -1662,7 +1714,10 @@ int32_t azk_async_begin(azk_engine *e, const azk_async_config *c, void *stream) 
     AsyncDev &a = e->ad;
     if (!a.slot_moves) {
         HIPCHK(e, dalloc(e, &a.slot_moves, (size_t)d.G));
-        HIPCHK(e, dalloc(e, &a.noise, (size_t)d.G * d.g.action_dim));
+        HIPCHK(e, dalloc(e, &a.noise, (size_t)d.G * 2 * d.g.action_dim));
+        HIPCHK(e, dalloc(e, &a.noise_key, (size_t)d.G));
+        HIPCHK(e, dalloc(e, &a.todo_list, (size_t)d.G));
+        HIPCHK(e, dalloc(e, &a.todo_count, 1));
         HIPCHK(e, dalloc(e, &a.fin_list, (size_t)d.G));
         HIPCHK(e, dalloc(e, &a.fin_count, 1));
     }
@@ -1678,11 +1733,18 @@ int32_t azk_async_begin(azk_engine *e, const azk_async_config *c, void *stream) 
     HIPCHK(e, hipMemcpyAsync(d.budget, e->budget_host, sizeof e->budget_host, hipMemcpyHostToDevice, st));
     HIPCHK(e, hipStreamSynchronize(st));
     d.noise = a.dirichlet ? a.noise : nullptr;
+    d.noise_sel = a.dirichlet ? a.slot_moves : nullptr;
     e->multi = true;
     e->async_on = true;
-    // first search of every game: fresh roots + the Dirichlet rows of move key 0
+    // first search of every game: fresh roots + the Dirichlet rows of move keys 0 (this search) and 1 (the next one)
     k_begin_search<<<(unsigned)((d.G + 255) / 256), 256, 0, st>>>(d);
-    if (a.dirichlet) k_gen_noise<<<d.G, AZK_WAVE, 0, st>>>(d.g.action_dim, a.seed, a.first_game, 0, a.alpha, a.noise, nullptr);
+    HIPCHK(e, hipMemsetAsync(a.todo_count, 0, sizeof(int), st));
+    if (a.dirichlet) {
+        const int A = d.g.action_dim;
+        k_gen_noise<<<d.G, AZK_WAVE, 0, st>>>(A, a.seed, a.first_game, 0, a.alpha, a.noise, nullptr, 2LL * A);
+        k_gen_noise<<<d.G, AZK_WAVE, 0, st>>>(A, a.seed, a.first_game, 1, a.alpha, a.noise + A, nullptr, 2LL * A);
+        k_fill_i32<<<(unsigned)((d.G + 255) / 256), 256, 0, st>>>(a.noise_key, d.G, 1);
+    }
     HIPCHK(e, hipGetLastError());
     return AZK_OK;
 }
@@ -1720,6 +1782,10 @@ int32_t azk_async_drain(azk_engine *e, float *states_dev, double *pis_dev, float
         k_emit_mark<<<(unsigned)((d.G + 255) / 256), 256, 0, st>>>(d);
     }
     k_async_restart<<<(unsigned)(d.G < 256 ? d.G : 256), AZK_WAVE, d.lds_bytes, st>>>(d, e->ad, e->async_recycle);
+    if (e->ad.dirichlet) {                                        // the rows of the searches AFTER the ones begun since the last drain
+        k_noise_ahead<<<(unsigned)(d.G < 512 ? d.G : 512), AZK_WAVE, 0, st>>>(d, e->ad);
+        HIPCHK(e, hipMemsetAsync(e->ad.todo_count, 0, sizeof(int), st));
+    }
     HIPCHK(e, hipGetLastError());
     return AZK_OK;
 }
@@ -2039,6 +2105,11 @@ int32_t azk_debug_stamps(azk_engine *e, int64_t *out8_host) {
     return AZK_OK;
 }
 
+int32_t azk_debug_stamps_raw(azk_engine *e, int64_t *out_host, int32_t n_games) {
+    if (!e || !out_host || n_games != e->d.G) return AZK_ERR_ARG;
+    return hipMemcpy(out_host, e->d.dbg, (size_t)e->d.G * 8 * sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess ? AZK_OK : AZK_ERR_HIP;
+}
+
 int32_t azk_reset_counters(azk_engine *e, void *stream) {
     if (!e) return AZK_ERR_ARG;
     HIPCHK(e, hipMemsetAsync(e->d.counters, 0, sizeof(long long) * CNT_N * e->d.G, (hipStream_t)stream));
@@ -2059,7 +2130,7 @@ int32_t azk_gen_noise(azk_engine *e, uint64_t seed, int64_t first_global_game, i
                       double *noise_dev, double *uniforms_dev, void *stream) {
     if (!e || alpha <= 0.0) return AZK_ERR_ARG;
     k_gen_noise<<<e->d.G, AZK_WAVE, 0, (hipStream_t)stream>>>(e->d.g.action_dim, seed, first_global_game, move_index, alpha,
-                                                            noise_dev, uniforms_dev);
+                                                            noise_dev, uniforms_dev, (long long)e->d.g.action_dim);
     HIPCHK(e, hipGetLastError());
     return AZK_OK;
 }

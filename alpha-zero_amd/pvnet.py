@@ -993,6 +993,8 @@ class PolicyValueNet:
         depth = self.cfg.depth
         if path == "clsfold" and self._exact is not None:
             return self.forward_exact(x)
+        if path == "clsfold" and self._fold is None and self.dtype == torch.float32:
+            path = "cls"    # a float32 network the hand-written kernels do not cover (configuration, or weights outside the fp16-plane scales): the torch float32 forward, same function
         if path == "clsfold":
             if self._fold is None:
                 raise RuntimeError("path 'clsfold' needs the HIP kernels (CUDA, bf16, supported embed_dim/heads)")

@@ -227,6 +227,10 @@ int32_t azk_reset_counters(azk_engine *e, void *stream);
 /* debug only: per-phase shader-clock sums of k_tree (collected when AZK_TREE_ABLATE has bit 16): expand, board+root
  * load, walk, terminal test, valid moves, writes (cycles), then summed depth and sample count.  Synchronises. */
 int32_t azk_debug_stamps(azk_engine *e, int64_t *out8_host);
+/* debug only: the raw [n_games][8] stamp records (AZK_TREE_ABLATE bit 8192: one record per wave of the LAST k_tree launch - cycles of
+ * expansion, walk, terminal test, legal moves, leaf writes + cache probe; depth; kind + 1 | legal moves << 8 | children created << 20;
+ * the wave's whole life).  Synchronises. */
+int32_t azk_debug_stamps_raw(azk_engine *e, int64_t *out_host, int32_t n_games);
 /* sticky device-side error word (arena overflow etc.); synchronises; returns AZK_OK or the error */
 int32_t azk_check_device_error(azk_engine *e, void *stream);
 

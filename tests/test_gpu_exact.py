@@ -251,7 +251,7 @@ def test_weights_outside_the_fp16_plane_scales_fall_back_to_the_torch_forward():
     net = PolicyValueNet(cfg, seed=0, device="cuda", dtype=torch.float32, path="clsfold")
     assert net._exact is not None
     sd = {k: v.clone() for k, v in net.state_dict().items()}
-    sd["blocks.0.mlp.3.weight"] *= 4000.0                       # |w| x 256 no longer fits fp16
+    sd["blocks.0.mlp.3.weight"] *= 1.0e5                       # |w| x 256 no longer fits fp16
     big = PolicyValueNet(cfg, weights=sd, device="cuda", dtype=torch.float32, path="clsfold")
     assert big._exact is None
     x = (torch.rand(4, 2, 15, 15, device="cuda") < 0.1).float()
