@@ -108,3 +108,67 @@ def test_async_replay_emission_equals_lockstep():
             break
     assert int(a.finish()[0]) == G
     assert ra.size() == rb.size() > 100 and digest(ra) == digest(rb)
+
+
+def test_async_production_path_play_move_with_a_small_record_ring():
+    """The path bench.py drives: play_move() / run_until_moves() - statistics read ONE CHUNK LATE from the ping-pong pinned buffers,
+    move records delivered on the copy stream while the next chunk is already writing the ring, no finish() inside the loop - with a
+    record ring only a few chunks deep.  Every record delivered equals the lock-step runner's (slot, move) record, none is delivered
+    twice, and the tiny search budget (a whole search fits between two drains) exercises the wait for the next search's Dirichlet row."""
+    from selfplay import AsyncSelfPlayRunner
+    A, G, sims, moves = 49, 32, 12, 30
+    ev = lambda x: fixture_logits_value(x, A, "hash")
+    want, _ = lockstep_records("gomoku", ev, G, sims, moves + 12, 7, 11, cache_entries=64)
+    rec = {}
+
+    def on(meta, q, pi):
+        for i in range(len(meta)):
+            key = (int(meta[i, 0]), int(meta[i, 1]))
+            assert key not in rec, key
+            rec[key] = (pi[i].tobytes(), float(q[i]), int(meta[i, 2]), int(meta[i, 3]))
+    r = AsyncSelfPlayRunner("gomoku", ev, G, sims, size=7, seed=11, recycle=True, on_records=on, cache_entries=64, per_launch=2, steps_per_graph=8,
+                            use_graph=False, record_capacity=6 * G)
+    for _ in range(moves):
+        r.play_move()                                           # returns once the batch has played G more moves; looks one chunk late
+    seen_before_finish = len(rec)
+    r.finish()
+    r.check_error()
+    assert seen_before_finish >= (moves - 4) * G and len(rec) == int(r._seen[5]) >= moves * G
+    for key, val in rec.items():
+        if key in want:
+            assert val == want[key], key
+    assert sum(1 for k in rec if k in want) >= moves * G * 3 // 4
+
+
+def test_clearing_the_shared_cache_in_the_middle_of_a_search_changes_nothing():
+    """bench.py --train-step promotes weights between moves and clears the eval cache (main.py:55-57) while asynchronous games are in
+    the middle of their searches, with pending leaves and cache claims: the cache is transparent, so the records with a clear after
+    every chunk equal the records of a run that never clears (and of a run without a cache)."""
+    from selfplay import AsyncSelfPlayRunner
+    A, G, sims, moves = 49, 24, 40, 12
+    ev = lambda x: fixture_logits_value(x, A, "hash")
+
+    def run(cache_entries, clear):
+        rec = {}
+
+        def on(meta, q, pi):
+            for i in range(len(meta)):
+                rec[(int(meta[i, 0]), int(meta[i, 1]))] = (pi[i].tobytes(), float(q[i]), int(meta[i, 2]), int(meta[i, 3]))
+        r = AsyncSelfPlayRunner("gomoku", ev, G, sims, size=7, seed=3, recycle=True, on_records=on, cache_entries=cache_entries, cache_shared=cache_entries > 0,
+                                per_launch=2, steps_per_graph=4, use_graph=False)
+        for _ in range(4000):
+            r.run_chunk()
+            if clear:
+                r.eng.clear_cache()
+            r.finish()
+            if all((g, moves - 1) in rec for g in range(G)):
+                break
+        r.check_error()
+        return rec, r.counters()
+    plain, _ = run(0, False)
+    cached, c1 = run(128, False)
+    cleared, c2 = run(128, True)
+    assert c1["cache_hits"] > c2["cache_hits"] >= 0 and c1["cache_hits"] > 0
+    for g in range(G):
+        for mv in range(moves):
+            assert cached[(g, mv)] == plain[(g, mv)] and cleared[(g, mv)] == plain[(g, mv)], (g, mv)
