@@ -34,7 +34,7 @@ SYMBOLS = [
     "azk_leaf_source_of", "azk_nn_embed_pool_leaves", "azk_nn_embed_pool_compact", "azk_nn_embed_pool_compact_leaves",
     "azk_nn_embed_fold", "azk_nn_embed_fold_leaves", "azk_nnx_embed_fold", "azk_nnx_embed_fold_leaves",
     "azk_nn_tail_gemm", "azk_nn_tail_gemm_lds", "azk_begin_search_budget", "azk_search_unfinished",
-    "azk_nnx_embed_pool", "azk_nnx_embed_pool_leaves", "azk_nnx_gemm", "azk_nnx_gemm_h",
+    "azk_nnx_embed_pool", "azk_nnx_embed_pool_leaves", "azk_nnx_gemm", "azk_nnx_gemm_h", "azk_nnx_gemm_h_lds",
     "azk_async_begin", "azk_async_step", "azk_async_drain", "azk_async_set_budget",
 ]
 
@@ -217,6 +217,7 @@ def lib():
     L.azk_nnx_embed_pool_leaves.argtypes = [C.POINTER(LeafSource), C.POINTER(EmbedPoolXConsts), vp, vp, vp]
     L.azk_nnx_gemm.argtypes = [C.POINTER(GemmX), vp]
     L.azk_nnx_gemm_h.argtypes = [C.POINTER(GemmH), vp]
+    L.azk_nnx_gemm_h_lds.argtypes = [C.POINTER(GemmH), vp]
     L.azk_async_begin.argtypes = [vp, C.POINTER(AsyncConfig), vp]
     L.azk_async_step.argtypes = [vp, vp, vp, i32, vp]
     L.azk_async_set_budget.argtypes = [vp, i32, i32, vp]
@@ -1355,7 +1356,7 @@ def pack_linear_weight_h(w):
 
 
 def nnx_gemm_h(a, w_packed, n_out, k, epilogue=TAIL_BF16, nbatch=1, a_batch_stride=0, bias=None, col_sums=None, out=None, out_f32=None,
-               resid=None, a_stats=None, stats_out=None, logits=None, values=None, action_dim=0, count=None, eps=1e-5):
+               resid=None, a_stats=None, stats_out=None, logits=None, values=None, action_dim=0, count=None, eps=1e-5, lds=False):
     """One link of the fp32-accurate tail on fp16 (hi, lo) planes (azk_nnx_gemm_h).  a: a float32 tensor [m, lda] (split on the fly)
     or a (hi, lo) pair of fp16 tensors; out: a (hi, lo) pair of fp16 tensors [m, nbatch * n_out] and / or out_f32."""
     torch = _torch()
@@ -1388,6 +1389,6 @@ def nnx_gemm_h(a, w_packed, n_out, k, epilogue=TAIL_BF16, nbatch=1, a_batch_stri
         d.resid_f32, d.ldr = resid.data_ptr(), resid.stride(0)
     if logits is not None:
         d.logits_out, d.values_out, d.action_dim = logits.data_ptr(), values.data_ptr(), int(action_dim)
-    rc = lib().azk_nnx_gemm_h(C.byref(d), _stream())
+    rc = (lib().azk_nnx_gemm_h_lds if lds else lib().azk_nnx_gemm_h)(C.byref(d), _stream())
     if rc != 0:
-        raise AzkError(f"azk_nnx_gemm_h failed ({rc})")
+        raise AzkError(f"azk_nnx_gemm_h{'_lds' if lds else ''} failed ({rc})")

@@ -488,8 +488,9 @@ class PolicyValueNet:
         else:
             self._launch(G, z.view(n, H * D), e["WvH"], D // H, D, azk.TAIL_BF16, nbatch=H, a_batch_stride=D, out=pl("u"), count=cnt)
         self._launch(G, pl("u"), e["WoH"], D, D, azk.TAIL_BF16, bias=e["bias1"], out=pl("x1"), out_f32=ws["x1f"][:n], stats_out=ws["st1"][:n], count=cnt)
-        self._launch(G, pl("x1"), e["W0GH"], 4 * D, D, azk.TAIL_GELU, bias=e["b0G"], col_sums=e["W0GH_csum"], out=pl("hh"), a_stats=ws["st1"][:n], count=cnt)
-        self._launch(G, pl("hh"), e["W3H"], D, 4 * D, azk.TAIL_RESID, bias=e["b3"], resid=ws["x1f"][:n], out=pl("x2"), stats_out=ws["st2"][:n], count=cnt)
+        lds = getattr(self, "use_lds_tail", True)        # the two wide links LDS-staged (azk_nnx_gemm_h_lds, csrc/azk_tail.hip): same chains, same epilogue
+        self._launch(G, pl("x1"), e["W0GH"], 4 * D, D, azk.TAIL_GELU, bias=e["b0G"], col_sums=e["W0GH_csum"], out=pl("hh"), a_stats=ws["st1"][:n], count=cnt, lds=lds)
+        self._launch(G, pl("hh"), e["W3H"], D, 4 * D, azk.TAIL_RESID, bias=e["b3"], resid=ws["x1f"][:n], out=pl("x2"), stats_out=ws["st2"][:n], count=cnt, lds=lds)
         if self.out_buffers is not None:
             lb, vb = self.out_buffers
         else:

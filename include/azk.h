@@ -575,6 +575,10 @@ typedef struct azk_gemm_h {
     float *logits_out, *values_out; int32_t action_dim;
 } azk_gemm_h;
 int32_t azk_nnx_gemm_h(const azk_gemm_h *desc, void *stream);
+/* azk_nnx_gemm_h_lds - the same descriptor, the two WIDE links (k = 512 -> n_out, LayerNorm + GELU; k = 2048, residual) with both
+ * operand planes staged through LDS by LDS-DMA (csrc/azk_tail.hip, as azk_nn_tail_gemm_lds): the same accumulation chains in the same
+ * order and the same epilogue arithmetic as azk_nnx_gemm_h.  (a_hi, a_lo) planes only, nbatch = 1; anything else: AZK_ERR_ARG. */
+int32_t azk_nnx_gemm_h_lds(const azk_gemm_h *desc, void *stream);
 
 /* ---- vanilla mode: MCTS.mcts(model=None, ...) (mcts.py:57-59), MCTS.simulate (mcts.py:62-79), UCB1 of
  * utils.py:29-44 mode 'normal'.  A search is azk_begin_search(e, NULL) followed by azk_vanilla_search calls summing to

@@ -107,3 +107,57 @@ def test_whole_chain_with_lds_links_matches_the_register_chain():
     net.tail_fast(z)
     torch.cuda.synchronize()
     assert (lr - outs[2048][0]).abs().max().item() < 3e-2 and (vr - outs[2048][1]).abs().max().item() < 1e-2
+
+
+@pytest.mark.parametrize("m,live", [(917, None), (2048, 1100), (100, 37), (2048, 2048)])
+def test_fp16_plane_links_are_bit_identical_to_the_register_form(m, live):
+    """The fp32-accurate tail's two wide links on (hi, lo) fp16 planes, LDS-staged (azk_nnx_gemm_h_lds) against the register form
+    (azk_nnx_gemm_h): the same accumulation chains in the same order and the same epilogue arithmetic - every output bit for bit
+    (float32 rows, both planes, row statistics), for both tilings of each link (the in-kernel switch at 1024 live rows)."""
+    import azk
+    g = torch.Generator("cuda").manual_seed(77 + m)
+    D = 512
+    cnt = torch.tensor([live], dtype=torch.int32, device="cuda") if live is not None else None
+    nl = m if live is None else live
+
+    def planes(x):
+        hi, lo = azk.split_fp16(x.double() , azk.GEMM_H_A_SCALE)
+        return hi.contiguous(), lo.contiguous()
+    # link 3: LayerNorm (epilogue) + 512 -> 2048 + GELU
+    x1 = torch.randn(m, D, device="cuda", generator=g) * 1.3 + 0.2
+    w0 = torch.randn(4 * D, D, device="cuda", generator=g) * 0.05
+    wp, csum = azk.pack_linear_weight_h(w0)
+    bias = torch.randn(4 * D, device="cuda", generator=g) * 0.1
+    st = torch.stack([x1.view(m, 8, 64).sum(2), (x1 ** 2).view(m, 8, 64).sum(2)], dim=2).contiguous()
+    res = []
+    for lds in (False, True):
+        oh, ol = torch.full((m, 4 * D), 7.0, device="cuda", dtype=torch.float16), torch.full((m, 4 * D), 7.0, device="cuda", dtype=torch.float16)
+        azk.nnx_gemm_h(planes(x1), wp, 4 * D, D, azk.TAIL_GELU, bias=bias, col_sums=csum, out=(oh, ol), a_stats=st, count=cnt, lds=lds)
+        torch.cuda.synchronize()
+        res.append((oh, ol))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert bool((res[1][0][nl:].float() == 7.0).all())
+    xd = x1[:nl].double()
+    mean = xd.mean(1, keepdim=True)
+    xn = (xd - mean) / torch.sqrt((xd * xd).mean(1, keepdim=True) - mean * mean + 1e-5)
+    ref = torch.nn.functional.gelu(xn @ w0.double().t() + bias.double())
+    got = (res[1][0][:nl].double() + res[1][1][:nl].double()) / azk.GEMM_H_A_SCALE
+    assert (got - ref).abs().max().item() < 2e-4
+    # link 4: 2048 -> 512 + bias + float32 residual, float32 rows + planes + row statistics
+    hh = torch.randn(m, 4 * D, device="cuda", generator=g) * 0.4
+    w3 = torch.randn(D, 4 * D, device="cuda", generator=g) * 0.03
+    wp3, _ = azk.pack_linear_weight_h(w3)
+    b3 = torch.randn(D, device="cuda", generator=g) * 0.1
+    xr = torch.randn(m, D, device="cuda", generator=g)
+    res = []
+    for lds in (False, True):
+        oh, ol = torch.full((m, D), 7.0, device="cuda", dtype=torch.float16), torch.full((m, D), 7.0, device="cuda", dtype=torch.float16)
+        of, so = torch.full((m, D), 7.0, device="cuda"), torch.full((m, D // 64, 2), 7.0, device="cuda")
+        azk.nnx_gemm_h(planes(hh), wp3, D, 4 * D, azk.TAIL_RESID, bias=b3, resid=xr, out=(oh, ol), out_f32=of, stats_out=so, count=cnt, lds=lds)
+        torch.cuda.synchronize()
+        res.append((oh, ol, of, so))
+    for a_, b_ in zip(res[0], res[1]):
+        assert torch.equal(a_, b_)
+    assert bool((res[1][2][nl:] == 7.0).all()) and bool((res[1][3][nl:] == 7.0).all())
+    ref = hh[:nl].double() @ w3.double().t() + b3.double() + xr[:nl].double()
+    assert (res[1][2][:nl].double() - ref).abs().max().item() < 2e-4

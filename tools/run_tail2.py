@@ -50,3 +50,13 @@ for rnd in range(2):
         t3 = timeit(lambda: azk.nn_tail_gemm(x1, f["W0GP"], 4 * D, D, azk.TAIL_GELU, bias=f["b0G_f"], out=o3, a_stats=st, count=cnt, col_sums=f["W0GP_csum"] if lds else None, lds=lds))
         t4 = timeit(lambda: azk.nn_tail_gemm(hh, f["W3P"], D, 4 * D, azk.TAIL_RESID, bias=f["b3_f"], resid=x1, out=o4, stats_out=st2, count=cnt, lds=lds))
         print(f"round {rnd} lds={lds}: link 3 (512 -> 2048, GELU) {t3:.2f} us   link 4 (2048 -> 512, residual) {t4:.2f} us   (back-to-back launches of the same link)")
+
+# the fp32-accurate tail (fp16 hi / lo planes): k_gemm_h x 5, with the two wide links LDS-staged or in registers
+netx = PolicyValueNet(cfg, seed=0, device="cuda", dtype=torch.float32, path="clsfold")
+zx = torch.randn(n, 8, azk.EMBED_FOLD_ROW, device="cuda") * 0.05
+netx.live_count = net.live_count
+netx.out_buffers = net.out_buffers
+for rnd in range(2):
+    for lds in (True, False):
+        netx.use_lds_tail = lds
+        print(f"round {rnd} fp32-accurate tail, wide links {'LDS-staged' if lds else 'in registers'}: rows {n} live {live}: {timeit(lambda: netx.tail_exact_h(zx)):.2f} us per tail")
