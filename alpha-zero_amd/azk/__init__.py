@@ -33,7 +33,7 @@ SYMBOLS = [
     "azk_nn_gemm_rows", "azk_nn_layernorm_sum", "azk_nn_heads_finalize_sum", "azk_nn_ln_heads",
     "azk_leaf_source_of", "azk_nn_embed_pool_leaves", "azk_nn_embed_pool_compact", "azk_nn_embed_pool_compact_leaves",
     "azk_nn_embed_fold", "azk_nn_embed_fold_leaves", "azk_nnx_embed_fold", "azk_nnx_embed_fold_leaves",
-    "azk_nn_tail_gemm", "azk_nn_tail_gemm_lds", "azk_begin_search_budget", "azk_search_unfinished",
+    "azk_nn_tail_gemm", "azk_nn_tail_gemm_lds", "azk_nn_gemm_tok", "azk_nn_attention_tok", "azk_begin_search_budget", "azk_search_unfinished",
     "azk_nnx_embed_pool", "azk_nnx_embed_pool_leaves", "azk_nnx_gemm", "azk_nnx_gemm_h", "azk_nnx_gemm_h_lds",
     "azk_async_begin", "azk_async_step", "azk_async_drain", "azk_async_set_budget",
 ]
@@ -81,6 +81,13 @@ class TailGemm(C.Structure):
                 ("a_stats", C.c_void_p), ("a_stats_groups", C.c_int32), ("stats_out", C.c_void_p),
                 ("out_bf16", C.c_void_p), ("ldo", C.c_int32), ("resid_bf16", C.c_void_p), ("ldr", C.c_int32),
                 ("logits_out", C.c_void_p), ("values_out", C.c_void_p), ("action_dim", C.c_int32), ("a_col_sums", C.c_void_p)]
+
+
+class GemmTok(C.Structure):
+    """azk_gemm_tok (include/azk.h): the LDS-staged GEMM of the full-token transformer block."""
+    _fields_ = [("a_bf16", C.c_void_p), ("lda", C.c_int32), ("w_packed", C.c_void_p), ("m", C.c_int32), ("n_out", C.c_int32), ("k", C.c_int32),
+                ("n_valid", C.c_void_p), ("bias", C.c_void_p), ("epilogue", C.c_int32), ("out", C.c_void_p), ("ldo", C.c_int32),
+                ("resid_bf16", C.c_void_p), ("ldr", C.c_int32)]
 
 
 class EmbedPoolXConsts(C.Structure):
@@ -213,6 +220,8 @@ def lib():
     L.azk_search_unfinished.argtypes = [vp, vp, vp]
     L.azk_nn_tail_gemm.argtypes = [C.POINTER(TailGemm), vp]
     L.azk_nn_tail_gemm_lds.argtypes = [C.POINTER(TailGemm), vp]
+    L.azk_nn_gemm_tok.argtypes = [C.POINTER(GemmTok), vp]
+    L.azk_nn_attention_tok.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp]
     L.azk_nnx_embed_pool.argtypes = [vp, i32, C.POINTER(EmbedPoolXConsts), vp, i32, i32, i32, i32, vp, vp, vp]
     L.azk_nnx_embed_pool_leaves.argtypes = [C.POINTER(LeafSource), C.POINTER(EmbedPoolXConsts), vp, vp, vp]
     L.azk_nnx_gemm.argtypes = [C.POINTER(GemmX), vp]
@@ -1010,6 +1019,58 @@ def nn_tail_gemm(a, w_packed, n_out, k, epilogue=TAIL_BF16, nbatch=1, a_batch_st
     rc = (lib().azk_nn_tail_gemm_lds if lds else lib().azk_nn_tail_gemm)(C.byref(d), _stream())
     if rc != 0:
         raise AzkError(f"azk_nn_tail_gemm{'_lds' if lds else ''} failed ({rc})")
+
+
+TOK_BF16, TOK_GELU, TOK_RESID, TOK_F32 = 0, 1, 2, 4
+
+
+def pack_linear_weight128(w):
+    """pack_linear_weight with the output dimension padded (zero rows) to a multiple of 128: the operand of nn_gemm_tok."""
+    torch = _torch()
+    n_out, k = w.shape
+    npad = (n_out + 127) // 128 * 128
+    wp = torch.zeros(npad, k, dtype=torch.float32, device=w.device)
+    wp[:n_out] = w.float()
+    return pack_linear_weight(wp)
+
+
+def nn_gemm_tok(a, w_packed, n_out, epilogue=TOK_BF16, bias=None, out=None, resid=None, count=None):
+    """out[m][n_out] = a[m][k] W^T (+ bias) through an epilogue (azk_nn_gemm_tok, csrc/azk_block.hip).  a: bf16 [m, k] (row stride
+    a.stride(0)); w_packed: pack_linear_weight128(W); n_out: the padded output width (a multiple of 128); out: bf16 (float32 for
+    TOK_F32) [m, >= n_out], allocated when None; resid: bf16 [m, >= n_out] for TOK_RESID."""
+    torch = _torch()
+    assert a.dtype == torch.bfloat16 and a.dim() == 2 and a.stride(1) == 1 and n_out % 128 == 0
+    m, k = a.shape
+    if out is None:
+        out = torch.empty((m, n_out), dtype=torch.float32 if epilogue == TOK_F32 else torch.bfloat16, device=a.device)
+    assert out.stride(1) == 1 and out.dtype == (torch.float32 if epilogue == TOK_F32 else torch.bfloat16)
+    d = GemmTok()
+    d.a_bf16, d.lda, d.w_packed, d.m, d.n_out, d.k = a.data_ptr(), a.stride(0), w_packed.data_ptr(), m, int(n_out), k
+    d.n_valid = count.data_ptr() if count is not None else None
+    if bias is not None:
+        assert bias.dtype == torch.float32 and bias.numel() >= n_out
+        d.bias = bias.data_ptr()
+    d.epilogue, d.out, d.ldo = int(epilogue), out.data_ptr(), out.stride(0)
+    if resid is not None:
+        assert resid.dtype == torch.bfloat16 and resid.stride(1) == 1
+        d.resid_bf16, d.ldr = resid.data_ptr(), resid.stride(0)
+    rc = lib().azk_nn_gemm_tok(C.byref(d), _stream())
+    if rc != 0:
+        raise AzkError(f"azk_nn_gemm_tok failed ({rc})")
+    return out
+
+
+def nn_attention_tok(qkv, n_boards, tokens, embed_dim, num_heads, out=None, count=None):
+    """softmax(q k^T / sqrt(dh)) v over all tokens of every board (azk_nn_attention_tok).  qkv: bf16 [n_boards * tokens, 3 embed_dim]."""
+    torch = _torch()
+    assert qkv.dtype == torch.bfloat16 and qkv.is_contiguous() and qkv.shape == (n_boards * tokens, 3 * embed_dim)
+    if out is None:
+        out = torch.empty((n_boards * tokens, embed_dim), dtype=torch.bfloat16, device=qkv.device)
+    assert out.is_contiguous() and out.dtype == torch.bfloat16
+    rc = lib().azk_nn_attention_tok(_p(qkv), _p(out), int(n_boards), int(tokens), int(embed_dim), int(num_heads), _p(count), _stream())
+    if rc != 0:
+        raise AzkError(f"azk_nn_attention_tok failed ({rc})")
+    return out
 
 
 def packed_weight_col_sums(w_packed, n_out, k):

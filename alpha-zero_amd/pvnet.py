@@ -108,6 +108,8 @@ def _same_structure(a, b):
                 and a.device == b.device)
     if isinstance(a, dict) or isinstance(b, dict):
         return isinstance(a, dict) and isinstance(b, dict) and a.keys() == b.keys() and all(_same_structure(a[k_], b[k_]) for k_ in a)
+    if isinstance(a, (list, tuple)) or isinstance(b, (list, tuple)):
+        return type(a) is type(b) and len(a) == len(b) and all(_same_structure(x_, y_) for x_, y_ in zip(a, b))
     if hasattr(a, "t") and isinstance(getattr(a, "t"), dict):           # azk.EmbedPoolTables / EmbedPoolXTables: their tensors live in .t
         return type(a) is type(b) and _same_structure(a.t, b.t)
     return type(a) is type(b) and (a is None or not isinstance(a, (int, float, str, bool)) or a == b)
@@ -120,6 +122,9 @@ def _copy_into(dst, src):
     elif isinstance(dst, dict):
         for k_ in dst:
             _copy_into(dst[k_], src[k_])
+    elif isinstance(dst, (list, tuple)):
+        for d_, s_ in zip(dst, src):
+            _copy_into(d_, s_)
     elif hasattr(dst, "t") and isinstance(getattr(dst, "t"), dict):
         _copy_into(dst.t, src.t)
 
@@ -179,7 +184,7 @@ class PolicyValueNet:
         want = reference_key_shapes(self.cfg)
         for k_, shape in want.items():
             assert k_ in sd and tuple(sd[k_].shape) == tuple(shape), k_
-        names = ("w", "_hip", "_fold", "_compact", "_exact", "_foldu")
+        names = ("w", "_hip", "_fold", "_compact", "_exact", "_foldu", "_blocks")
         old = {n_: getattr(self, n_, None) for n_ in names}
         old_flags = (self.fused_embed_pool, self.chain_tail, self.hip_tail, self._gelu_epilogue)
         self.master = {k_: torch.as_tensor(sd[k_]).detach().to("cpu", torch.float32).clone() for k_ in want}
@@ -205,10 +210,13 @@ class PolicyValueNet:
         self._gelu_epilogue = False
         self._exact = None
         self._foldu = None
+        self._blocks = None
         if self.device.type == "cuda" and self.dtype == torch.bfloat16:
             self._prepare_hip_embed()
             if self._hip is not None:
                 self._prepare_folded()
+                if self.cfg.depth > 1:
+                    self._prepare_blocks()
         elif self.device.type == "cuda" and self.dtype == torch.float32:
             self._prepare_exact()
         return self
@@ -706,6 +714,89 @@ class PolicyValueNet:
         t["l_all"] = lall.float()
         return azk.EmbedPoolTables(t, H, cfg.patch_size, D)
 
+    def _prepare_blocks(self):
+        """Operands of the hand-written path for networks deeper than one block (csrc/azk_block.hip; main.py:186-188 builds
+        Net(embed_dim=256, num_heads=8, depth=2)): per full block the four linear maps in fragment packing (output padded to 128) with
+        float32 biases and the LayerNorm affines; for the LAST block, whose only consumer is the cls row (nn.py:80), the folded cls
+        path as plain GEMMs - the per-board attention query m_h = scale Wk_h^T (Wq_h LN1(x0) + bq_h) and offset c_h = scale bk_h . q_h as
+        ONE linear map of LN1(x0) (composed in float64), the value and output projections composed per head into [H D -> D]."""
+        import azk
+        cfg, m, dev = self.cfg, self.master, self.device
+        D, H, A = cfg.embed_dim, cfg.num_heads, cfg.action_dim
+        dh = D // H
+        if D % 128 or dh not in (32, 64) or cfg.tokens > 256 or (D, H) not in ((512, 8), (256, 8), (256, 4), (512, 4)):
+            return
+        f32 = lambda t: t.to(dev, torch.float32).contiguous()
+
+        def lin(wt, bias):
+            n_out = wt.shape[0]
+            npad = (n_out + 127) // 128 * 128
+            bp = torch.zeros(npad, dtype=torch.float32, device=dev)
+            bp[:n_out] = bias.to(dev, torch.float32)
+            return dict(w=azk.pack_linear_weight128(wt.to(dev)), b=bp, n=npad)
+        blocks = []
+        for i in range(cfg.depth - 1):
+            b = f"blocks.{i}."
+            blocks.append(dict(ln1=(f32(m[b + "norm1.weight"]), f32(m[b + "norm1.bias"])), ln2=(f32(m[b + "norm2.weight"]), f32(m[b + "norm2.bias"])),
+                               qkv=lin(m[b + "attn.in_proj_weight"], m[b + "attn.in_proj_bias"]), out=lin(m[b + "attn.out_proj.weight"], m[b + "attn.out_proj.bias"]),
+                               up=lin(m[b + "mlp.0.weight"], m[b + "mlp.0.bias"]), down=lin(m[b + "mlp.3.weight"], m[b + "mlp.3.bias"])))
+        b = f"blocks.{cfg.depth - 1}."
+        dd = lambda k_: m[k_].to(dev, torch.float64)
+        Wi, bi = dd(b + "attn.in_proj_weight"), dd(b + "attn.in_proj_bias")
+        Wq, bq = Wi[:D].view(H, dh, D), bi[:D].view(H, dh)
+        Wk, bk = Wi[D:2 * D].view(H, dh, D), bi[D:2 * D].view(H, dh)
+        Wv, bv = Wi[2 * D:].view(H, dh, D), bi[2 * D:]
+        scale = 1.0 / math.sqrt(dh)
+        Wm = torch.einsum("hed,hef->hdf", Wk, Wq).reshape(H * D, D) * scale            # m_h = Wm_h LN1(x0) + bm_h
+        bm = torch.einsum("hed,he->hd", Wk, bq).reshape(H * D) * scale
+        Wc = torch.einsum("he,hef->hf", bk, Wq) * scale                                 # c_h = Wc_h . LN1(x0) + bc_h
+        bc = (bk * bq).sum(1) * scale
+        Wo, bo = dd(b + "attn.out_proj.weight"), dd(b + "attn.out_proj.bias")
+        Wcomb = torch.einsum("ohe,hed->ohd", Wo.view(D, H, dh), Wv).reshape(D, H * D)      # x1 = x0 + Wcomb z_flat + (bo + Wo bv)
+        Wh = torch.zeros(A + 1, D, dtype=torch.float64, device=dev)
+        Wh[:A], Wh[A] = dd("policy_head.weight"), dd("value_head.weight")[0]
+        bh = torch.cat([dd("policy_head.bias"), dd("value_head.bias")])
+        last = dict(ln1=(f32(m[b + "norm1.weight"]), f32(m[b + "norm1.bias"])), ln2=(f32(m[b + "norm2.weight"]), f32(m[b + "norm2.bias"])),
+                    lnf=(f32(m["norm.weight"]), f32(m["norm.bias"])),
+                    mc=lin(torch.cat([Wm, Wc]).float(), torch.cat([bm, bc]).float()), comb=lin(Wcomb.float(), (bo + Wo @ bv).float()),
+                    up=lin(m[b + "mlp.0.weight"], m[b + "mlp.0.bias"]), down=lin(m[b + "mlp.3.weight"], m[b + "mlp.3.bias"]),
+                    heads=lin(Wh.float(), bh.float()))
+        self._blocks = dict(full=blocks, last=last)
+
+    def forward_blocks_hip(self, x):
+        """depth > 1 on hand-written kernels only (no F.linear, torch.bmm or scaled_dot_product_attention): token embedding
+        (k_embed) -> depth - 1 full-token blocks (k_ln_rows, k_gemm_tok, k_attn_tok: nn.py:52-61) -> the last block for the cls row
+        (k_ln_rows, the per-board folded query as one GEMM, k_cls_attn, four GEMMs) -> final LayerNorm + merged heads (nn.py:78-83)."""
+        import azk
+        cfg, bl = self.cfg, self._blocks
+        n, T, D, H, A = x.shape[0], cfg.tokens, cfg.embed_dim, cfg.num_heads, cfg.action_dim
+        if x.dtype not in (torch.bfloat16, torch.float32):
+            x = x.float()
+        t = self.embed_hip(x.contiguous(), want_x=True, want_xhat=False)[0].view(n * T, D)     # tokens, bf16
+        G = azk.nn_gemm_tok
+        for blk in bl["full"]:
+            h = azk.nn_layernorm_rows(t, *blk["ln1"])
+            qkv = G(h, blk["qkv"]["w"], blk["qkv"]["n"], azk.TOK_BF16, bias=blk["qkv"]["b"])
+            o = azk.nn_attention_tok(qkv, n, T, D, H)
+            t = G(o, blk["out"]["w"], blk["out"]["n"], azk.TOK_RESID, bias=blk["out"]["b"], resid=t)            # nn.py:54-56
+            h = azk.nn_layernorm_rows(t, *blk["ln2"])
+            hh = G(h, blk["up"]["w"], blk["up"]["n"], azk.TOK_GELU, bias=blk["up"]["b"])
+            t = G(hh, blk["down"]["w"], blk["down"]["n"], azk.TOK_RESID, bias=blk["down"]["b"], resid=t)        # nn.py:59-60
+        la = bl["last"]
+        xhat = azk.nn_layernorm_rows(t, *la["ln1"])                                                          # LN1 of every token: keys / values of the cls query
+        x0, xh0 = t.view(n, T, D)[:, 0], xhat.view(n, T, D)[:, 0]                                             # the cls rows (row stride T D)
+        mc = G(xh0, la["mc"]["w"], la["mc"]["n"], azk.TOK_F32, bias=la["mc"]["b"])                            # [n, H D + H (+ pad)] float32
+        mm, cc = mc[:, :H * D].reshape(n, H, D), mc[:, H * D:H * D + H]
+        z = azk.nn_cls_attention(xhat.view(n, T, D), mm, cc, H)                                               # [n, H, D] = sum_t a_t LN1(x)_t per head
+        x1 = G(z.view(n, H * D), la["comb"]["w"], la["comb"]["n"], azk.TOK_RESID, bias=la["comb"]["b"], resid=x0)
+        h = azk.nn_layernorm_rows(x1, *la["ln2"])
+        hh = G(h, la["up"]["w"], la["up"]["n"], azk.TOK_GELU, bias=la["up"]["b"])
+        x2 = G(hh, la["down"]["w"], la["down"]["n"], azk.TOK_RESID, bias=la["down"]["b"], resid=x1)
+        y = azk.nn_layernorm_rows(x2, *la["lnf"])
+        out = G(y, la["heads"]["w"], la["heads"]["n"], azk.TOK_F32, bias=la["heads"]["b"])
+        self.last_forward_kernels = "hand-written"
+        return out[:, :A].contiguous(), torch.tanh(out[:, A:A + 1])
+
     def tail_hip(self, z):
         """tail_fast on the hand-written kernels: every launch honours the device-side live count, split-K partial sums are
         added by the row-wise kernel that follows (LayerNorm / finalize)."""
@@ -1042,6 +1133,8 @@ class PolicyValueNet:
                 x0 = hp["cpos"][0].to(self.dtype).expand(x.shape[0], -1)
                 _, xhat = self.embed_hip(x, want_x=False, want_xhat=True)
             else:
+                if getattr(self, "_blocks", None) is not None and getattr(self, "use_hip_blocks", True) and x.is_cuda:
+                    return self.forward_blocks_hip(x)
                 t = self.embed(x)
                 for i in range(last):
                     t = self.block_full(t, i)

@@ -592,6 +592,28 @@ int32_t azk_vanilla_set_rng(azk_engine *e, int32_t first, int32_t count, const u
 int32_t azk_vanilla_get_rng(azk_engine *e, int32_t first, int32_t count, uint32_t *mt_states_host, void *stream);  /* synchronises */
 int32_t azk_vanilla_search(azk_engine *e, int32_t n_sims, void *stream);
 
+/* ---- the full-token transformer block (ai/nn.py:38-61) for networks with depth > 1 (csrc/azk_block.hip) ----
+ * azk_nn_gemm_tok: out[m][n_out] = A[m][k] W^T (+ bias) through an epilogue, LDS-staged (LDS-DMA in full lines, counted-wait ring):
+ *   a_bf16 [m][lda] row-major; w_packed = an nn.Linear weight [n_out][k] in azk_nn_gemm_rows' fragment packing (n_out a multiple of
+ *   128 - pad with zero rows -, k a multiple of 64, k >= 128); epilogue 0: bf16 out; 1: bf16 GELU(.) (erf form); 2: bf16 out = . +
+ *   resid_bf16[m][ldr]; 4: float32 out.  n_valid (optional, device): rows at or beyond it are neither read nor written. */
+typedef struct azk_gemm_tok {
+    const void *a_bf16; int32_t lda;
+    const void *w_packed;
+    int32_t m, n_out, k;
+    const int32_t *n_valid;
+    const float *bias;
+    int32_t epilogue;
+    void *out; int32_t ldo;
+    const void *resid_bf16; int32_t ldr;
+} azk_gemm_tok;
+int32_t azk_nn_gemm_tok(const azk_gemm_tok *desc, void *stream);
+/* azk_nn_attention_tok: nn.MultiheadAttention (eval mode) over ALL tokens of every board: out[b][t][h dh ..] = softmax_t'(q k^T /
+ * sqrt(dh)) v per board b and head h.  qkv_bf16 [n_boards][tokens][3 embed_dim] = the in-projection's output (q | k | v);
+ * tokens <= 256; head dimension 32 or 64.  n_valid (optional, device): boards at or beyond it are skipped. */
+int32_t azk_nn_attention_tok(const void *qkv_bf16_dev, void *out_bf16_dev, int32_t n_boards, int32_t tokens, int32_t embed_dim,
+                             int32_t num_heads, const int32_t *n_valid_dev, void *stream);
+
 /* nn.LayerNorm over the rows of a bf16 matrix [n][embed_dim] (norm2 / norm of nn.py:41-42,78; fp32 statistics) -> y;
  * with add_bias_dev != NULL the rows of x are also replaced by x + add_bias (the residual the next GEMM accumulates
  * onto, nn.py:59-60).  embed_dim in {128, 256, 512}. */

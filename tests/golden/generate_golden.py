@@ -515,6 +515,31 @@ def gen_nn_small():
     return out
 
 
+def gen_nn_depth2():
+    """main.py:186-188's network (the compare mode builds Net(rows, patch_size=5, embed_dim=256, num_heads=8, depth=2)) at 15x15 under
+    torch.manual_seed(0): outputs on eight boards + the parameter sums (the weights themselves are not committed: the build's
+    initialiser reproduces them from the seed, checked against the sums)."""
+    import json
+    out = {}
+    torch.manual_seed(0)
+    cfg = dict(img_size=15, patch_size=5, embed_dim=256, action_dim=225, num_heads=8, depth=2, channels=2)
+    net = RefNet(dropout=0.1, **cfg).eval()
+    rng = np.random.RandomState(11)
+    x = np.zeros((8, 2, 15, 15), np.float32)
+    for b in range(8):
+        k = 6 * b
+        cells = rng.choice(225, size=k, replace=False)
+        x[b, 0].reshape(-1)[cells[: k // 2]] = 1
+        x[b, 1].reshape(-1)[cells[k // 2:]] = 1
+    with torch.no_grad():
+        logits, v = net(torch.from_numpy(x))
+    out["x"], out["logits"], out["value"] = x, logits.numpy(), v.numpy()
+    out["cfg_json"] = np.frombuffer(json.dumps(cfg).encode(), np.uint8)
+    out["keys_json"] = np.frombuffer(json.dumps({k: list(v_.shape) for k, v_ in net.state_dict().items()}).encode(), np.uint8)
+    out["param_sums"] = np.array([float(t.double().sum()) for t in net.state_dict().values()], np.float64)
+    return out
+
+
 # =================================================================================
 # 5. train step (train.py:85-123): loss, L2 quirk, Adam - small net, dropout 0 (deterministic)
 # =================================================================================
@@ -565,7 +590,7 @@ def gen_train(dropout=0.0, torch_seed_for_masks=None):
 
 
 def main():
-    which = sys.argv[1:] or ["rules", "search", "games", "compete", "nn", "train", "train_dropout"]
+    which = sys.argv[1:] or ["rules", "search", "games", "compete", "nn", "nn_depth2", "train", "train_dropout"]
     print("python", sys.version.split()[0], "numpy", np.__version__, "torch", torch.__version__,
           "cpus", os.cpu_count(), "torch threads", torch.get_num_threads())
     if "rules" in which:
@@ -587,6 +612,8 @@ def main():
         np.savez_compressed(os.path.join(HERE, "compete.npz"), **gen_compete())
     if "nn" in which:
         np.savez_compressed(os.path.join(HERE, "nn_small.npz"), **gen_nn_small())
+    if "nn_depth2" in which:
+        np.savez_compressed(os.path.join(HERE, "nn_depth2.npz"), **gen_nn_depth2())
     if "train" in which:
         np.savez_compressed(os.path.join(HERE, "train_small.npz"), **gen_train())
     if "train_dropout" in which:

@@ -1,0 +1,121 @@
+"""The hand-written path for networks deeper than one block (csrc/azk_block.hip; reference: ai/nn.py:38-61, main.py:186-188 builds
+Net(embed_dim=256, num_heads=8, depth=2)): the LDS-staged token GEMM, the all-token attention kernel, and the whole depth-2
+evaluator against the reference's outputs (tests/golden/nn_depth2.npz) with the library GEMM / attention entry points disabled."""
+import json
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("m,k,n_out,live", [(226 * 40, 256, 768, None), (226 * 40, 512, 1536, None), (917, 2048, 256, 600), (100, 1024, 256, None),
+                                              (300, 256, 2176, None), (64, 128, 128, 1)])
+@pytest.mark.parametrize("epi", ["bf16", "gelu", "resid", "f32"])
+def test_gemm_tok_against_float64(m, k, n_out, live, epi):
+    import azk
+    g = torch.Generator("cuda").manual_seed(m + k)
+    a = (torch.randn(m, k, device="cuda", generator=g) * 0.7).to(torch.bfloat16)
+    w = torch.randn(n_out - 37, k, device="cuda", generator=g) * (1.0 / k ** 0.5)          # (an output width that needs padding)
+    wp = azk.pack_linear_weight128(w)
+    bias = torch.zeros(n_out, device="cuda")
+    bias[: n_out - 37] = torch.randn(n_out - 37, device="cuda", generator=g) * 0.2
+    resid = torch.randn(m, n_out, device="cuda", generator=g).to(torch.bfloat16)
+    cnt = torch.tensor([live], dtype=torch.int32, device="cuda") if live is not None else None
+    code = {"bf16": azk.TOK_BF16, "gelu": azk.TOK_GELU, "resid": azk.TOK_RESID, "f32": azk.TOK_F32}[epi]
+    out = torch.full((m, n_out), 7.0, device="cuda", dtype=torch.float32 if epi == "f32" else torch.bfloat16)
+    azk.nn_gemm_tok(a, wp, n_out, code, bias=bias, out=out, resid=resid if epi == "resid" else None, count=cnt)
+    torch.cuda.synchronize()
+    nl = m if live is None else live
+    assert bool((out[nl:].float() == 7.0).all())
+    wb = torch.zeros(n_out, k, device="cuda", dtype=torch.float64)
+    wb[: n_out - 37] = w.to(torch.bfloat16).double()
+    ref = a[:nl].double() @ wb.t() + bias.double()
+    if epi == "gelu":
+        ref = F.gelu(ref)
+    if epi == "resid":
+        ref = ref + resid[:nl].double()
+    err = (out[:nl].double() - ref).abs()
+    tol = 1e-4 if epi == "f32" else 2.0 ** -8
+    assert (err <= ref.abs() * tol + 2e-3).all(), float(err.max())
+
+
+@pytest.mark.parametrize("n,T,D,H", [(5, 226, 512, 8), (7, 226, 256, 8), (3, 50, 256, 4), (2, 256, 512, 8), (4, 10, 256, 8)])
+def test_attention_tok_against_float32(n, T, D, H):
+    import azk
+    g = torch.Generator("cuda").manual_seed(n * T)
+    qkv = (torch.randn(n * T, 3 * D, device="cuda", generator=g) * 1.2).to(torch.bfloat16)
+    out = azk.nn_attention_tok(qkv, n, T, D, H)
+    torch.cuda.synchronize()
+    dh = D // H
+    q, k, v = qkv.float().view(n, T, 3, H, dh).permute(2, 0, 3, 1, 4)
+    ref = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(n * T, D)
+    err = (out.float() - ref).abs().max().item()
+    assert err < 2e-2, err                                     # bf16 probabilities and outputs of O(1) values
+    live = torch.tensor([max(1, n - 2)], dtype=torch.int32, device="cuda")
+    o2 = torch.full((n * T, D), 7.0, device="cuda", dtype=torch.bfloat16)
+    azk.nn_attention_tok(qkv, n, T, D, H, out=o2, count=live)
+    torch.cuda.synchronize()
+    nl = max(1, n - 2)
+    assert torch.equal(o2[: nl * T], out[: nl * T]) and bool((o2[nl * T:].float() == 7.0).all())
+
+
+def test_depth2_evaluator_on_hand_written_kernels_only(monkeypatch):
+    """Net(15, patch 5, embed 256, heads 8, depth 2) - main.py:186-188's network - under torch.manual_seed(0): the build's initialiser
+    reproduces the reference's weights (parameter sums), and the bf16 forward on the hand-written kernels alone (F.linear, torch.bmm,
+    torch.matmul and scaled_dot_product_attention raise while it runs) gives the reference's float32 outputs within SURVEY 8(c)'s
+    bf16 bar of 2e-2; the same for a depth-3, D = 512 network against the build's own float32 forward."""
+    from pvnet import NetConfig, PolicyValueNet
+    z = load_golden("nn_depth2.npz")
+    cfgj = json.loads(bytes(z["cfg_json"]).decode())
+    cfg = NetConfig(15, 15, 2, 225, cfgj["patch_size"], cfgj["embed_dim"], cfgj["num_heads"], cfgj["depth"])
+    net = PolicyValueNet(cfg, seed=0, device="cuda", dtype=torch.bfloat16, path="clsfold")
+    sums = np.array([float(net.master[k].double().sum()) for k in json.loads(bytes(z["keys_json"]).decode())])
+    assert np.allclose(sums, z["param_sums"], rtol=0, atol=1e-6)
+    assert net._blocks is not None
+    x = torch.from_numpy(z["x"]).cuda()
+
+    def banned(*a, **k):
+        raise AssertionError("a library GEMM / attention entry point was called inside the hand-written forward")
+    with monkeypatch.context() as mp:
+        for mod, name in ((F, "linear"), (torch, "bmm"), (torch, "matmul"), (F, "scaled_dot_product_attention"), (torch, "addmm"), (torch, "einsum")):
+            mp.setattr(mod, name, banned)
+        net.last_forward_kernels = None
+        logits, value = net(x.to(torch.bfloat16))
+        torch.cuda.synchronize()
+    assert net.last_forward_kernels == "hand-written"
+    dl = (logits.cpu() - torch.from_numpy(z["logits"])).abs().max().item()
+    dv = (value.cpu().reshape(-1) - torch.from_numpy(z["value"]).reshape(-1)).abs().max().item()
+    assert dl < 2e-2 and dv < 1e-2, (dl, dv)
+    # the library path of the same network agrees too (it is the fallback for shapes the kernels do not cover)
+    net.use_hip_blocks = False
+    l2, v2 = net(x.to(torch.bfloat16))
+    assert (l2.cpu() - torch.from_numpy(z["logits"])).abs().max().item() < 4e-2
+    # depth 3, D = 512, 8 heads (head dimension 64) against the float32 forward of the same weights
+    cfg3 = NetConfig(15, 15, 2, 225, 5, 512, 8, 3)
+    n3 = PolicyValueNet(cfg3, seed=3, device="cuda", dtype=torch.bfloat16, path="clsfold")
+    ref3 = PolicyValueNet(cfg3, seed=3, device="cuda", dtype=torch.float32, path="full")
+    xb = (torch.rand(24, 2, 15, 15, device="cuda") < 0.12).float()
+    xb[:, 1] *= 1 - xb[:, 0]
+    lr, vr = ref3(xb)
+    with monkeypatch.context() as mp:
+        for mod, name in ((F, "linear"), (torch, "bmm"), (F, "scaled_dot_product_attention")):
+            mp.setattr(mod, name, banned)
+        lh, vh = n3(xb.to(torch.bfloat16))
+    assert (lh - lr).abs().max().item() < 4e-2 and (vh.reshape(-1) - vr.reshape(-1)).abs().max().item() < 2e-2
+
+
+def test_depth2_in_place_promotion_refreshes_the_block_tables():
+    from pvnet import NetConfig, PolicyValueNet
+    cfg = NetConfig(15, 15, 2, 225, 5, 256, 8, 2)
+    net = PolicyValueNet(cfg, seed=1, device="cuda", dtype=torch.bfloat16, path="clsfold")
+    other = PolicyValueNet(cfg, seed=2, device="cuda", dtype=torch.bfloat16, path="clsfold")
+    x = (torch.rand(6, 2, 15, 15, device="cuda") < 0.1).to(torch.bfloat16)
+    ptr = net._blocks["full"][0]["qkv"]["w"].data_ptr()
+    assert net.load_state_dict(other.state_dict()) is True
+    assert net._blocks["full"][0]["qkv"]["w"].data_ptr() == ptr
+    assert torch.equal(net(x)[0], other(x)[0])

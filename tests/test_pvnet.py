@@ -114,3 +114,23 @@ def test_patch_pooling_fold_is_the_same_function():
     out = ln(x2) @ f8(r["WhG"]).t() + f8(r["bhG"])
     np.testing.assert_allclose(out[:, :225].float().numpy(), Z["full_logits"], rtol=0, atol=5e-6)
     assert PolicyValueNet(NetConfig(15, 15, 2, 225, 5, 512, 8, 2), seed=0).fold_u() is None
+
+
+def test_depth2_network_of_the_compare_mode_against_the_reference():
+    """main.py:186-188: Net(rows, patch_size=5, embed_dim=256, num_heads=8, depth=2).  tests/golden/nn_depth2.npz holds the reference's
+    seed-0 outputs and parameter sums: the build's initialiser draws the same weights, and the float32 forward (every path) the same
+    outputs."""
+    import json
+    z = load_golden("nn_depth2.npz")
+    c = json.loads(bytes(z["cfg_json"]).decode())
+    cfg = NetConfig(15, 15, 2, 225, c["patch_size"], c["embed_dim"], c["num_heads"], c["depth"])
+    net = PolicyValueNet(cfg, seed=0, device="cpu", dtype=torch.float32, path="full")
+    keys = json.loads(bytes(z["keys_json"]).decode())
+    assert set(keys) == set(net.state_dict().keys()) and all(list(net.master[k].shape) == v for k, v in keys.items())
+    sums = np.array([float(net.master[k].double().sum()) for k in keys])
+    assert np.allclose(sums, z["param_sums"], rtol=0, atol=1e-6)
+    x = torch.from_numpy(z["x"])
+    for path in ("full", "cls"):
+        logits, value = net(x, path=path)
+        assert (logits - torch.from_numpy(z["logits"])).abs().max().item() < 2e-5
+        assert (value - torch.from_numpy(z["value"])).abs().max().item() < 2e-6
