@@ -773,27 +773,30 @@ class PolicyValueNet:
         if x.dtype not in (torch.bfloat16, torch.float32):
             x = x.float()
         t = self.embed_hip(x.contiguous(), want_x=True, want_xhat=False)[0].view(n * T, D)     # tokens, bf16
+        # a device-side live board count (the step graph's leaf buffer is fixed-size): boards past it are skipped by every kernel
+        cb = self.live_count
+        ct = (cb * T) if cb is not None else None                                              # the same count in token rows
         G = azk.nn_gemm_tok
         for blk in bl["full"]:
-            h = azk.nn_layernorm_rows(t, *blk["ln1"])
-            qkv = G(h, blk["qkv"]["w"], blk["qkv"]["n"], azk.TOK_BF16, bias=blk["qkv"]["b"])
-            o = azk.nn_attention_tok(qkv, n, T, D, H)
-            t = G(o, blk["out"]["w"], blk["out"]["n"], azk.TOK_RESID, bias=blk["out"]["b"], resid=t)            # nn.py:54-56
-            h = azk.nn_layernorm_rows(t, *blk["ln2"])
-            hh = G(h, blk["up"]["w"], blk["up"]["n"], azk.TOK_GELU, bias=blk["up"]["b"])
-            t = G(hh, blk["down"]["w"], blk["down"]["n"], azk.TOK_RESID, bias=blk["down"]["b"], resid=t)        # nn.py:59-60
+            h = azk.nn_layernorm_rows(t, *blk["ln1"], count=ct)
+            qkv = G(h, blk["qkv"]["w"], blk["qkv"]["n"], azk.TOK_BF16, bias=blk["qkv"]["b"], count=ct)
+            o = azk.nn_attention_tok(qkv, n, T, D, H, count=cb)
+            t = G(o, blk["out"]["w"], blk["out"]["n"], azk.TOK_RESID, bias=blk["out"]["b"], resid=t, count=ct)            # nn.py:54-56
+            h = azk.nn_layernorm_rows(t, *blk["ln2"], count=ct)
+            hh = G(h, blk["up"]["w"], blk["up"]["n"], azk.TOK_GELU, bias=blk["up"]["b"], count=ct)
+            t = G(hh, blk["down"]["w"], blk["down"]["n"], azk.TOK_RESID, bias=blk["down"]["b"], resid=t, count=ct)        # nn.py:59-60
         la = bl["last"]
-        xhat = azk.nn_layernorm_rows(t, *la["ln1"])                                                          # LN1 of every token: keys / values of the cls query
+        xhat = azk.nn_layernorm_rows(t, *la["ln1"], count=ct)                                                 # LN1 of every token: keys / values of the cls query
         x0, xh0 = t.view(n, T, D)[:, 0], xhat.view(n, T, D)[:, 0]                                             # the cls rows (row stride T D)
-        mc = G(xh0, la["mc"]["w"], la["mc"]["n"], azk.TOK_F32, bias=la["mc"]["b"])                            # [n, H D + H (+ pad)] float32
+        mc = G(xh0, la["mc"]["w"], la["mc"]["n"], azk.TOK_F32, bias=la["mc"]["b"], count=cb)                  # [n, H D + H (+ pad)] float32
         mm, cc = mc[:, :H * D].reshape(n, H, D), mc[:, H * D:H * D + H]
         z = azk.nn_cls_attention(xhat.view(n, T, D), mm, cc, H)                                               # [n, H, D] = sum_t a_t LN1(x)_t per head
-        x1 = G(z.view(n, H * D), la["comb"]["w"], la["comb"]["n"], azk.TOK_RESID, bias=la["comb"]["b"], resid=x0)
-        h = azk.nn_layernorm_rows(x1, *la["ln2"])
-        hh = G(h, la["up"]["w"], la["up"]["n"], azk.TOK_GELU, bias=la["up"]["b"])
-        x2 = G(hh, la["down"]["w"], la["down"]["n"], azk.TOK_RESID, bias=la["down"]["b"], resid=x1)
-        y = azk.nn_layernorm_rows(x2, *la["lnf"])
-        out = G(y, la["heads"]["w"], la["heads"]["n"], azk.TOK_F32, bias=la["heads"]["b"])
+        x1 = G(z.view(n, H * D), la["comb"]["w"], la["comb"]["n"], azk.TOK_RESID, bias=la["comb"]["b"], resid=x0, count=cb)
+        h = azk.nn_layernorm_rows(x1, *la["ln2"], count=cb)
+        hh = G(h, la["up"]["w"], la["up"]["n"], azk.TOK_GELU, bias=la["up"]["b"], count=cb)
+        x2 = G(hh, la["down"]["w"], la["down"]["n"], azk.TOK_RESID, bias=la["down"]["b"], resid=x1, count=cb)
+        y = azk.nn_layernorm_rows(x2, *la["lnf"], count=cb)
+        out = G(y, la["heads"]["w"], la["heads"]["n"], azk.TOK_F32, bias=la["heads"]["b"], count=cb)
         self.last_forward_kernels = "hand-written"
         return out[:, :A].contiguous(), torch.tanh(out[:, A:A + 1])
 

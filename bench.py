@@ -296,6 +296,12 @@ def main():
     ap.add_argument("--fp32-steps", type=int, default=12,
                     help="the default (bf16) run ends with a second timed window on the fp32-accurate evaluator (`fp32_line`): this many moves (0 = skip)")
     ap.add_argument("--fp32-warmup", type=int, default=4, help="untimed moves of the fp32 window after its own pre-roll")
+    ap.add_argument("--net", default="main", choices=["main", "compare"],
+                    help="main (default): main.py:134's network, Net(patch 5, embed 512, heads 8, depth 1) - the metric's config.  compare: SIDE LINE on "
+                         "main.py:186-188's network, Net(patch 5, embed 256, heads 8, depth 2): every block on the hand-written full-token kernels "
+                         "(csrc/azk_block.hip), evaluated over the fixed-size leaf buffer with the device-side live count")
+    ap.add_argument("--blocks", default="hip", choices=["hip", "library"],
+                    help="--net compare: the full-token blocks on the hand-written kernels (default) or on the torch library (F.linear / SDPA)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--train-step", action="store_true",
                     help="BASELINE.json configs[4]: one train.py step (batch 512 per GPU, Adam lr 2.5e-4, one fused gradient bucket "
@@ -337,7 +343,9 @@ def main():
 
     from pvnet import NetConfig
     A = args.size * args.size
-    cfg = NetConfig(args.size, args.size, 2, A, 5, 512, 8, 1)
+    cfg = NetConfig(args.size, args.size, 2, A, 5, 512, 8, 1) if args.net == "main" else NetConfig(args.size, args.size, 2, A, 5, 256, 8, 2)
+    if args.net != "main":
+        args.fp32_steps = 0
     replay = trainer = None
     train_ms = []
     if stub:
@@ -355,6 +363,7 @@ def main():
         nn_torch_dtype = torch.bfloat16 if args.nn_dtype == "bf16" else torch.float32
         net = PolicyValueNet(cfg, seed=0, device=f"cuda:{local_rank}", dtype=nn_torch_dtype, path=args.nn_path)
         net.use_chain_tail = args.tail == "chain"
+        net.use_hip_blocks = args.blocks == "hip"
         kt = KernelTimer(stride=args.timer_stride)
         exact = getattr(net, "_exact", None) is not None and args.nn_path == "clsfold"      # fp32: the hand-written fp32-accurate kernels (csrc/azk_nnx.hip)
         net.use_fold_u = args.embed == "fold"
@@ -650,9 +659,10 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.nn_dtype == "bf16" else "f32", "data": "synthetic",
             "config": {"workload": f"Gomoku {args.size}x{args.size}, {args.sims} sims/move, {args.games} concurrent self-play games per GPU "
                                    f"(BASELINE.json configs[2]), continuous self-play", "games_per_gpu": args.games,
-                       "sims_per_move": args.sims, "net": f"ViT patch5 embed512 heads8 depth1 (ai/nn.py), random init seed 0, path={args.nn_path}, "
+                       "sims_per_move": args.sims, "net": f"ViT patch5 embed{cfg.embed_dim} heads{cfg.num_heads} depth{cfg.depth} (ai/nn.py), random init seed 0, path={args.nn_path}, "
                                                            f"{args.nn_dtype}" + (f", tail={args.tail}" if args.nn_path == "clsfold" else "")
-                                                           + (f", embed={args.embed}" if args.nn_dtype == "bf16" and args.nn_path == "clsfold" else ""),
+                                                           + (f", embed={args.embed}" if args.nn_dtype == "bf16" and args.nn_path == "clsfold" and cfg.depth == 1 else "")
+                                                           + (f", full-token blocks={args.blocks}" if cfg.depth > 1 else ""),
                        "parallelism": f"games sharded over {world} GPU(s), no collectives on the generation path"},
             "sims_per_sec": sims_all / dt_max, "leaf_evals_per_sec": leaves_all / dt_max,
             "eval_cache": {"entries_per_game": args.cache_entries, "mode": args.cache, "hits_rank0": c.get("cache_hits", 0),
