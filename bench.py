@@ -300,6 +300,8 @@ def main():
                     help="main (default): main.py:134's network, Net(patch 5, embed 512, heads 8, depth 1) - the metric's config.  compare: SIDE LINE on "
                          "main.py:186-188's network, Net(patch 5, embed 256, heads 8, depth 2): every block on the hand-written full-token kernels "
                          "(csrc/azk_block.hip), evaluated over the fixed-size leaf buffer with the device-side live count")
+    ap.add_argument("--tail-wide", default="lds", choices=["lds", "registers"],
+                    help="the two wide links of the chain tail: LDS-staged (csrc/azk_tail.hip, default) or round 3's whole-K-in-registers form (same-box A/B)")
     ap.add_argument("--blocks", default="hip", choices=["hip", "library"],
                     help="--net compare: the full-token blocks on the hand-written kernels (default) or on the torch library (F.linear / SDPA)")
     ap.add_argument("--seed", type=int, default=0)
@@ -364,6 +366,7 @@ def main():
         net = PolicyValueNet(cfg, seed=0, device=f"cuda:{local_rank}", dtype=nn_torch_dtype, path=args.nn_path)
         net.use_chain_tail = args.tail == "chain"
         net.use_hip_blocks = args.blocks == "hip"
+        net.use_lds_tail = args.tail_wide == "lds"
         kt = KernelTimer(stride=args.timer_stride)
         exact = getattr(net, "_exact", None) is not None and args.nn_path == "clsfold"      # fp32: the hand-written fp32-accurate kernels (csrc/azk_nnx.hip)
         net.use_fold_u = args.embed == "fold"
