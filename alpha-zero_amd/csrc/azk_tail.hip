@@ -217,12 +217,18 @@ __device__ __forceinline__ bool lds_reduce_chains(f32x4 (&accs)[T::NCH][T::RT][4
     return true;
 }
 
-template <class T, int AMODE, int EPI>
+template <class T, int AMODE, int EPI, bool AZK_XCD_ROWS>
 __device__ __forceinline__ void tail_lds_body(const TailArgs &a, const int nvalid, char *const lds) {
     constexpr int WM = T::WM, WN = T::WN, RT = T::RT, BM = T::BM, BN = T::BN, KT = T::KT, WK = T::WK;
     static_assert(T::PL == 1, "bf16 operands");
     const int ctiles = a.N / BN;
-    const int ct = blockIdx.x % ctiles, rt = blockIdx.x / ctiles;
+    // block -> tile.  Blocks b and b + 8 share an XCD (round-robin dispatch; speed only): with XR the XCD index picks the ROW tile (row tiles
+    // x, x + 8, .. and every column tile on XCD x), so that an XCD's L2 pulls an eighth of the activation rows and the whole weight once -
+    // the K = 2 048 links, whose activations are the bigger operand; otherwise the column tile varies fastest (an XCD sees two column
+    // tiles of the weight and every row)
+    const bool XR = AZK_XCD_ROWS && (ctiles & 7) == 0;
+    const int ct = XR ? (int)(blockIdx.x >> 3) % ctiles : (int)blockIdx.x % ctiles;
+    const int rt = XR ? (int)(blockIdx.x & 7) + 8 * ((int)(blockIdx.x >> 3) / ctiles) : (int)blockIdx.x / ctiles;
     const int row0 = rt * BM;
     if (row0 >= nvalid) return;                                          // (uniform per workgroup; nothing has been issued yet)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
@@ -323,8 +329,8 @@ __global__ __launch_bounds__(64 * T1::NW, 2) void k_tail_lds(TailArgs a) {
     asm volatile("" :: "s"(a.A), "s"(a.Wp), "s"(a.out), "s"(a.bias), "s"(a.resid), "s"(a.stats_in), "s"(a.stats_out), "s"(a.csum),
                  "s"(a.lda), "s"(a.ldo), "s"(a.N), "s"(a.M), "s"(a.ldr), "s"(a.ln_eps));
     const int nvalid = a.count ? min(a.M, *a.count) : a.M;
-    if (SWITCH > 0 && nvalid > SWITCH) tail_lds_body<T2, AMODE, EPI>(a, nvalid, (char *)smem);
-    else tail_lds_body<T1, AMODE, EPI>(a, nvalid, (char *)smem);
+    if (SWITCH > 0 && nvalid > SWITCH) tail_lds_body<T2, AMODE, EPI, EPI == TAIL_EPI_RESID>(a, nvalid, (char *)smem);
+    else tail_lds_body<T1, AMODE, EPI, EPI == TAIL_EPI_RESID>(a, nvalid, (char *)smem);
 }
 
 template <class T1, class T2, int SWITCH, int AMODE, int EPI>
@@ -332,7 +338,8 @@ int launch_lds(TailArgs &a, hipStream_t st) {
     constexpr size_t lds_bytes = T1::LDS_BYTES > T2::LDS_BYTES ? T1::LDS_BYTES : T2::LDS_BYTES;
     auto kern = k_tail_lds<T1, T2, SWITCH, AMODE, EPI>;
     if (azk_set_max_lds((const void *)kern, (int)lds_bytes) != hipSuccess) return AZK_ERR_HIP;
-    const unsigned b1 = (unsigned)(((a.M + T1::BM - 1) / T1::BM) * (a.N / T1::BN)), b2 = (unsigned)(((a.M + T2::BM - 1) / T2::BM) * (a.N / T2::BN));
+    constexpr int RND = EPI == TAIL_EPI_RESID ? 8 : 1;                   // (the XCD-row mapping walks the row tiles in groups of eight)
+    const unsigned b1 = (unsigned)(((a.M + T1::BM - 1) / T1::BM + RND - 1) / RND * RND * (a.N / T1::BN)), b2 = (unsigned)(((a.M + T2::BM - 1) / T2::BM + RND - 1) / RND * RND * (a.N / T2::BN));
     kern<<<b1 > b2 ? b1 : b2, 64 * T1::NW, lds_bytes, st>>>(a);
     return hipGetLastError() == hipSuccess ? AZK_OK : AZK_ERR_HIP;
 }
@@ -360,12 +367,19 @@ __device__ __forceinline__ float gelu_as(float x) {
     return 0.5f * x * (1.0f + copysignf(erf_abs, x));
 }
 
-template <class T, int LNA, int EPI>
+template <class T, int LNA, int EPI, bool AZK_XCD_ROWS>
 __device__ __forceinline__ void gemm_h_lds_body(const HArgs &a, const int nvalid, char *const lds) {
     constexpr int WM = T::WM, WN = T::WN, RT = T::RT, BM = T::BM, BN = T::BN;
     static_assert(T::PL == 2, "(hi, lo) fp16 planes");
+    if ((int)(threadIdx.x >> 6) >= T::NW) return;                       // a tiling with fewer waves than the launch carries: the surplus waves leave before any barrier
     const int ctiles = a.N / BN;
-    const int ct = blockIdx.x % ctiles, rt = blockIdx.x / ctiles;
+    // block -> tile.  Blocks b and b + 8 share an XCD (round-robin dispatch; speed only): with XR the XCD index picks the ROW tile (row tiles
+    // x, x + 8, .. and every column tile on XCD x), so that an XCD's L2 pulls an eighth of the activation rows and the whole weight once -
+    // the K = 2 048 links, whose activations are the bigger operand; otherwise the column tile varies fastest (an XCD sees two column
+    // tiles of the weight and every row)
+    const bool XR = AZK_XCD_ROWS && (ctiles & 7) == 0;
+    const int ct = XR ? (int)(blockIdx.x >> 3) % ctiles : (int)blockIdx.x % ctiles;
+    const int rt = XR ? (int)(blockIdx.x & 7) + 8 * ((int)(blockIdx.x >> 3) / ctiles) : (int)blockIdx.x / ctiles;
     const int row0 = rt * BM;
     if (row0 >= nvalid) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
@@ -441,14 +455,13 @@ __device__ __forceinline__ void gemm_h_lds_body(const HArgs &a, const int nvalid
 }
 
 template <class T1, class T2, int SWITCH, int LNA, int EPI>
-__global__ __launch_bounds__(64 * T1::NW, 2) void k_gemm_h_lds(HArgs a) {
-    static_assert(T1::NW == T2::NW, "one workgroup shape");
+__global__ __launch_bounds__(64 * (T1::NW > T2::NW ? T1::NW : T2::NW), 2) void k_gemm_h_lds(HArgs a) {
     extern __shared__ uint4 smem[];
     asm volatile("" :: "s"(a.Ahi), "s"(a.Alo), "s"(a.Wp), "s"(a.bias), "s"(a.csum), "s"(a.ohi), "s"(a.olo), "s"(a.of32), "s"(a.resid), "s"(a.stats_in),
                  "s"(a.stats_out), "s"(a.lda), "s"(a.ldo), "s"(a.ldr), "s"(a.N), "s"(a.M), "s"(a.inv_scale), "s"(a.a_scale), "s"(a.ln_eps));
     const int nvalid = a.count ? min(a.M, *a.count) : a.M;
-    if (SWITCH > 0 && nvalid > SWITCH) gemm_h_lds_body<T2, LNA, EPI>(a, nvalid, (char *)smem);
-    else gemm_h_lds_body<T1, LNA, EPI>(a, nvalid, (char *)smem);
+    if (SWITCH > 0 && nvalid > SWITCH) gemm_h_lds_body<T2, LNA, EPI, EPI == TAIL_EPI_RESID>(a, nvalid, (char *)smem);
+    else gemm_h_lds_body<T1, LNA, EPI, EPI == TAIL_EPI_RESID>(a, nvalid, (char *)smem);
 }
 
 template <class T1, class T2, int SWITCH, int LNA, int EPI>
@@ -456,8 +469,9 @@ int launch_h_lds(HArgs &a, hipStream_t st) {
     constexpr size_t lds_bytes = T1::LDS_BYTES > T2::LDS_BYTES ? T1::LDS_BYTES : T2::LDS_BYTES;
     auto kern = k_gemm_h_lds<T1, T2, SWITCH, LNA, EPI>;
     if (azk_set_max_lds((const void *)kern, (int)lds_bytes) != hipSuccess) return AZK_ERR_HIP;
-    const unsigned b1 = (unsigned)(((a.M + T1::BM - 1) / T1::BM) * (a.N / T1::BN)), b2 = (unsigned)(((a.M + T2::BM - 1) / T2::BM) * (a.N / T2::BN));
-    kern<<<b1 > b2 ? b1 : b2, 64 * T1::NW, lds_bytes, st>>>(a);
+    constexpr int RND = EPI == TAIL_EPI_RESID ? 8 : 1;
+    const unsigned b1 = (unsigned)(((a.M + T1::BM - 1) / T1::BM + RND - 1) / RND * RND * (a.N / T1::BN)), b2 = (unsigned)(((a.M + T2::BM - 1) / T2::BM + RND - 1) / RND * RND * (a.N / T2::BN));
+    kern<<<b1 > b2 ? b1 : b2, 64 * (T1::NW > T2::NW ? T1::NW : T2::NW), lds_bytes, st>>>(a);
     return hipGetLastError() == hipSuccess ? AZK_OK : AZK_ERR_HIP;
 }
 
@@ -511,9 +525,11 @@ extern "C" int32_t azk_nnx_gemm_h_lds(const azk_gemm_h *t, void *stream) {
     }
     if (t->k == 2048 && t->epilogue == TAIL_EPI_RESID && !t->layernorm_a && t->n_out % 64 == 0) {
         if (!t->resid_f32 || (t->ldr & 3)) return AZK_ERR_ARG;
-        // 64 x 64 tiles, two wave groups x two chains (64 KB per stage, two stages): one round of workgroups up to 2048 rows
-        using T = TailTiling<4, 1, 2, 2, 8, 2, 1, 2>;
-        return launch_h_lds<T, T, 0, 0, TAIL_EPI_RESID>(a, st);
+        // up to 1024 live rows: 32 x 64 tiles on FOUR waves (two wave groups x two chains; 48 KB per stage, two stages) - twice the workgroups
+        // of the 64 x 64 form, half the matrix-pipe time per SIMD; above: 64 x 64 tiles on eight waves, one round of workgroups up to 2048 rows
+        using TA = TailTiling<2, 1, 2, 2, 8, 2, 1, 2>;
+        using TB = TailTiling<4, 1, 2, 2, 8, 2, 1, 2>;
+        return launch_h_lds<TA, TB, 1024, 0, TAIL_EPI_RESID>(a, st);
     }
     return AZK_ERR_ARG;
 }
