@@ -33,7 +33,7 @@ SYMBOLS = [
     "azk_nn_gemm_rows", "azk_nn_layernorm_sum", "azk_nn_heads_finalize_sum", "azk_nn_ln_heads",
     "azk_leaf_source_of", "azk_nn_embed_pool_leaves", "azk_nn_embed_pool_compact", "azk_nn_embed_pool_compact_leaves",
     "azk_nn_embed_fold", "azk_nn_embed_fold_leaves", "azk_nnx_embed_fold", "azk_nnx_embed_fold_leaves",
-    "azk_nn_tail_gemm", "azk_nn_tail_gemm_lds", "azk_nn_gemm_tok", "azk_nn_attention_tok", "azk_begin_search_budget", "azk_search_unfinished",
+    "azk_nn_tail_gemm", "azk_nn_tail_gemm_lds", "azk_nn_tail_lds_footprint", "azk_nn_embed_fold_grid", "azk_nn_gemm_tok", "azk_nn_attention_tok", "azk_begin_search_budget", "azk_search_unfinished",
     "azk_nnx_embed_pool", "azk_nnx_embed_pool_leaves", "azk_nnx_gemm", "azk_nnx_gemm_h", "azk_nnx_gemm_h_lds",
     "azk_async_begin", "azk_async_step", "azk_async_drain", "azk_async_set_budget",
 ]

@@ -2190,16 +2190,28 @@ __global__ __launch_bounds__(256, 2) void k_embed_fold(EmbedFoldArgs a) {
 #endif
 }
 
+int g_fold_grid = 0;
+
 template <int NC, int KSZ, int NH, bool SRC, bool EX>
 int launch_embed_fold(const EmbedFoldArgs &a, hipStream_t st) {
     const int tp16 = ((a.T + 15) / 16) * 16;
     const int lds = 256 * 16 + tp16 * 8 + tp16 * 4 + 128 + 128 + 32 + tp16 * 32 + 4 * 8 * 64 * 4 + (SRC ? ((a.src.n_games + 7) / 8) * 16 : 0);   // 29 KB at 2 048 games
     if (azk_set_max_lds((const void *)k_embed_fold<NC, KSZ, NH, SRC, EX>, lds + 2 * FOLD_MAX_SLOTS) != hipSuccess) return AZK_ERR_HIP;
-    const int blocks = a.n < 512 ? a.n : 512;                      // two resident workgroups per CU; each pulls boards until the queue is dry
+    // two resident workgroups per CU by default; each pulls boards until the queue is dry.  azk_nn_embed_fold_grid(n): a caller that steps
+    // several game groups on separate streams caps the grid (one workgroup per CU leaves the register file room for another group's
+    // tree waves)
+    const int cap = g_fold_grid > 0 ? g_fold_grid : 512;
+    const int blocks = a.n < cap ? a.n : cap;
     k_embed_fold<NC, KSZ, NH, SRC, EX><<<blocks, 256, lds, st>>>(a);
     return hipGetLastError() == hipSuccess ? AZK_OK : AZK_ERR_HIP;
 }
 }  // namespace
+
+extern "C" int32_t azk_nn_embed_fold_grid(int32_t max_workgroups) {
+    if (max_workgroups < 0) return AZK_ERR_ARG;
+    g_fold_grid = max_workgroups;                                   // 0: the default (512)
+    return AZK_OK;
+}
 
 static int32_t embed_fold_impl(const void *boards_dev, int32_t boards_are_f32, const azk_leaf_source *src, const azk_embed_fold_consts *k,
                                void *rows_out, int32_t n, int32_t channels, int32_t rows, int32_t cols, const int32_t *n_valid_dev,

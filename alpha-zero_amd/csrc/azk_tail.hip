@@ -477,6 +477,11 @@ int launch_h_lds(HArgs &a, hipStream_t st) {
 
 }  // namespace
 
+// azk_nn_tail_lds_footprint(1): the K = 2048 link keeps two ring buffers instead of three (96 KB of LDS instead of 144): for callers that
+// step several game groups on separate streams, so that another group's tree waves (14 KB of LDS each) fit beside a tail workgroup
+static int g_tail_small_lds = 0;
+extern "C" int32_t azk_nn_tail_lds_footprint(int32_t small) { g_tail_small_lds = small ? 1 : 0; return AZK_OK; }
+
 // azk_nn_tail_gemm_lds: the LDS-staged form of azk_nn_tail_gemm for its two wide links (include/azk.h).
 extern "C" int32_t azk_nn_tail_gemm_lds(const azk_tail_gemm *t, void *stream) {
     if (!t || !t->a_bf16 || !t->w_packed || t->m < 0 || t->nbatch != 1 || !t->out_bf16) return AZK_ERR_ARG;
@@ -498,6 +503,7 @@ extern "C" int32_t azk_nn_tail_gemm_lds(const azk_tail_gemm *t, void *stream) {
         if (!t->resid_bf16 || (t->ldr & 3)) return AZK_ERR_ARG;
         // up to 1024 live rows: 32 x 64 tiles, four wave groups x one chain (144 KB of LDS: one workgroup per CU, 8 x rows / 32 of them);
         // above: 64 x 64 tiles, two wave groups x two chains, so that the launch stays one round of workgroups
+        if (g_tail_small_lds) return launch_lds<TailTiling<2, 1, 4, 1, 8, 2>, TailTiling<4, 1, 2, 2, 8, 2>, 1024, 0, TAIL_EPI_RESID>(a, st);   // two ring buffers: 96 / 64 KB
         return launch_lds<TailTiling<2, 1, 4, 1, 8, 3>, TailTiling<4, 1, 2, 2, 8, 3>, 1024, 0, TAIL_EPI_RESID>(a, st);
     }
     return AZK_ERR_ARG;

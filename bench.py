@@ -302,6 +302,9 @@ def main():
                          "(csrc/azk_block.hip), evaluated over the fixed-size leaf buffer with the device-side live count")
     ap.add_argument("--tail-wide", default="lds", choices=["lds", "registers"],
                     help="the two wide links of the chain tail: LDS-staged (csrc/azk_tail.hip, default) or round 3's whole-K-in-registers form (same-box A/B)")
+    ap.add_argument("--split-fit", type=int, default=0,
+                    help="with --split N: shape the network kernels so that another group's tree waves fit beside them - k_embed_fold launches at most this "
+                         "many workgroups (256 = one per CU), the K = 2048 tail link keeps two LDS ring buffers")
     ap.add_argument("--blocks", default="hip", choices=["hip", "library"],
                     help="--net compare: the full-token blocks on the hand-written kernels (default) or on the torch library (F.linear / SDPA)")
     ap.add_argument("--seed", type=int, default=0)
@@ -367,6 +370,10 @@ def main():
         net.use_chain_tail = args.tail == "chain"
         net.use_hip_blocks = args.blocks == "hip"
         net.use_lds_tail = args.tail_wide == "lds"
+        if args.split > 1 and args.split_fit:
+            import azk
+            azk.lib().azk_nn_tail_lds_footprint(1)
+            azk.lib().azk_nn_embed_fold_grid(args.split_fit)
         kt = KernelTimer(stride=args.timer_stride)
         exact = getattr(net, "_exact", None) is not None and args.nn_path == "clsfold"      # fp32: the hand-written fp32-accurate kernels (csrc/azk_nnx.hip)
         net.use_fold_u = args.embed == "fold"

@@ -438,6 +438,11 @@ int32_t azk_nn_tail_gemm(const azk_tail_gemm *desc, void *stream);
  *             the fixed order 0..3 - bit for bit azk_nn_tail_gemm's result on the same inputs; optional stats_out.
  * Anything else: AZK_ERR_ARG (use azk_nn_tail_gemm). */
 int32_t azk_nn_tail_gemm_lds(const azk_tail_gemm *desc, void *stream);
+/* process-wide launch-shape knobs for callers that step several game groups on separate streams (selfplay.SelfPlayRunner n_split > 1):
+ * azk_nn_tail_lds_footprint(1): the K = 2048 link keeps two LDS ring buffers (96 KB) instead of three (144 KB);
+ * azk_nn_embed_fold_grid(n): azk_nn_embed_fold(_leaves) launches at most n workgroups (0 = default, two per CU).  Results do not change. */
+int32_t azk_nn_tail_lds_footprint(int32_t small);
+int32_t azk_nn_embed_fold_grid(int32_t max_workgroups);
 
 /* azk_nn_ln_heads: final LayerNorm + merged policy/value head + finalize in one launch (nn.py:78-83 for the cls row):
  *   logits[n][A] = LN(x) Wh^T + bh (float32), values[n] = tanh(column A).  w_packed_dev: the merged head weight
