@@ -161,3 +161,25 @@ def test_fp16_plane_links_are_bit_identical_to_the_register_form(m, live):
     assert bool((res[1][2][nl:] == 7.0).all()) and bool((res[1][3][nl:] == 7.0).all())
     ref = hh[:nl].double() @ w3.double().t() + b3.double() + xr[:nl].double()
     assert (res[1][2][:nl].double() - ref).abs().max().item() < 2e-4
+
+
+def test_launch_shape_knobs_do_not_change_results():
+    """azk_nn_tail_lds_footprint / azk_nn_embed_fold_grid (launch shapes for game groups stepped on separate streams: two LDS ring buffers
+    for the K = 2048 link, a cap on k_embed_fold's grid) change where and when the work runs, never its results."""
+    import azk
+    from pvnet import NetConfig, PolicyValueNet
+    cfg = NetConfig(15, 15, 2, 225, 5, 512, 8, 1)
+    net = PolicyValueNet(cfg, seed=8, device="cuda", dtype=torch.bfloat16, path="clsfold")
+    x = (torch.rand(700, 2, 15, 15, device="cuda") < 0.08).to(torch.bfloat16)
+    x[:, 1] *= 1 - x[:, 0]
+    L = azk.lib()
+    try:
+        ref_l, ref_v = net(x)
+        assert L.azk_nn_tail_lds_footprint(1) == 0 and L.azk_nn_embed_fold_grid(96) == 0
+        l2, v2 = net(x)
+        assert torch.equal(ref_l, l2) and torch.equal(ref_v, v2)
+    finally:
+        L.azk_nn_tail_lds_footprint(0)
+        L.azk_nn_embed_fold_grid(0)
+    l3, _ = net(x)
+    assert torch.equal(ref_l, l3)
