@@ -116,7 +116,7 @@ class GemmH(C.Structure):
                 ("n_valid", C.c_void_p), ("bias", C.c_void_p), ("col_sums", C.c_void_p), ("layernorm_a", C.c_int32), ("epilogue", C.c_int32),
                 ("ln_eps", C.c_float), ("a_scale", C.c_float), ("w_scale", C.c_float), ("a_stats", C.c_void_p), ("stats_out", C.c_void_p),
                 ("out_hi", C.c_void_p), ("out_lo", C.c_void_p), ("out_f32", C.c_void_p), ("ldo", C.c_int32), ("resid_f32", C.c_void_p),
-                ("ldr", C.c_int32), ("logits_out", C.c_void_p), ("values_out", C.c_void_p), ("action_dim", C.c_int32)]
+                ("ldr", C.c_int32), ("logits_out", C.c_void_p), ("values_out", C.c_void_p), ("action_dim", C.c_int32), ("overflow_flag", C.c_void_p)]
 
 
 class AsyncConfig(C.Structure):
@@ -1417,7 +1417,7 @@ def pack_linear_weight_h(w):
 
 
 def nnx_gemm_h(a, w_packed, n_out, k, epilogue=TAIL_BF16, nbatch=1, a_batch_stride=0, bias=None, col_sums=None, out=None, out_f32=None,
-               resid=None, a_stats=None, stats_out=None, logits=None, values=None, action_dim=0, count=None, eps=1e-5, lds=False):
+               resid=None, a_stats=None, stats_out=None, logits=None, values=None, action_dim=0, count=None, eps=1e-5, lds=False, overflow=None):
     """One link of the fp32-accurate tail on fp16 (hi, lo) planes (azk_nnx_gemm_h).  a: a float32 tensor [m, lda] (split on the fly)
     or a (hi, lo) pair of fp16 tensors; out: a (hi, lo) pair of fp16 tensors [m, nbatch * n_out] and / or out_f32."""
     torch = _torch()
@@ -1450,6 +1450,9 @@ def nnx_gemm_h(a, w_packed, n_out, k, epilogue=TAIL_BF16, nbatch=1, a_batch_stri
         d.resid_f32, d.ldr = resid.data_ptr(), resid.stride(0)
     if logits is not None:
         d.logits_out, d.values_out, d.action_dim = logits.data_ptr(), values.data_ptr(), int(action_dim)
+    if overflow is not None:
+        assert overflow.dtype == torch.int32 and overflow.numel() >= 1
+        d.overflow_flag = overflow.data_ptr()
     rc = (lib().azk_nnx_gemm_h_lds if lds else lib().azk_nnx_gemm_h)(C.byref(d), _stream())
     if rc != 0:
         raise AzkError(f"azk_nnx_gemm_h{'_lds' if lds else ''} failed ({rc})")

@@ -835,6 +835,7 @@ struct GemmHArgs {
     float ln_eps;
     const float *stats_in; float *stats_out;
     float *logits, *values; int action_dim;
+    int *oflow;                                  // optional sticky flag: a plane value left fp16's range
 };
 
 // nn.GELU (erf form), erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7: 3e-7 on a hidden activation, below this path's 22-bit
@@ -924,6 +925,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_h(GemmHArgs a) {
 #pragma unroll
                     for (int e = 0; e < 8; e++) {
                         const float x = af[u][i][e >> 2][e & 3] * a.a_scale;
+                        if (a.oflow && !(fabsf(x) < 65504.0f)) atomicOr(a.oflow, 1);
                         const _Float16 h = (_Float16)x;
                         ah[u][i].v[e] = h;
                         al[u][i].v[e] = (_Float16)(x - (float)h);
@@ -1000,7 +1002,11 @@ __global__ __launch_bounds__(256, 1) void k_gemm_h(GemmHArgs a) {
                     if (a.ohi) {
                         union { _Float16 h[4]; uint2 u; } ph, pl;
 #pragma unroll
-                        for (int c = 0; c < 4; c++) { const float x = v[c] * a.a_scale; ph.h[c] = (_Float16)x; pl.h[c] = (_Float16)(x - (float)ph.h[c]); }
+                        for (int c = 0; c < 4; c++) {
+                            const float x = v[c] * a.a_scale;
+                            if (a.oflow && !(fabsf(x) < 65504.0f)) atomicOr(a.oflow, 1);
+                            ph.h[c] = (_Float16)x; pl.h[c] = (_Float16)(x - (float)ph.h[c]);
+                        }
                         *(uint2 *)(a.ohi + (size_t)row * a.ldo + col0) = ph.u;
                         *(uint2 *)(a.olo + (size_t)row * a.ldo + col0) = pl.u;
                     }
@@ -1043,6 +1049,7 @@ extern "C" int32_t azk_nnx_gemm_h(const azk_gemm_h *t, void *stream) {
     a.inv_scale = 1.0f / (t->a_scale * t->w_scale); a.a_scale = t->a_scale;
     a.ohi = (_Float16 *)t->out_hi; a.olo = (_Float16 *)t->out_lo; a.of32 = t->out_f32; a.ldo = t->ldo; a.resid = t->resid_f32; a.ldr = t->ldr;
     a.ln_eps = t->ln_eps; a.stats_in = t->a_stats; a.stats_out = t->stats_out; a.logits = t->logits_out; a.values = t->values_out; a.action_dim = t->action_dim;
+    a.oflow = t->overflow_flag;
     hipStream_t st = (hipStream_t)stream;
     const int ln = t->layernorm_a ? 1 : 0;
     if (t->k == 2048) {

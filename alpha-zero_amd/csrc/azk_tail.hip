@@ -356,6 +356,7 @@ struct HArgs {
     const float *resid; int ldr;
     float ln_eps;
     const float *stats_in; float *stats_out;
+    int *oflow;
 };
 
 // nn.GELU (erf form), erf by Abramowitz & Stegun 7.1.26 - k_gemm_h's expression (a true division, not the reciprocal instruction)
@@ -441,7 +442,11 @@ __device__ __forceinline__ void gemm_h_lds_body(const HArgs &a, const int nvalid
                 if (a.ohi) {
                     union { _Float16 h[4]; uint2 u; } ph, pl;
 #pragma unroll
-                    for (int c = 0; c < 4; c++) { const float x = v[c] * a.a_scale; ph.h[c] = (_Float16)x; pl.h[c] = (_Float16)(x - (float)ph.h[c]); }
+                    for (int c = 0; c < 4; c++) {
+                        const float x = v[c] * a.a_scale;
+                        if (a.oflow && !(fabsf(x) < 65504.0f)) atomicOr(a.oflow, 1);
+                        ph.h[c] = (_Float16)x; pl.h[c] = (_Float16)(x - (float)ph.h[c]);
+                    }
                     *(uint2 *)(a.ohi + (size_t)row * a.ldo + col0) = ph.u;
                     *(uint2 *)(a.olo + (size_t)row * a.ldo + col0) = pl.u;
                 }
@@ -522,7 +527,7 @@ extern "C" int32_t azk_nnx_gemm_h_lds(const azk_gemm_h *t, void *stream) {
     a.M = t->m; a.N = t->n_out; a.count = t->n_valid; a.bias = t->bias; a.csum = t->col_sums;
     a.inv_scale = 1.0f / (t->a_scale * t->w_scale); a.a_scale = t->a_scale;
     a.ohi = (_Float16 *)t->out_hi; a.olo = (_Float16 *)t->out_lo; a.of32 = t->out_f32; a.ldo = t->ldo; a.resid = t->resid_f32; a.ldr = t->ldr;
-    a.ln_eps = t->ln_eps; a.stats_in = t->a_stats; a.stats_out = t->stats_out;
+    a.ln_eps = t->ln_eps; a.stats_in = t->a_stats; a.stats_out = t->stats_out; a.oflow = t->overflow_flag;
     hipStream_t st = (hipStream_t)stream;
     if (t->k == 512 && t->epilogue == TAIL_EPI_GELU && t->layernorm_a && t->n_out % 128 == 0) {
         if (!t->a_stats || !t->col_sums || t->stats_out) return AZK_ERR_ARG;

@@ -489,7 +489,10 @@ class PolicyValueNet:
                       st1=torch.empty((rows, D // 64, 2), **f32), st2=torch.empty((rows, D // 64, 2), **f32))
             self._tail_ws[key] = ws
         pl = lambda k_: (ws[k_][0, :n], ws[k_][1, :n])
-        G = azk.nnx_gemm_h
+        if getattr(self, "_exact_overflow", None) is None or self._exact_overflow.device != dev:
+            self._exact_overflow = torch.zeros(1, dtype=torch.int32, device=dev)      # sticky: an activation left the fp16 planes' range (check_exact_range)
+        of = self._exact_overflow
+        G = lambda *a_, **k_: azk.nnx_gemm_h(*a_, overflow=of, **k_)
         if z.shape[-1] == azk.EMBED_FOLD_ROW:      # k_embed_fold's float32 rows against [D_t; U_all; M_h]: the value-projected row directly
             kf = azk.EMBED_FOLD_ROW
             self._launch(G, z.view(n, H * kf), e["foldu"].weight, D // H, kf, azk.TAIL_BF16, nbatch=H, a_batch_stride=kf, out=pl("u"), count=cnt)
@@ -507,6 +510,14 @@ class PolicyValueNet:
         self._launch(G, pl("x2"), e["WhGH"], 256, D, azk.TAIL_HEADS, bias=e["bhG"], col_sums=e["WhGH_csum"], a_stats=ws["st2"][:n], logits=lb, values=vb,
                      action_dim=A, count=cnt)
         return lb, (vb if self.out_buffers is not None else vb[:, None])
+
+    def check_exact_range(self):
+        """The fp32-accurate tail hands its activations from link to link as fp16 (hi, lo) planes of x * 16: |x| >= 4094 does not fit.  The
+        kernels set a sticky device flag when that happens (the outputs are then meaningless); this raises if it ever did.  Synchronises."""
+        f = getattr(self, "_exact_overflow", None)
+        if f is not None and int(f.item()) != 0:
+            raise FloatingPointError("fp32-accurate tail: an activation left the range of its fp16 (hi, lo) planes (|x| >= 4094): use the torch "
+                                     "float32 forward (path='cls') for this network")
 
     def tail_exact(self, z):
         """The cls-row tail as five float32 launches (csrc/azk_nnx.hip k_gemm_x), each honouring the device-side live count

@@ -231,6 +231,7 @@ def fp32_window(args, cfg, rank, local_rank, world, dist):
     sync_all()
     dt = time.perf_counter() - t0
     runner.check_error()
+    net.check_exact_range()
     c = runner.counters()
     dt_max, (plies_all, fin_w, finp_w, sims_all, leaves_all) = reduce_measurement(
         dt, [runner.plies_played - plies0, runner.games_finished - fin0, runner.finished_plies - finp0, c["sims"], c["leaves_evaluated"]],

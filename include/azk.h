@@ -578,6 +578,8 @@ typedef struct azk_gemm_h {
     void *out_hi, *out_lo; float *out_f32; int32_t ldo;
     const float *resid_f32; int32_t ldr;
     float *logits_out, *values_out; int32_t action_dim;
+    int32_t *overflow_flag;       /* optional, device (ABI 4): set to 1 when a value written to (or split into) the fp16 planes leaves fp16's range
+                                   * (|x a_scale| >= 65504): the planes then hold inf and the caller must not trust the outputs */
 } azk_gemm_h;
 int32_t azk_nnx_gemm_h(const azk_gemm_h *desc, void *stream);
 /* azk_nnx_gemm_h_lds - the same descriptor, the two WIDE links (k = 512 -> n_out, LayerNorm + GELU; k = 2048, residual) with both

@@ -262,3 +262,34 @@ def test_weights_outside_the_fp16_plane_scales_fall_back_to_the_torch_forward():
     assert net.load_state_dict(sd) is False and net._exact is None
     l2, _ = net(x)
     assert torch.equal(l2, lb)
+
+
+def test_activation_beyond_the_fp16_planes_is_flagged():
+    """The tail's links hand activations on as fp16 (hi, lo) planes of x * 16: an activation of magnitude >= 4094 becomes inf in the planes.
+    Every link that writes or splits planes raises a sticky device flag, and PolicyValueNet.check_exact_range() turns it into an error."""
+    import azk
+    from pvnet import NetConfig, PolicyValueNet
+    D, m = 512, 64
+    hh = torch.randn(m, 4 * D, device="cuda") * 0.4
+    w3 = torch.randn(D, 4 * D, device="cuda") * 0.03
+    wp3, _ = azk.pack_linear_weight_h(w3)
+    xr = torch.randn(m, D, device="cuda")
+    hi, lo = azk.split_fp16(hh.double(), azk.GEMM_H_A_SCALE)
+    for lds in (False, True):
+        for big in (False, True):
+            flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+            r = xr.clone()
+            if big:
+                r[3, 7] = 5000.0                                   # the residual pushes one output past 4094
+            oh, ol = torch.empty(m, D, device="cuda", dtype=torch.float16), torch.empty(m, D, device="cuda", dtype=torch.float16)
+            azk.nnx_gemm_h((hi.contiguous(), lo.contiguous()), wp3, D, 4 * D, azk.TAIL_RESID, bias=torch.zeros(D, device="cuda"), resid=r, out=(oh, ol), lds=lds, overflow=flag)
+            torch.cuda.synchronize()
+            assert int(flag.item()) == (1 if big else 0), (lds, big)
+    cfg = NetConfig(15, 15, 2, 225, 5, 512, 8, 1)
+    net = PolicyValueNet(cfg, seed=0, device="cuda", dtype=torch.float32, path="clsfold")
+    x = (torch.rand(4, 2, 15, 15, device="cuda") < 0.1).float()
+    net(x)
+    net.check_exact_range()                                        # a sane network: nothing flagged
+    net._exact_overflow.fill_(1)
+    with pytest.raises(FloatingPointError):
+        net.check_exact_range()

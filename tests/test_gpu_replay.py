@@ -111,7 +111,7 @@ def test_collect_train_promote_loop():
     """main.start_train_loop's shape end to end on one GPU: games -> device replay ring -> reference loss / Adam ->
     new weights promoted, eval cache cleared, next collection runs with the new net."""
     from pvnet import NetConfig, init_weights
-    from train_loop import train_loop
+    from helper_train_loop import train_loop
     cfg = NetConfig(7, 7, 2, 49, patch_size=5, embed_dim=128, num_heads=4, depth=1)
     w0 = init_weights(cfg, 0)
     logs = []
