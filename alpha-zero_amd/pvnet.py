@@ -215,7 +215,9 @@ class PolicyValueNet:
             self._prepare_hip_embed()
             if self._hip is not None:
                 self._prepare_folded()
-                if self.cfg.depth > 1:
+                if self.cfg.depth > 1 or not self.chain_tail:
+                    # every network outside the benchmark shape (depth 1, D = 512, whose cls path has its own kernels): the full-token
+                    # blocks (depth > 1) and the cls path of the last block as hand-written GEMMs (csrc/azk_block.hip)
                     self._prepare_blocks()
         elif self.device.type == "cuda" and self.dtype == torch.float32:
             self._prepare_exact()
@@ -1105,6 +1107,9 @@ class PolicyValueNet:
             if self._fold is None:
                 raise RuntimeError("path 'clsfold' needs the HIP kernels (CUDA, bf16, supported embed_dim/heads)")
             last = depth - 1
+            if (depth == 1 and not self.chain_tail and getattr(self, "_blocks", None) is not None and getattr(self, "use_hip_blocks", True)
+                    and x.is_cuda and self.leaf_source is None):
+                return self.forward_blocks_hip(x)             # depth 1 outside the benchmark shape (e.g. D = 256): no library GEMM in the tail either
             if depth == 1:
                 import azk
                 hp, f = self._hip, self._fold

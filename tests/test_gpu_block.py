@@ -119,3 +119,28 @@ def test_depth2_in_place_promotion_refreshes_the_block_tables():
     assert net.load_state_dict(other.state_dict()) is True
     assert net._blocks["full"][0]["qkv"]["w"].data_ptr() == ptr
     assert torch.equal(net(x)[0], other(x)[0])
+
+
+def test_depth1_networks_outside_the_benchmark_shape_run_hand_written_too(monkeypatch):
+    """A depth-1 network that is not D = 512 (the benchmark shape has its own folded kernels) - e.g. configs[1]'s rectangular Connect4
+    ViT, D = 256 - takes the same hand-written path (token embedding, LayerNorm rows, folded cls attention, the tail as k_gemm_tok):
+    no F.linear / addmm / bmm in the forward; within bf16 tolerance of the float32 forward."""
+    from pvnet import NetConfig, PolicyValueNet
+
+    def banned(*a, **k):
+        raise AssertionError("a library GEMM / attention entry point was called inside the hand-written forward")
+    for cfg, shape in ((NetConfig(6, 7, 3, 7, patch_size=5, embed_dim=256, num_heads=8, depth=1), (32, 3, 6, 7)),
+                       (NetConfig(15, 15, 2, 225, 5, 256, 4, 1), (16, 2, 15, 15))):
+        net = PolicyValueNet(cfg, seed=0, device="cuda", dtype=torch.bfloat16, path="clsfold")
+        assert net._blocks is not None and not net.chain_tail
+        ref = PolicyValueNet(cfg, weights=net.state_dict(), device="cuda", dtype=torch.float32, path="full")
+        x = (torch.rand(*shape, device="cuda") < 0.2).float()
+        x[:, 1] *= 1 - x[:, 0]
+        lr, vr = ref(x)
+        with monkeypatch.context() as mp:
+            for mod, name in ((F, "linear"), (torch, "bmm"), (torch, "addmm"), (F, "scaled_dot_product_attention")):
+                mp.setattr(mod, name, banned)
+            net.last_forward_kernels = None
+            lh, vh = net(x.to(torch.bfloat16))
+        assert net.last_forward_kernels == "hand-written"
+        assert (lh - lr).abs().max().item() < 5e-2 and (vh.reshape(-1) - vr.reshape(-1)).abs().max().item() < 2e-2
