@@ -1779,11 +1779,25 @@ __global__ __launch_bounds__(256, 2) void k_embed_fold(EmbedFoldArgs a) {
                     if (c) { if (c <= 4) c_lo += 1ull << (16 * (c - 1)); else c_hi += 1ull << (16 * (c - 5)); }
                 }
             }
-        unsigned long long i_lo = c_lo, i_hi = c_hi;
+        // inclusive wave scan of the eight packed 16-bit counters on DPP (row_shr 1, 2, 4, 8, then row_bcast 15 / 31: six dependent
+        // v_add per dword instead of six ds_bpermute round trips per 64-bit word - ~2 k cycles at the head of every launch).  The fields
+        // never carry into each other (a count is at most the slot count, < 65536), so the four dwords scan independently.
+        unsigned long long i_lo, i_hi;
+        {
+            int w4[4] = {(int)(unsigned)c_lo, (int)(unsigned)(c_lo >> 32), (int)(unsigned)c_hi, (int)(unsigned)(c_hi >> 32)};
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const unsigned long long v_lo = __shfl_up(i_lo, off), v_hi = __shfl_up(i_hi, off);
-            if (lane >= off) { i_lo += v_lo; i_hi += v_hi; }
+            for (int q = 0; q < 4; q++) {
+                int v = w4[q];
+                v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);
+                v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);
+                v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);
+                v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);
+                v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);
+                v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);
+                w4[q] = v;
+            }
+            i_lo = ((unsigned long long)(unsigned)w4[1] << 32) | (unsigned)w4[0];
+            i_hi = ((unsigned long long)(unsigned)w4[3] << 32) | (unsigned)w4[2];
         }
         unsigned long long *wtot = (unsigned long long *)(scan + 16);           // [4 waves][2]
         if (lane == 63) { wtot[2 * wave] = i_lo; wtot[2 * wave + 1] = i_hi; }
