@@ -25,6 +25,29 @@ __device__ __forceinline__ int azk_lane() { return threadIdx.x & 63; }
 
 __device__ __forceinline__ int uniform_i32(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// ---- single-wave workgroups: ordering without waiting -------------------------------------------
+// Every kernel built on this header runs one 64-lane wave per workgroup.  The LDS executes a wave's instructions in issue
+// order, so "lane A writes, lane B reads" needs no s_waitcnt between the two - only that the compiler keeps their order.
+// (__syncthreads() in a single-wave workgroup is already barrier-free, but it still drains the LDS queue: one full round trip.)
+__device__ __forceinline__ void azk_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// bit `lane` of a wave-uniform 64-bit mask selects between two per-lane values: the mask goes to v_cndmask as its scalar
+// select operand (no per-lane shift / and / compare)
+__device__ __forceinline__ unsigned azk_sel_mask(unsigned long long mask, unsigned if_set, unsigned if_clear) {
+    unsigned r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(mask));
+    return r;
+}
+
+__device__ __forceinline__ unsigned long long azk_readlane_u64(unsigned long long v, int lane) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, lane), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), lane);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
 // ---- wave reductions -------------------------------------------------------------------------
 // argmax with "first maximum wins" (Python max(), node.py:47,81): larger value, then lower index.
 // Steps inside a 16-lane row use DPP lane permutes (quad_perm, row_half_mirror, row_mirror: any pairing of disjoint
@@ -220,63 +243,67 @@ __device__ int azk_valid_moves(const uint8_t *b, const GameDesc &g, int16_t *mov
         return __popcll(m);
     }
     // ---- Gomoku ----
+    // The workgroup is ONE wave: LDS instructions of a wave execute in issue order, so a write followed by another lane's read
+    // needs no wait between them, only a compiler-level fence (azk_wave_sync).  Every wait in this function is a data wait.
     const int R = g.rows, C = g.cols, rc = g.rc;
     const int nwords = (rc * 8 + 31) >> 5;
     constexpr int KMAX = 7;                                       // cells per lane: rc <= 448
     long long s0 = dbgv ? clock64() : 0, s1 = 0, s2 = 0, s3 = 0;
-    // row bitmasks (bit c+1 of word r+1; zero border all around): stones (code & 3) and occupied (code != 0)
-    uint32_t *rowst = ms.rows, *rowoc = ms.rows + 32;
-    // this lane's cells (lane + 64 k): board codes and (row, col) once, straight-line (no load sits behind a branch);
+    // this lane's cells (lane + 64 k): board codes and columns once, straight-line (no load sits behind a branch);
     // e / C by multiplication: exact for e < 65536 / C
     const unsigned inv = (65536u + (unsigned)C - 1u) / (unsigned)C;
     uint8_t code[KMAX];
-    int rr[KMAX], cc[KMAX];
 #pragma unroll
     for (int k = 0; k < KMAX; k++) {
-        const int e = lane + AZK_WAVE * k, ec = e < rc ? e : 0;
-        code[k] = b[ec];
-        rr[k] = (int)(((unsigned)ec * inv) >> 16);
-        cc[k] = ec - rr[k] * C;
+        const int e = lane + AZK_WAVE * k;
+        code[k] = b[e < rc ? e : 0];
     }
     for (int w = lane; w < nwords; w += AZK_WAVE) ms.bits[w] = 0u;
-    if (lane < 8) { ms.tabA[lane] = 0; ms.claim[lane] = 0xffffffffu; }     // the first table; larger ones are cleared when the set grows into them
-    ms.rows[lane] = 0u;
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < KMAX; k++) {
-        if (AZK_WAVE * k >= rc) break;
-        const bool in = lane + AZK_WAVE * k < rc;
-        if (in && code[k]) atomicOr(&rowoc[rr[k] + 1], 1u << (cc[k] + 1));
-        if (in && (code[k] & 3)) atomicOr(&rowst[rr[k] + 1], 1u << (cc[k] + 1));
-    }
-    __syncthreads();
     // 1. per empty cell: key = (row-major index of the first stone that adds it) * 8 + (its slot in that stone's add
     //    order: (0,+1) (0,-1) (+1,0) (-1,0) (+1,+1) (-1,-1) (+1,-1) (-1,+1)), gomoku.py:97-102.  The smallest key belongs
     //    to the smallest stone index, i.e. row r-1 (c-1, c, c+1), then row r (c-1, c+1), then row r+1 (c-1, c, c+1).
+    //    The board as a bit string in scalar registers (one ballot per 64 cells): "is there a stone at cell e + delta" for the
+    //    cell of lane l is bit l of the string shifted by delta - a wave-uniform 64-bit word used directly as the select mask
+    //    of v_cndmask.  Neighbours across a row end are cut by the column masks (left neighbours need c >= 1, right ones
+    //    c <= C - 2); rows outside the board are zeros of the string.  No LDS, no atomics.  Needs C + 1 <= 63 (make_game: <= 30).
+    unsigned long long S[KMAX + 1], CL[KMAX], CR[KMAX];
+    bool empty[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; k++) {
+        const int e = lane + AZK_WAVE * k;
+        const bool in = e < rc;
+        const int r = (int)(((unsigned)(in ? e : 0) * inv) >> 16), c = (in ? e : 0) - r * C;
+        S[k] = __ballot(in && (code[k] & 3));
+        CL[k] = __ballot(c >= 1);
+        CR[k] = __ballot(c <= C - 2);
+        empty[k] = in && code[k] == 0;
+    }
+    S[KMAX] = 0ull;
     unsigned key[KMAX];
 #pragma unroll
     for (int k = 0; k < KMAX; k++) {
         key[k] = 0xffffffffu;
         if (AZK_WAVE * k >= rc) continue;                             // wave-uniform
-        const int e = lane + AZK_WAVE * k, r = rr[k], c = cc[k];
-        const uint32_t up = rowst[r] >> c, mid = rowst[r + 1] >> c, dn = rowst[r + 2] >> c;   // bit0 = col c-1, bit1 = c, bit2 = c+1
-        const bool empty = e < rc && ((rowoc[r + 1] >> (c + 1)) & 1u) == 0u;
-        const unsigned ib = (unsigned)((r - 1) * C + c - 1), im = (unsigned)(r * C + c - 1), id = (unsigned)((r + 1) * C + c - 1);
-        // select chain from the last candidate to the first (the first adder wins), no branches
+        const unsigned long long below = k > 0 ? S[k - 1] : 0ull, here = S[k], above = S[k + 1];
+        // bit l of up(a) = stone at cell (64 k + l) - a;  of down(d) = stone at cell (64 k + l) + d   (0 <= a, d <= 63)
+        auto up = [&](int a) { return (here << a) | ((below >> (63 - a)) >> 1); };
+        auto down = [&](int d) { return (here >> d) | ((above << (63 - d)) << 1); };
+        const unsigned e8 = (unsigned)(lane + AZK_WAVE * k) * 8u;
+        // select chain from the last candidate to the first (the first adder wins); value = (stone index) * 8 + slot
         unsigned kk = 0xffffffffu;
-        kk = (dn & 4u) ? (id + 2u) * 8u + 5u : kk;                    // (r+1, c+1) through (-1,-1)
-        kk = (dn & 2u) ? (id + 1u) * 8u + 3u : kk;                    // (r+1, c)   through (-1, 0)
-        kk = (dn & 1u) ? id * 8u + 7u : kk;                           // (r+1, c-1) through (-1,+1)
-        kk = (mid & 4u) ? (im + 2u) * 8u + 1u : kk;                   // (r, c+1)   through (0,-1)
-        kk = (mid & 1u) ? im * 8u + 0u : kk;                          // (r, c-1)   through (0,+1)
-        kk = (up & 4u) ? (ib + 2u) * 8u + 6u : kk;                    // (r-1, c+1) through (+1,-1)
-        kk = (up & 2u) ? (ib + 1u) * 8u + 2u : kk;                    // (r-1, c)   through (+1, 0)
-        kk = (up & 1u) ? ib * 8u + 4u : kk;                           // stone (r-1, c-1) adds e through (+1,+1)
-        kk = empty ? kk : 0xffffffffu;
+        kk = azk_sel_mask(down(C + 1) & CR[k], e8 + (unsigned)((C + 1) * 8 + 5), kk);   // (r+1, c+1) through (-1,-1)
+        kk = azk_sel_mask(down(C), e8 + (unsigned)(C * 8 + 3), kk);                     // (r+1, c)   through (-1, 0)
+        kk = azk_sel_mask(down(C - 1) & CL[k], e8 + (unsigned)((C - 1) * 8 + 7), kk);   // (r+1, c-1) through (-1,+1)
+        kk = azk_sel_mask(down(1) & CR[k], e8 + (unsigned)(8 + 1), kk);                 // (r, c+1)   through (0,-1)
+        kk = azk_sel_mask(up(1) & CL[k], e8 - 8u + 0u, kk);                             // (r, c-1)   through (0,+1)
+        kk = azk_sel_mask(up(C - 1) & CR[k], e8 - (unsigned)((C - 1) * 8) + 6u, kk);    // (r-1, c+1) through (+1,-1)
+        kk = azk_sel_mask(up(C), e8 - (unsigned)(C * 8) + 2u, kk);                      // (r-1, c)   through (+1, 0)
+        kk = azk_sel_mask(up(C + 1) & CL[k], e8 - (unsigned)((C + 1) * 8) + 4u, kk);    // stone (r-1, c-1) adds e through (+1,+1)
+        kk = empty[k] ? kk : 0xffffffffu;
         if (kk != 0xffffffffu) atomicOr(&ms.bits[kk >> 5], 1u << (kk & 31));
         key[k] = kk;
     }
-    __syncthreads();
+    azk_wave_sync();
     if (dbgv) s1 = clock64();
     // 2. exclusive popcount prefix over the key bitmap (<= 128 words)
     int total = 0;
@@ -295,11 +322,11 @@ __device__ int azk_valid_moves(const uint8_t *b, const GameDesc &g, int16_t *mov
         if (w < nwords) ms.pref[w] = (uint16_t)(total + incl - p);
         total += __builtin_amdgcn_readlane(incl, AZK_WAVE - 1);
     }
-    __syncthreads();
+    azk_wave_sync();
     const int m = total;
     if (m == 0) {                                                 // gomoku.py:103-104
         if (lane == 0) moves[0] = (int16_t)((R / 2) * C + (C / 2));
-        __syncthreads();
+        azk_wave_sync();
         return 1;
     }
     // 3. rank every candidate by its key -> first-insertion order (ord[] holds cell + 1)
@@ -319,33 +346,103 @@ __device__ int azk_valid_moves(const uint8_t *b, const GameDesc &g, int16_t *mov
             }
         }
     }
-    __syncthreads();
+    azk_wave_sync();
     if (skip_set) {   // timing experiment only: first-insertion order instead of CPython set order
         for (int i = lane; i < m; i += AZK_WAVE) moves[i] = (int16_t)(ms.ord[i] - 1);
-        __syncthreads();
+        azk_wave_sync();
         return m;
     }
     if (dbgv) s2 = clock64();
-    // 4. replay the inserts into the emulated CPython set (set_add_entry + set_table_resize).  Sequential semantics,
-    //    parallel execution: up to 64 keys IN ORDER per round, one per lane.  Every lane probes for its key against the
-    //    committed table (probe = slot i..i+9 then perturb, LINEAR_PROBES = 9); atomicMin claims on the chosen (first
-    //    empty) slot expose clashes; the conflict-free PREFIX commits (a later key may only commit once every earlier key
-    //    has, otherwise an earlier key re-probing could have reached its slot first); the rest retry next round.
+    // 4. replay the inserts into the emulated CPython set (set_add_entry + set_table_resize; both probe slot i .. i+9 when
+    //    i + 9 <= mask, else slot i alone, then i = i*5 + 1 + (perturb >>= 5)).
+    //    4a. The 8-slot and the 32-slot generation (the first 5, then up to 19 keys - every position goes through them) run
+    //        SEQUENTIALLY ON THE SCALAR UNIT: key j and its hash sit in lane j, the table in one register (lane s = slot s), the
+    //        occupancy in a scalar 64-bit word; an insert is three v_readlane, a few scalar shifts / ff1 and one select -
+    //        no LDS round trips, no claims, no retries.  (As parallel LDS rounds these two generations cost as many dependent
+    //        LDS round trips as all later ones together.)
+    constexpr int GEN2_FILL = 19;                                    // 32-slot table: resize once fill * 5 >= 31 * 3
+    auto hash_cell1 = [&](int cell1) {                              // hash((r, c)) of the key "cell + 1"
+        const int cell = cell1 > 0 ? cell1 - 1 : 0;
+        const int hr = (int)(((unsigned)cell * inv) >> 16);
+        return py_tuple2_hash(hr, cell - hr * C);
+    };
+    auto probe_scalar = [](unsigned long long h, unsigned msk, unsigned long long occ64) {   // all operands wave-uniform, msk <= 63
+        unsigned long long perturb = h;
+        unsigned i = (unsigned)h & msk;
+        for (;;) {
+            if (i + 9 <= msk) {
+                const unsigned z = (unsigned)((~occ64) >> i) & 0x3ffu;
+                if (z) return i + (unsigned)__ffs((int)z) - 1u;
+            } else if (((occ64 >> i) & 1ull) == 0ull) return i;
+            perturb >>= 5;
+            i = (unsigned)((unsigned long long)i * 5 + 1 + perturb) & msk;
+        }
+    };
+    const int n_small = m < GEN2_FILL ? m : GEN2_FILL;             // keys that enter the two small generations
+    const int kreg = lane < n_small ? (int)ms.ord[lane] : 0;       // key j (cell + 1) in lane j
+    const unsigned long long hreg = hash_cell1(kreg);
+    unsigned long long nocc = ~0ull;                                // complement of the occupancy (one bit per slot), scalar
+    int tkey = 0;                                                   // the table: lane s holds slot s (0 = empty)
+    // one insert: the first window of the probe sequence decides almost always (straight-line scalar code); the perturbed
+    // sequence is the rare path
+    auto insert_scalar = [&](int hv_lo, int hv_hi, int kv_reg, int src_lane, unsigned msk) {
+        const unsigned hl = (unsigned)__builtin_amdgcn_readlane(hv_lo, src_lane);
+        const unsigned i = hl & msk;
+        const unsigned win = (msk >= 9u && i + 9u <= msk) ? 0x3ffu : 1u;
+        const unsigned z = (unsigned)(nocc >> i) & win;
+        unsigned slot;
+        if (__builtin_expect(z == 0u, 0))
+            slot = probe_scalar(((unsigned long long)(unsigned)__builtin_amdgcn_readlane(hv_hi, src_lane) << 32) | hl, msk, ~nocc);
+        else slot = i + (unsigned)__builtin_ctz(z);
+        const unsigned long long bit = 1ull << slot;
+        nocc &= ~bit;
+        tkey = (int)azk_sel_mask(bit, (unsigned)__builtin_amdgcn_readlane(kv_reg, src_lane), (unsigned)tkey);
+    };
+    const int n_gen1 = n_small < 5 ? n_small : 5;                  // 8-slot table: resize once fill * 5 >= 7 * 3
+    for (int j = 0; j < n_gen1; j++) insert_scalar((int)(unsigned)hreg, (int)(unsigned)(hreg >> 32), kreg, j, 7u);
+    if (n_gen1 == 5) {                                              // set_table_resize(so, 20): 32 slots, old table re-inserted in slot order
+        const unsigned long long oldh = hash_cell1(tkey);
+        const int oldk = tkey;
+        unsigned long long old = ~nocc;
+        nocc = ~0ull; tkey = 0;
+        while (old) {
+            const int s = __builtin_ctzll(old);
+            old &= old - 1ull;
+            insert_scalar((int)(unsigned)oldh, (int)(unsigned)(oldh >> 32), oldk, s, 31u);
+        }
+        for (int j = 5; j < n_small; j++) insert_scalar((int)(unsigned)hreg, (int)(unsigned)(hreg >> 32), kreg, j, 31u);
+    }
+    const unsigned long long occ64 = ~nocc;
+    const int below_me = __popcll(occ64 & ((1ull << lane) - 1ull));
+    if (m < GEN2_FILL) {                                            // the set never outgrew 32 slots: list(set) = slot order
+        if (tkey) moves[below_me] = (int16_t)(tkey - 1);
+        azk_wave_sync();
+        if (dbgv && lane == 0) { s3 = clock64(); dbgv[0] += s1 - s0; dbgv[1] += s2 - s1; dbgv[2] += s3 - s2; dbgv[4] += m; }
+        return m;
+    }
+    //    4b. From the 128-slot generation on: parallel rounds in LDS.  Up to 64 keys IN ORDER per round, one per lane.  Every
+    //        lane probes for its key against the committed table; atomicMin claims on the chosen (first empty) slot expose
+    //        clashes; the conflict-free PREFIX commits (a later key may only commit once every earlier key has, otherwise an
+    //        earlier key re-probing could have reached its slot first); the rest retry next round.
     unsigned stamp = 0x00ffffffu;     // claims carry a per-round stamp that only decreases: a newer round's atomicMin always beats
                                       // whatever an older round left in the slot, so claims never need to be reset
     // occupancy bitmap of the CURRENT table (one bit per slot; the first-adder bitmap of steps 1-3 is free by now): a probe reads
     // two words of it instead of sixteen table entries
     uint32_t *occ = ms.bits;
-    for (int w = lane; w <= (ms.table_size >> 5); w += AZK_WAVE) occ[w] = 0u;
-    __syncthreads();
+    uint16_t *tab = ms.tabA, *other = ms.tabB;
+    unsigned mask = 127;                                            // set_table_resize(so, 76)
+    int fill = 0, pos = GEN2_FILL;
+    int nlist = GEN2_FILL;                                          // re-insertions waiting in moves[0 .. nlist): the 32-slot table in slot order
+    if (tkey) moves[below_me] = (int16_t)tkey;
+    for (int i = lane; i < 128; i += AZK_WAVE) { tab[i] = 0; ms.claim[i] = 0xffffffffu; }
+    if (lane <= 4) occ[lane] = 0u;
+    azk_wave_sync();
     auto insert_batch = [&](uint16_t *tb, unsigned msk, const int16_t *list, int count) {
         for (int c0 = 0; c0 < count; c0 += AZK_WAVE) {
             const int idx = c0 + lane;
             const bool have = idx < count;
             const unsigned keyv = have ? (unsigned)list[idx] : 1u;   // cell + 1
-            const int cell = (int)keyv - 1;
-            const int hr = (int)(((unsigned)cell * inv) >> 16);
-            const unsigned long long h = py_tuple2_hash(hr, cell - hr * C);
+            const unsigned long long h = hash_cell1((int)keyv);
             bool placed = !have;
             while (__ballot(!placed) != 0ull) {
                 unsigned slot = 0;
@@ -365,29 +462,25 @@ __device__ int azk_valid_moves(const uint8_t *b, const GameDesc &g, int16_t *mov
                     }
                     atomicMin(&ms.claim[slot], (stamp << 6) | (unsigned)lane);
                 }
-                __syncthreads();
+                azk_wave_sync();                                      // the claims are applied before the read below (issue order)
                 const bool conflict = !placed && ms.claim[slot] != ((stamp << 6) | (unsigned)lane);
                 const unsigned long long cb = __ballot(conflict);
                 const int first_bad = cb ? __ffsll((long long)cb) - 1 : AZK_WAVE;
                 if (!placed && lane < first_bad) { tb[slot] = (uint16_t)keyv; atomicOr(&occ[slot >> 5], 1u << (slot & 31u)); placed = true; }
                 stamp--;
-                __syncthreads();
+                azk_wave_sync();
             }
         }
     };
-    uint16_t *tab = ms.tabA, *other = ms.tabB;
-    unsigned mask = 7;
-    int fill = 0, pos = 0;
     // the keys of one table generation are inserted as ONE ordered batch: [re-insertions in old-table order] + [new
     // candidates up to the next resize threshold]
-    int nlist = 0;                                                 // re-insertions waiting in moves[0 .. nlist)
     while (pos < m || nlist > 0) {
         const int thr = (int)((mask * 3u + 4u) / 5u);             // smallest fill with fill*5 >= mask*3
         int cnt = m - pos;
         if (cnt > thr - (fill + nlist)) cnt = thr - (fill + nlist);
         if (cnt < 0) cnt = 0;
         for (int i = lane; i < cnt; i += AZK_WAVE) moves[nlist + i] = ms.ord[pos + i];
-        __syncthreads();
+        azk_wave_sync();
         insert_batch(tab, mask, moves, nlist + cnt);
         fill += nlist + cnt; pos += cnt; nlist = 0;
         if ((unsigned)fill * 5u >= mask * 3u) {                   // set_table_resize(so, used * 4)
@@ -406,7 +499,7 @@ __device__ int azk_valid_moves(const uint8_t *b, const GameDesc &g, int16_t *mov
                 if (i > mask) ms.claim[i] = 0xffffffffu;
                 if (i <= (newsize >> 5)) occ[i] = 0u;
             }
-            __syncthreads();
+            azk_wave_sync();
             uint16_t *tmp = tab; tab = other; other = tmp;
             mask = newsize - 1;
             fill = 0;                                             // the new table is empty until the batch above re-inserts
@@ -421,7 +514,7 @@ __device__ int azk_valid_moves(const uint8_t *b, const GameDesc &g, int16_t *mov
         if (kv) moves[n + __popcll(bm & ((1ull << lane) - 1ull))] = (int16_t)(kv - 1);
         n += __popcll(bm);
     }
-    __syncthreads();
+    azk_wave_sync();
     if (dbgv && lane == 0) { dbgv[0] += s1 - s0; dbgv[1] += s2 - s1; dbgv[2] += s3 - s2; dbgv[3] += clock64() - s3; dbgv[4] += m; }
     return n;
 }
