@@ -216,8 +216,10 @@ struct MoveScratch {
 //   Gomoku     gomoku.py:93-106     empty 8-neighbours of any stone as list(set(...)): CPython set
 //                                   iteration order; centre cell when there is no candidate.
 // All lanes must call this (it synchronises the single-wave workgroup).
-__device__ int azk_valid_moves(const uint8_t *b, const GameDesc &g, int16_t *moves, const MoveScratch &ms, bool skip_set = false,
-                               long long *dbgv = nullptr) {
+struct AzkNoHook { __device__ __forceinline__ void operator()() const {} };
+
+// The two small games (all lanes must call; synchronises the single-wave workgroup).
+__device__ __forceinline__ int azk_valid_moves_small(const uint8_t *b, const GameDesc &g, int16_t *moves) {
     const int lane = azk_lane();
     int n = 0;
     if (g.kind == AZK_KIND_TTT) {
@@ -231,17 +233,24 @@ __device__ int azk_valid_moves(const uint8_t *b, const GameDesc &g, int16_t *mov
         __syncthreads();
         return n;
     }
-    if (g.kind == AZK_KIND_C4) {
-        int cell = -1;
-        if (lane < g.cols && b[lane] == 0) {
-            for (int row = g.rows - 1; row >= 0; row--)
-                if (b[row * g.cols + lane] == 0) { cell = row * g.cols + lane; break; }
-        }
-        unsigned long long m = __ballot(cell >= 0);
-        if (cell >= 0) moves[__popcll(m & ((1ull << lane) - 1ull))] = (int16_t)cell;
-        __syncthreads();
-        return __popcll(m);
+    int cell = -1;                                                    // Connect4
+    if (lane < g.cols && b[lane] == 0) {
+        for (int row = g.rows - 1; row >= 0; row--)
+            if (b[row * g.cols + lane] == 0) { cell = row * g.cols + lane; break; }
     }
+    unsigned long long m = __ballot(cell >= 0);
+    if (cell >= 0) moves[__popcll(m & ((1ull << lane) - 1ull))] = (int16_t)cell;
+    __syncthreads();
+    return __popcll(m);
+}
+
+// Gomoku.  `mid` is called exactly once, by all lanes, after the first-adder keys - a few thousand cycles into the function:
+// k_tree looks at its eval-cache probe there, whose loads it issued before the call.
+template <typename Mid = AzkNoHook>
+__device__ int azk_valid_moves_gomoku(const uint8_t *b, const GameDesc &g, int16_t *moves, const MoveScratch &ms, bool skip_set = false,
+                                      long long *dbgv = nullptr, Mid &&mid = Mid()) {
+    const int lane = azk_lane();
+    int n = 0;
     // ---- Gomoku ----
     // The workgroup is ONE wave: LDS instructions of a wave execute in issue order, so a write followed by another lane's read
     // needs no wait between them, only a compiler-level fence (azk_wave_sync).  Every wait in this function is a data wait.
@@ -265,11 +274,13 @@ __device__ int azk_valid_moves(const uint8_t *b, const GameDesc &g, int16_t *mov
     //    The board as a bit string in scalar registers (one ballot per 64 cells): "is there a stone at cell e + delta" for the
     //    cell of lane l is bit l of the string shifted by delta - a wave-uniform 64-bit word used directly as the select mask
     //    of v_cndmask.  Neighbours across a row end are cut by the column masks (left neighbours need c >= 1, right ones
-    //    c <= C - 2); rows outside the board are zeros of the string.  No LDS, no atomics.  Needs C + 1 <= 63 (make_game: <= 30).
+    //    c <= C - 2); rows outside the board are zeros of the string.  No LDS round trip.  Needs C + 1 <= 63 (make_game: <= 30).
     unsigned long long S[KMAX + 1], CL[KMAX], CR[KMAX];
     bool empty[KMAX];
 #pragma unroll
     for (int k = 0; k < KMAX; k++) {
+        S[k] = 0ull; CL[k] = 0ull; CR[k] = 0ull; empty[k] = false;
+        if (AZK_WAVE * k >= rc) continue;                             // wave-uniform
         const int e = lane + AZK_WAVE * k;
         const bool in = e < rc;
         const int r = (int)(((unsigned)(in ? e : 0) * inv) >> 16), c = (in ? e : 0) - r * C;
@@ -279,31 +290,37 @@ __device__ int azk_valid_moves(const uint8_t *b, const GameDesc &g, int16_t *mov
         empty[k] = in && code[k] == 0;
     }
     S[KMAX] = 0ull;
+    // value of a key relative to its cell: (stone index - cell) * 8 + slot, per neighbour; the select chain runs over these eight
+    // constants (one register each, shared by all of a lane's cells) and the cell's own e * 8 is added once
+    const int cm1 = C > 1 ? C - 1 : 1;                               // (C = 1: the diagonal masks are empty, the shift just has to be legal)
+    const unsigned NONE = 0x7fffffffu;
+    const unsigned v_dr = (unsigned)((C + 1) * 8 + 5), v_d = (unsigned)(C * 8 + 3), v_dl = (unsigned)((C - 1) * 8 + 7), v_r = 9u;
+    const unsigned v_l = (unsigned)(-8), v_ur = (unsigned)(-(C - 1) * 8 + 6), v_u = (unsigned)(-C * 8 + 2), v_ul = (unsigned)(-(C + 1) * 8 + 4);
     unsigned key[KMAX];
 #pragma unroll
     for (int k = 0; k < KMAX; k++) {
         key[k] = 0xffffffffu;
         if (AZK_WAVE * k >= rc) continue;                             // wave-uniform
         const unsigned long long below = k > 0 ? S[k - 1] : 0ull, here = S[k], above = S[k + 1];
-        // bit l of up(a) = stone at cell (64 k + l) - a;  of down(d) = stone at cell (64 k + l) + d   (0 <= a, d <= 63)
-        auto up = [&](int a) { return (here << a) | ((below >> (63 - a)) >> 1); };
-        auto down = [&](int d) { return (here >> d) | ((above << (63 - d)) << 1); };
-        const unsigned e8 = (unsigned)(lane + AZK_WAVE * k) * 8u;
-        // select chain from the last candidate to the first (the first adder wins); value = (stone index) * 8 + slot
-        unsigned kk = 0xffffffffu;
-        kk = azk_sel_mask(down(C + 1) & CR[k], e8 + (unsigned)((C + 1) * 8 + 5), kk);   // (r+1, c+1) through (-1,-1)
-        kk = azk_sel_mask(down(C), e8 + (unsigned)(C * 8 + 3), kk);                     // (r+1, c)   through (-1, 0)
-        kk = azk_sel_mask(down(C - 1) & CL[k], e8 + (unsigned)((C - 1) * 8 + 7), kk);   // (r+1, c-1) through (-1,+1)
-        kk = azk_sel_mask(down(1) & CR[k], e8 + (unsigned)(8 + 1), kk);                 // (r, c+1)   through (0,-1)
-        kk = azk_sel_mask(up(1) & CL[k], e8 - 8u + 0u, kk);                             // (r, c-1)   through (0,+1)
-        kk = azk_sel_mask(up(C - 1) & CR[k], e8 - (unsigned)((C - 1) * 8) + 6u, kk);    // (r-1, c+1) through (+1,-1)
-        kk = azk_sel_mask(up(C), e8 - (unsigned)(C * 8) + 2u, kk);                      // (r-1, c)   through (+1, 0)
-        kk = azk_sel_mask(up(C + 1) & CL[k], e8 - (unsigned)((C + 1) * 8) + 4u, kk);    // stone (r-1, c-1) adds e through (+1,+1)
-        kk = empty[k] ? kk : 0xffffffffu;
+        // bit l of up(a) = stone at cell (64 k + l) - a;  of down(d) = stone at cell (64 k + l) + d   (1 <= a, d <= 63)
+        auto up = [&](int a) { return (here << a) | (below >> (64 - a)); };
+        auto down = [&](int d) { return (here >> d) | (above << (64 - d)); };
+        // select chain from the last candidate to the first (the first adder wins)
+        unsigned kk = NONE;
+        kk = azk_sel_mask(down(C + 1) & CR[k], v_dr, kk);             // (r+1, c+1) through (-1,-1)
+        kk = azk_sel_mask(down(C), v_d, kk);                          // (r+1, c)   through (-1, 0)
+        kk = azk_sel_mask(down(cm1) & CL[k], v_dl, kk);               // (r+1, c-1) through (-1,+1)
+        kk = azk_sel_mask(down(1) & CR[k], v_r, kk);                  // (r, c+1)   through (0,-1)
+        kk = azk_sel_mask(up(1) & CL[k], v_l, kk);                    // (r, c-1)   through (0,+1)
+        kk = azk_sel_mask(up(cm1) & CR[k], v_ur, kk);                 // (r-1, c+1) through (+1,-1)
+        kk = azk_sel_mask(up(C), v_u, kk);                            // (r-1, c)   through (+1, 0)
+        kk = azk_sel_mask(up(C + 1) & CL[k], v_ul, kk);               // stone (r-1, c-1) adds e through (+1,+1)
+        kk = (empty[k] && kk != NONE) ? (unsigned)(lane + AZK_WAVE * k) * 8u + kk : 0xffffffffu;
         if (kk != 0xffffffffu) atomicOr(&ms.bits[kk >> 5], 1u << (kk & 31));
         key[k] = kk;
     }
     azk_wave_sync();
+    mid();
     if (dbgv) s1 = clock64();
     // 2. exclusive popcount prefix over the key bitmap (<= 128 words)
     int total = 0;
@@ -382,36 +399,39 @@ __device__ int azk_valid_moves(const uint8_t *b, const GameDesc &g, int16_t *mov
     const int kreg = lane < n_small ? (int)ms.ord[lane] : 0;       // key j (cell + 1) in lane j
     const unsigned long long hreg = hash_cell1(kreg);
     unsigned long long nocc = ~0ull;                                // complement of the occupancy (one bit per slot), scalar
-    int tkey = 0;                                                   // the table: lane s holds slot s (0 = empty)
+    unsigned msk_cur = 7u;
+    int tidx = 0;                                                   // the table: lane s holds slot s as (list index of its key) + 1, 0 = empty
     // one insert: the first window of the probe sequence decides almost always (straight-line scalar code); the perturbed
-    // sequence is the rare path
-    auto insert_scalar = [&](int hv_lo, int hv_hi, int kv_reg, int src_lane, unsigned msk) {
-        const unsigned hl = (unsigned)__builtin_amdgcn_readlane(hv_lo, src_lane);
-        const unsigned i = hl & msk;
-        const unsigned win = (msk >= 9u && i + 9u <= msk) ? 0x3ffu : 1u;
+    // sequence is the rare path.  The table stores the key's LIST INDEX, so a re-insertion finds the key's hash where the first
+    // insertion did (lane j of hreg) - the tuple hash is computed once for both generations.
+    auto insert_scalar = [&](int j) {
+        const unsigned hl = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)hreg, j);
+        const unsigned i = hl & msk_cur;
+        const unsigned win = (msk_cur >= 9u && i + 9u <= msk_cur) ? 0x3ffu : 1u;
         const unsigned z = (unsigned)(nocc >> i) & win;
         unsigned slot;
         if (__builtin_expect(z == 0u, 0))
-            slot = probe_scalar(((unsigned long long)(unsigned)__builtin_amdgcn_readlane(hv_hi, src_lane) << 32) | hl, msk, ~nocc);
+            slot = probe_scalar(((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(hreg >> 32), j) << 32) | hl, msk_cur, ~nocc);
         else slot = i + (unsigned)__builtin_ctz(z);
         const unsigned long long bit = 1ull << slot;
         nocc &= ~bit;
-        tkey = (int)azk_sel_mask(bit, (unsigned)__builtin_amdgcn_readlane(kv_reg, src_lane), (unsigned)tkey);
+        tidx = (int)azk_sel_mask(bit, (unsigned)(j + 1), (unsigned)tidx);
     };
     const int n_gen1 = n_small < 5 ? n_small : 5;                  // 8-slot table: resize once fill * 5 >= 7 * 3
-    for (int j = 0; j < n_gen1; j++) insert_scalar((int)(unsigned)hreg, (int)(unsigned)(hreg >> 32), kreg, j, 7u);
+    for (int j = 0; j < n_gen1; j++) insert_scalar(j);
     if (n_gen1 == 5) {                                              // set_table_resize(so, 20): 32 slots, old table re-inserted in slot order
-        const unsigned long long oldh = hash_cell1(tkey);
-        const int oldk = tkey;
+        const int oldt = tidx;
         unsigned long long old = ~nocc;
-        nocc = ~0ull; tkey = 0;
+        nocc = ~0ull; tidx = 0; msk_cur = 31u;
         while (old) {
             const int s = __builtin_ctzll(old);
             old &= old - 1ull;
-            insert_scalar((int)(unsigned)oldh, (int)(unsigned)(oldh >> 32), oldk, s, 31u);
+            insert_scalar(__builtin_amdgcn_readlane(oldt, s) - 1);
         }
-        for (int j = 5; j < n_small; j++) insert_scalar((int)(unsigned)hreg, (int)(unsigned)(hreg >> 32), kreg, j, 31u);
+        for (int j = 5; j < n_small; j++) insert_scalar(j);
     }
+    const int key_of_slot = __shfl(kreg, tidx > 0 ? tidx - 1 : 0);  // (all lanes take part in the exchange)
+    const int tkey = tidx ? key_of_slot : 0;                        // slot s -> its key (cell + 1)
     const unsigned long long occ64 = ~nocc;
     const int below_me = __popcll(occ64 & ((1ull << lane) - 1ull));
     if (m < GEN2_FILL) {                                            // the set never outgrew 32 slots: list(set) = slot order
@@ -519,6 +539,10 @@ __device__ int azk_valid_moves(const uint8_t *b, const GameDesc &g, int16_t *mov
     return n;
 }
 
+__device__ __forceinline__ int azk_valid_moves(const uint8_t *b, const GameDesc &g, int16_t *moves, const MoveScratch &ms) {
+    return g.kind == AZK_KIND_GOMOKU ? azk_valid_moves_gomoku(b, g, moves, ms) : azk_valid_moves_small(b, g, moves);
+}
+
 // ---- deterministic float32 exp shared bit-for-bit with oracle/az_oracle.c (azo_exp_det) --------------
 __device__ __forceinline__ double azk_exp_det64(double x) {
     const double LOG2E = 1.4426950408889634, LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
@@ -591,7 +615,7 @@ __device__ float azk_pairwise_sum(const float *a, int n, float *racc) {
         for (int u = 1; u < 16; u++) r = (8 * u < lim) ? r + v[u] : r;
         racc[lane] = r;
     }
-    __syncthreads();
+    azk_wave_sync();
     if (lane == 0) {
         float left = azk_pw_block(a + s0, l0, racc);
         if (l1 > 0) left = left + azk_pw_block(a + s1, l1, racc + 8);
@@ -603,8 +627,8 @@ __device__ float azk_pairwise_sum(const float *a, int n, float *racc) {
         }
         racc[0] = res;
     }
-    __syncthreads();
+    azk_wave_sync();
     float res = racc[0];
-    __syncthreads();
+    azk_wave_sync();
     return res;
 }

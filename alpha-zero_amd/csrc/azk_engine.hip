@@ -332,7 +332,7 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev dd, const float *__restri
                 const float ev = (ablate & 1) ? 1.0f : azk_exp_det(lgv[k4]);
                 if (i < A) L.e[i] = ev;
             }
-            __syncthreads();
+            azk_wave_sync();
             if (cache_write) {
                 // (behind the exponentials: by now every logit is in its register, and the stores go out back to back - placed
                 //  right behind the loads, each store waited for the one before it, one write round trip per 64 actions)
@@ -389,7 +389,7 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev dd, const float *__restri
                 count_add(d, CNT_TRACE, g, depth + 1);
             }
         }
-        __syncthreads();   // this wave's tree writes are visible to its own SELECT reads below
+        azk_wave_sync();   // this wave's tree writes are visible to its own SELECT reads below
     }
 
     if (SELECT) {
@@ -406,7 +406,7 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev dd, const float *__restri
         const int root_player = uniform_i32(s_player);
         const int root_mc = uniform_i32(s_mc);
         if (lane == 0) L.path[0] = 0;
-        __syncthreads();
+        azk_wave_sync();
         int node = 0, depth = 0, scanned = 0;
         // header of the current node, carried in registers: one dependent round trip per level (the child scan itself
         // brings every candidate's header along, and the winner's is taken from the winning lane)
@@ -575,7 +575,7 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev dd, const float *__restri
             long long *qq = d.dbg + (size_t)g * 8;
             qq[0] += seg_a; qq[1] += seg_b; qq[2] += seg_c; qq[3] += seg_d; qq[5] += depth; qq[6] += 1;
         }
-        __syncthreads();
+        azk_wave_sync();
         if (stamp) t2 = clock64();
         if (vl && fc == -2) {                                         // the walk ended on a node another slot is already evaluating: no simulation
             done_sims--;
@@ -607,22 +607,20 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev dd, const float *__restri
             break;
         }
         if (stamp) t3 = clock64();
-        int nv;
-        if (ablate & 4) { nv = 1; if (lane == 0) L.moves[0] = (int16_t)(gd.rc / 2); __syncthreads(); }
-        else nv = azk_valid_moves(L.board, gd, L.moves, L.ms, (ablate & 8) != 0, (ablate & 32) ? d.dbg + (size_t)g * 8 : nullptr);  // mcts.py:34
-        if (stamp) t4 = clock64();
-        for (int i = lane; i < nv; i += AZK_WAVE) d.leaf_moves[(size_t)vi * rc + i] = L.moves[i];
-        for (int i = lane; i < rc; i += AZK_WAVE) d.leaf_cells[(size_t)vi * d.rc_pad + i] = L.board[i];
-        for (int i = lane; i <= depth; i += AZK_WAVE) d.path[(size_t)vi * d.path_cap + i] = L.path[i];
-        if (vl) {                                                     // virtual loss: the path counts a visit now and a lost game until its value arrives
-            for (int i = lane; i <= depth; i += AZK_WAVE) { const int nd = L.path[i]; d.H[base + nd].N += 1; d.W[base + nd] -= 1.0; }
-            if (lane == 0) d.H[base + node].fc = -2;           // "expansion pending": a second slot arriving here gives up
-        }
+        // ---- eval-cache probe (mcts.py:37-44: key = canonical board bytes), ISSUED HERE and looked at after the legal moves: the
+        //      table sits in HBM, and its round trips (claim word + key + row, then the claim word again for a hit) pass under the
+        //      move generation instead of behind it.  key = ballots of "own stone" / "opponent stone" over the cells (own = the
+        //      side to move at the leaf)
         bool cached = false;
-        if (d.cache_entries) {                                        // mcts.py:37-44: key = canonical board bytes
-            // key = ballots of "own stone" / "opponent stone" over the cells (own = the side to move at the leaf)
-            const int KW = d.key_words, half = KW >> 1;
-            unsigned long long mykey = 0ull, h = 0x9E3779B97F4A7C15ull;
+        int entry = 0;
+        unsigned long long mykey = 0ull, kw = 0ull;
+        unsigned c1v = 0u, c2v = 0u;
+        float row[KSL] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, vv = 0.f;
+        bool maybe_hit = false;                                       // shared table: key and claim word say "hit" - the second claim read decides
+        const int KW = d.key_words;
+        if (d.cache_entries) {
+            const int half = KW >> 1;
+            unsigned long long h = 0x9E3779B97F4A7C15ull;
             for (int q = 0; q < half; q++) {
                 const int c = q * AZK_WAVE + lane;
                 const uint8_t code = c < rc ? L.board[c] : (uint8_t)0;
@@ -634,37 +632,63 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev dd, const float *__restri
                 h = (h ^ own) * 0xFF51AFD7ED558CCDull; h ^= h >> 29;
                 h = (h ^ opp) * 0xC4CEB9FE1A85EC53ull; h ^= h >> 32;
             }
-            int entry;
             if (shared) {
                 entry = (int)(h & d.cache_mask);
-                // one round trip for the claim word, the key and the entry's row (fetched on speculation: most probes miss, a row is
-                // 900 bytes), a second one for the claim word again; the reads of a hit used to be four dependent round trips
-                const unsigned c1 = (unsigned)uniform_i32((int)__hip_atomic_load(d.cache_claim + entry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                const unsigned long long kw = d.cache_key[(size_t)entry * KW + min(lane, KW - 1)];
-                float row[KSL];
+                // the claim word, the key and the entry's row (fetched on speculation: most probes miss, a row is 900 bytes) together
+                c1v = __hip_atomic_load(d.cache_claim + entry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                kw = d.cache_key[(size_t)entry * KW + min(lane, KW - 1)];
 #pragma unroll
                 for (int k4 = 0; k4 < KSL; k4++) { const int i = lane + AZK_WAVE * k4; row[k4] = d.cache_logits[(size_t)entry * A + (i < A ? i : A - 1)]; }
-                const float vv = d.cache_value[entry];
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the copy is in registers before the claim word is read again
-                const bool same = lane < KW ? kw == mykey : true;
-                if (c1 != 0u && c1 < cstamp && __ballot(!same) == 0ull) {     // written in an earlier launch (complete and visible), same position
-                    const unsigned c2 = (unsigned)uniform_i32((int)__hip_atomic_load(d.cache_claim + entry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                    if (c2 == c1) {                                       // nobody started rewriting the entry meanwhile: the copy is whole
-                        cached = true;
+                vv = d.cache_value[entry];
+            } else {
+                entry = (int)(h & (unsigned long long)(d.cache_entries - 1));
+                kw = d.cache_key[((size_t)g * d.cache_entries + entry) * KW + min(lane, KW - 1)];
+            }
+        }
+        // called by the move generator once its first phase is behind it (a few thousand cycles after the loads above went out):
+        // the copy of the row is in registers before the claim word is read again
+        auto probe_mid = [&]() {
+            if (!(d.cache_entries && shared)) return;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned c1 = (unsigned)uniform_i32((int)c1v);
+            const bool same = lane < KW ? kw == mykey : true;
+            maybe_hit = c1 != 0u && c1 < cstamp && __ballot(!same) == 0ull;   // written in an earlier launch (complete and visible), same position
+            if (maybe_hit) c2v = __hip_atomic_load(d.cache_claim + entry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        };
+        // (the second claim read is consumed inside each branch: a load still in flight where the branches meet makes the compiler
+        //  wait for it wherever its register is reused - here that was the head of the Gomoku move generation, in front of
+        //  everything the probe is meant to pass under)
+        int nv;
+        unsigned c2 = 0u;
+        if (ablate & 4) { nv = 1; if (lane == 0) L.moves[0] = (int16_t)(gd.rc / 2); __syncthreads(); probe_mid(); c2 = (unsigned)uniform_i32((int)c2v); }
+        else if (gd.kind == AZK_KIND_GOMOKU) {                         // mcts.py:34
+            nv = azk_valid_moves_gomoku(L.board, gd, L.moves, L.ms, (ablate & 8) != 0, (ablate & 32) ? d.dbg + (size_t)g * 8 : nullptr, probe_mid);
+            c2 = (unsigned)uniform_i32((int)c2v);
+        } else { probe_mid(); c2 = (unsigned)uniform_i32((int)c2v); nv = azk_valid_moves_small(L.board, gd, L.moves); }
+        if (stamp) t4 = clock64();
+        if (d.cache_entries) {
+            if (shared) {
+                if (maybe_hit && c2 == (unsigned)uniform_i32((int)c1v)) {   // nobody started rewriting the entry meanwhile: the copy is whole
+                    cached = true;
 #pragma unroll
-                        for (int k4 = 0; k4 < KSL; k4++) { const int i = lane + AZK_WAVE * k4; if (i < A) d.hit_logits[(size_t)vi * A + i] = row[k4]; }
-                        if (lane == 0) d.hit_value[vi] = vv;
-                    }
+                    for (int k4 = 0; k4 < KSL; k4++) { const int i = lane + AZK_WAVE * k4; if (i < A) d.hit_logits[(size_t)vi * A + i] = row[k4]; }
+                    if (lane == 0) d.hit_value[vi] = vv;
                 }
                 if (!cached && lane < KW) d.leaf_key[(size_t)vi * KW + lane] = mykey;      // written into the table at expansion
             } else {
-                entry = (int)(h & (unsigned long long)(d.cache_entries - 1));
                 unsigned long long *kp = d.cache_key + ((size_t)g * d.cache_entries + entry) * KW;
-                const bool same = lane < KW ? kp[lane] == mykey : true;
+                const bool same = lane < KW ? kw == mykey : true;
                 cached = __ballot(!same) == 0ull;
                 if (!cached && lane < KW) kp[lane] = mykey;            // claim the slot now; logits/value land at expansion
             }
             if (lane == 0) d.leaf_cache[vi] = cached ? entry : -(entry + 1);
+        }
+        for (int i = lane; i < nv; i += AZK_WAVE) d.leaf_moves[(size_t)vi * rc + i] = L.moves[i];
+        for (int i = lane; i < rc; i += AZK_WAVE) d.leaf_cells[(size_t)vi * d.rc_pad + i] = L.board[i];
+        for (int i = lane; i <= depth; i += AZK_WAVE) d.path[(size_t)vi * d.path_cap + i] = L.path[i];
+        if (vl) {                                                     // virtual loss: the path counts a visit now and a lost game until its value arrives
+            for (int i = lane; i <= depth; i += AZK_WAVE) { const int nd = L.path[i]; d.H[base + nd].N += 1; d.W[base + nd] -= 1.0; }
+            if (lane == 0) d.H[base + node].fc = -2;           // "expansion pending": a second slot arriving here gives up
         }
         if (lane == 0) {
             d.leaf_node[vi] = node; d.leaf_depth[vi] = depth; d.leaf_nmoves[vi] = nv;
@@ -1489,7 +1513,8 @@ bool make_game(int kind, int rows, int cols, GameDesc *g, std::string *err) {
     if (kind == AZK_TICTACTOE) { rows = 3; cols = 3; g->planes = 3; g->win_len = 3; g->action_dim = 9; }
     else if (kind == AZK_CONNECT4) { rows = 6; cols = 7; g->planes = 3; g->win_len = 4; g->action_dim = 7; }
     else if (kind == AZK_GOMOKU) {
-        if (rows < 1 || cols < 1 || rows * cols > 400) { *err = "gomoku board must have 1..400 cells"; return false; }
+        // (<= 30 columns: azk_valid_moves_gomoku shifts the board's bit string by up to cols + 1 inside 64-bit words)
+        if (rows < 1 || cols < 1 || rows * cols > 400 || cols > 30) { *err = "gomoku board must have 1..400 cells and at most 30 columns"; return false; }
         g->planes = 2; g->win_len = 5; g->action_dim = rows * cols;
     } else { *err = "unknown game id"; return false; }
     g->rows = rows; g->cols = cols; g->rc = rows * cols; g->state_dim = rows * cols;

@@ -52,6 +52,6 @@ if os.environ.get("AZK_TREE_ABLATE") == "64":
     print("walk per simulation (cycles): load wait %.0f | loads+ucb %.0f (incl. the wait) | argmax+readlanes %.0f | path/board update %.0f | levels %.2f" % (
         out[0] / n, out[1] / n, out[2] / n, out[3] / n, out[5] / n))
 if os.environ.get("AZK_TREE_ABLATE") == "32":
-    n = 8192000
-    print("valid_moves sub-phases (cycles per sim): keys %.0f | prefix+rank %.0f | inserts %.0f | emit %.0f | candidates %.1f" % (
+    n = max(1, eng.counters()["leaves_evaluated"] + eng.counters()["cache_hits"])      # one call per non-terminal simulation
+    print("valid_moves sub-phases (cycles per call): keys %.0f | prefix+rank %.0f | inserts %.0f | emit %.0f | candidates %.1f" % (
         out[0] / n, out[1] / n, out[2] / n, out[3] / n, out[4] / n))
