@@ -574,22 +574,14 @@ __device__ __forceinline__ double azk_exp_det64(double x) {
 __device__ __forceinline__ float azk_exp_det(float x) { return (float)azk_exp_det64((double)x); }
 
 // numpy's float32 pairwise summation (numpy/core/src/umath/loops_utils.h.src), n <= 512.
-// a[] in LDS, racc = 32 floats of LDS scratch.  All lanes call; returns the sum on every lane.
-// Recursion: n <= 128 -> one 8-accumulator block; else split at n2 = n/2 - (n/2)%8 and recurse.
-__device__ __forceinline__ float azk_pw_block(const float *p, int len, const float *r) {
-    // finish one leaf block on a single lane: r[0..7] are the strided accumulators
-    float s;
-    if (len < 8) {
-        s = 0.f;
-        for (int i = 0; i < len; i++) s += p[i];
-    } else {
-        s = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
-        for (int i = len - (len % 8); i < len; i++) s += p[i];
-    }
-    return s;
-}
-
+// a[] in LDS (racc is no longer used).  All lanes call; returns the sum on every lane.
+// Recursion: n <= 128 -> one 8-accumulator block; else split at n2 = n/2 - (n/2)%8 and recurse: at most four leaf blocks.
+// Lanes 8q .. 8q+7 own block q: lane j runs accumulator r[j] (a[j] + a[j+8] + ... in index order), the combine
+// ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) is three DPP exchanges inside the group of eight (float addition commutes, so either side of a
+// pair computes the same bits), the block's last len % 8 elements are added in order, and the block sums meet through v_readlane.
+// No LDS writes and no single-lane epilogue.
 __device__ float azk_pairwise_sum(const float *a, int n, float *racc) {
+    (void)racc;
     const int lane = azk_lane();
     // leaf blocks (start, len); a block with len 0 does not exist
     int s0 = 0, l0 = n, s1 = 0, l1 = 0, s2 = 0, l2 = 0, s3 = 0, l3 = 0;
@@ -600,35 +592,38 @@ __device__ float azk_pairwise_sum(const float *a, int n, float *racc) {
         if (ll > 128) { int h = ll / 2; h -= h % 8; l0 = h; s1 = ls + h; l1 = ll - h; }
         if (rl > 128) { int h = rl / 2; h -= h % 8; l2 = h; s3 = rs + h; l3 = rl - h; }
     }
-    int q = lane >> 3, j = lane & 7;
-    int ms = q == 0 ? s0 : (q == 1 ? s1 : (q == 2 ? s2 : s3));
-    int ml = q == 0 ? l0 : (q == 1 ? l1 : (q == 2 ? l2 : (q == 3 ? l3 : 0)));
-    if (ml >= 8) {
-        const float *p = a + ms;
-        const int lim = ml - (ml % 8);
-        // a leaf block has at most 128 elements: 16 strided terms per accumulator, all loads in flight before the first add
-        float v[16];
+    const int q = (lane >> 3) & 3, j = lane & 7;                      // (lanes 32..63 repeat the blocks: their results are not read)
+    const int ms = q == 0 ? s0 : (q == 1 ? s1 : (q == 2 ? s2 : s3));
+    const int ml = q == 0 ? l0 : (q == 1 ? l1 : (q == 2 ? l2 : l3));
+    const float *p = a + ms;
+    const int lim = ml - (ml % 8);                                    // elements that go through the accumulators (0 when ml < 8)
+    // a leaf block has at most 128 elements: 16 strided terms per accumulator and up to 7 in the tail, all loads in flight
+    // before the first add (indices clamped into the block; a block of length 0 reads a[0])
+    float v[16], tl[7];
 #pragma unroll
-        for (int u = 0; u < 16; u++) v[u] = p[(8 * u < lim ? 8 * u : 0) + j];
-        float r = v[0];
+    for (int u = 0; u < 16; u++) v[u] = p[(8 * u < lim ? 8 * u : 0) + (lim > 0 ? j : 0)];
 #pragma unroll
-        for (int u = 1; u < 16; u++) r = (8 * u < lim) ? r + v[u] : r;
-        racc[lane] = r;
+    for (int t = 0; t < 7; t++) tl[t] = p[lim + t < ml ? lim + t : 0];
+    float r = v[0];
+#pragma unroll
+    for (int u = 1; u < 16; u++) r = (8 * u < lim) ? r + v[u] : r;
+    r = r + dpp_f32<0xB1>(r);                                         // r0+r1 | r2+r3 | r4+r5 | r6+r7      (quad_perm [1,0,3,2])
+    r = r + dpp_f32<0x4E>(r);                                         // (r0+r1)+(r2+r3) | (r4+r5)+(r6+r7)  (quad_perm [2,3,0,1])
+    r = r + dpp_f32<0x141>(r);                                        // both halves of the eight            (row_half_mirror)
+    float sblk = lim > 0 ? r : 0.f;                                   // numpy: n < 8 starts from 0. and adds the elements in order
+#pragma unroll
+    for (int t = 0; t < 7; t++) sblk = (lim + t < ml) ? sblk + tl[t] : sblk;
+    const float b0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sblk), 0));
+    const float b1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sblk), 8));
+    const float b2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sblk), 16));
+    const float b3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sblk), 24));
+    float left = b0;
+    if (l1 > 0) left = left + b1;
+    float res = left;
+    if (l2 > 0) {
+        float right = b2;
+        if (l3 > 0) right = right + b3;
+        res = left + right;
     }
-    azk_wave_sync();
-    if (lane == 0) {
-        float left = azk_pw_block(a + s0, l0, racc);
-        if (l1 > 0) left = left + azk_pw_block(a + s1, l1, racc + 8);
-        float res = left;
-        if (l2 > 0) {
-            float right = azk_pw_block(a + s2, l2, racc + 16);
-            if (l3 > 0) right = right + azk_pw_block(a + s3, l3, racc + 24);
-            res = left + right;
-        }
-        racc[0] = res;
-    }
-    azk_wave_sync();
-    float res = racc[0];
-    azk_wave_sync();
     return res;
 }
