@@ -866,6 +866,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_h(GemmHArgs a) {
     const int rtiles = (nvalid + WROWS - 1) / WROWS, ctiles = a.N / WCOLS;
     const int nitems = rtiles * ctiles * a.nbatch;
     union HF { uint4 u; f16x8 v; };
+    bool oflow_seen = false;                                          // a plane value left fp16's range: reported once, at the end (a.oflow, sticky)
     for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
         if (NWK > 1 && item != (int)blockIdx.x) __syncthreads();
         const int ct = item % ctiles, r2 = item / ctiles, rt = r2 % rtiles, b = r2 / rtiles;
@@ -925,7 +926,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_h(GemmHArgs a) {
 #pragma unroll
                     for (int e = 0; e < 8; e++) {
                         const float x = af[u][i][e >> 2][e & 3] * a.a_scale;
-                        if (a.oflow && !(fabsf(x) < 65504.0f)) atomicOr(a.oflow, 1);
+                        oflow_seen |= !(fabsf(x) < 65504.0f);
                         const _Float16 h = (_Float16)x;
                         ah[u][i].v[e] = h;
                         al[u][i].v[e] = (_Float16)(x - (float)h);
@@ -1004,7 +1005,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_h(GemmHArgs a) {
 #pragma unroll
                         for (int c = 0; c < 4; c++) {
                             const float x = v[c] * a.a_scale;
-                            if (a.oflow && !(fabsf(x) < 65504.0f)) atomicOr(a.oflow, 1);
+                            oflow_seen |= !(fabsf(x) < 65504.0f);
                             ph.h[c] = (_Float16)x; pl.h[c] = (_Float16)(x - (float)ph.h[c]);
                         }
                         *(uint2 *)(a.ohi + (size_t)row * a.ldo + col0) = ph.u;
@@ -1017,6 +1018,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_h(GemmHArgs a) {
                 }
             }
     }
+    if (a.oflow && oflow_seen) atomicOr(a.oflow, 1);
 }
 
 template <int EPI, int LNA, int AIN, int NWK, int KW>

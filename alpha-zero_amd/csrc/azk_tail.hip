@@ -372,6 +372,7 @@ template <class T, int LNA, int EPI, bool AZK_XCD_ROWS>
 __device__ __forceinline__ void gemm_h_lds_body(const HArgs &a, const int nvalid, char *const lds) {
     constexpr int WM = T::WM, WN = T::WN, RT = T::RT, BM = T::BM, BN = T::BN;
     static_assert(T::PL == 2, "(hi, lo) fp16 planes");
+    bool oflow_seen = false;                                             // a plane value left fp16's range: reported once, at the end (a.oflow, sticky)
     if ((int)(threadIdx.x >> 6) >= T::NW) return;                       // a tiling with fewer waves than the launch carries: the surplus waves leave before any barrier
     const int ctiles = a.N / BN;
     // block -> tile.  Blocks b and b + 8 share an XCD (round-robin dispatch; speed only): with XR the XCD index picks the ROW tile (row tiles
@@ -444,7 +445,7 @@ __device__ __forceinline__ void gemm_h_lds_body(const HArgs &a, const int nvalid
 #pragma unroll
                     for (int c = 0; c < 4; c++) {
                         const float x = v[c] * a.a_scale;
-                        if (a.oflow && !(fabsf(x) < 65504.0f)) atomicOr(a.oflow, 1);
+                        oflow_seen |= !(fabsf(x) < 65504.0f);
                         ph.h[c] = (_Float16)x; pl.h[c] = (_Float16)(x - (float)ph.h[c]);
                     }
                     *(uint2 *)(a.ohi + (size_t)row * a.ldo + col0) = ph.u;
@@ -457,6 +458,7 @@ __device__ __forceinline__ void gemm_h_lds_body(const HArgs &a, const int nvalid
             }
         }
     }
+    if (a.oflow && oflow_seen) atomicOr(a.oflow, 1);
 }
 
 template <class T1, class T2, int SWITCH, int LNA, int EPI>
