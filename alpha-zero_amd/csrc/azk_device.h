@@ -15,6 +15,7 @@
 // stateless float32 API).  Empty <=> code == 0 (the reference tests plane0 == 0 and plane1 == 0).
 struct GameDesc {
     int kind, rows, cols, rc, planes, win_len, action_dim, state_dim;
+    unsigned inv_cols;      // ceil(65536 / cols): cell / cols == (cell * inv_cols) >> 16, exact for cell < 65536 / cols (make_game)
 };
 
 __device__ __forceinline__ int azk_action_idx(const GameDesc &g, int cell) {
@@ -170,20 +171,30 @@ __device__ __forceinline__ int wave_sum_i32(int v) {
 // 1 + run(+dir) + run(-dir) >= K for any of the four directions; the origin cell itself is NOT
 // tested (the reference's counter starts at 1).  Lanes 0..7 each walk one (direction, side).
 __device__ __forceinline__ int azk_check_winner(const uint8_t *b, const GameDesc &g, int player, int cell) {
-    int lane = azk_lane();
-    int cnt = 0;
-    if (lane < 8) {
-        int d = lane >> 1, sg = (lane & 1) ? -1 : 1;
-        int dr = (d > 0 ? 1 : 0) * sg;
-        int dc = (d == 0 ? 1 : (d == 1 ? 0 : (d == 2 ? 1 : -1))) * sg;
-        int r = cell / g.cols + dr, c = cell % g.cols + dc;
-        while (cnt < g.win_len - 1 && r >= 0 && r < g.rows && c >= 0 && c < g.cols &&
-               ((b[r * g.cols + c] >> player) & 1)) {
-            cnt++; r += dr; c += dc;
-        }
+    const int lane = azk_lane();
+    // lanes 0..7: one (direction, side) each.  The up to win_len - 1 <= 4 cells of the walk are fetched together (one LDS round trip,
+    // not one per step) and the run is the number of leading own stones.
+    const int d = (lane >> 1) & 3, sg = (lane & 1) ? -1 : 1;
+    const int dr = (d > 0 ? 1 : 0) * sg;
+    const int dc = (d == 0 ? 1 : (d == 1 ? 0 : (d == 2 ? 1 : -1))) * sg;
+    const int r0 = (int)(((unsigned)cell * g.inv_cols) >> 16), c0 = cell - r0 * g.cols;
+    uint8_t v[4];
+    bool in[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int r = r0 + dr * (k + 1), c = c0 + dc * (k + 1);
+        in[k] = k + 1 < g.win_len && r >= 0 && r < g.rows && c >= 0 && c < g.cols;
+        v[k] = b[in[k] ? r * g.cols + c : 0];
     }
-    int other = __shfl_xor(cnt, 1);
-    bool win = lane < 8 && (1 + cnt + other >= g.win_len);
+    int cnt = 0;
+    bool run = lane < 8;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        run = run && in[k] && ((v[k] >> player) & 1);
+        cnt += run ? 1 : 0;
+    }
+    const int other = dpp_i32<0xB1>(cnt);                              // the opposite side of the same direction (quad_perm [1,0,3,2])
+    const bool win = lane < 8 && (1 + cnt + other >= g.win_len);
     return __ballot(win) != 0ull ? player : -1;
 }
 
@@ -260,7 +271,7 @@ __device__ int azk_valid_moves_gomoku(const uint8_t *b, const GameDesc &g, int16
     long long s0 = dbgv ? clock64() : 0, s1 = 0, s2 = 0, s3 = 0;
     // this lane's cells (lane + 64 k): board codes and columns once, straight-line (no load sits behind a branch);
     // e / C by multiplication: exact for e < 65536 / C
-    const unsigned inv = (65536u + (unsigned)C - 1u) / (unsigned)C;
+    const unsigned inv = g.inv_cols;
     uint8_t code[KMAX];
 #pragma unroll
     for (int k = 0; k < KMAX; k++) {

@@ -1551,6 +1551,7 @@ bool make_game(int kind, int rows, int cols, GameDesc *g, std::string *err) {
         g->planes = 2; g->win_len = 5; g->action_dim = rows * cols;
     } else { *err = "unknown game id"; return false; }
     g->rows = rows; g->cols = cols; g->rc = rows * cols; g->state_dim = rows * cols;
+    g->inv_cols = (65536u + (unsigned)cols - 1u) / (unsigned)cols;
     return true;
 }
 
