@@ -503,6 +503,55 @@ def test_budget_stepping_whole_games_identical(azk):
     assert s0["sims"] == s1["sims"] and s0["leaves_evaluated"] == s1["leaves_evaluated"] and s0["cache_hits"] == s1["cache_hits"]
 
 
+def test_gomoku_move_lists_around_the_set_resize_thresholds(azk, ao):
+    """The CPython set behind gomoku.py:93-106 grows 8 -> 32 -> 128 -> 512 slots at 5, 19 and 77 elements; the kernel replays the
+    first two generations on the scalar unit and hands over to LDS rounds at the third.  Boards with exactly 1..24, 60..66 (one lane per
+    key, then two chunks) and 75..80 candidate moves, several of each, against the oracle's list order."""
+    size = 15
+    game = ao.OracleGame("gomoku", size)
+    rng = np.random.RandomState(77)
+    want = set(range(3, 25)) | set(range(60, 67)) | set(range(75, 81))
+    per_count, boards = {}, []
+    boards.append(np.zeros((2, size, size), np.float32))          # no stone: the centre cell alone (gomoku.py:103-104)
+    for k in (1, 2, 3):                                            # a full board but for k cells: 1, 2, 3 candidates
+        b = np.zeros((2, size, size), np.float32)
+        u = rng.rand(size, size)
+        b[0] = u < 0.5
+        b[1] = u >= 0.5
+        for cell in rng.choice(size * size, k, replace=False):
+            b[:, cell // size, cell % size] = 0.0
+        assert len(game.valid_cells(b)) == k
+        boards.append(b)
+    tries = 0
+    while tries < 40000 and any(per_count.get(m, 0) < 3 for m in want):
+        tries += 1
+        n_stones = int(rng.randint(1, 60))
+        b = np.zeros((2, size, size), np.float32)
+        if rng.rand() < 0.5:                       # clustered: few candidates per stone
+            r0, c0 = rng.randint(0, size, 2)
+            cells = set()
+            for _ in range(4 * n_stones):               # (bounded: a window at the board's edge has fewer than n_stones cells)
+                r, c = r0 + int(rng.randint(-3, 4)), c0 + int(rng.randint(-3, 4))
+                if 0 <= r < size and 0 <= c < size and len(cells) < n_stones:
+                    cells.add((r, c))
+            cells.add((int(r0), int(c0)))
+        else:                                       # scattered: many
+            cells = set(map(tuple, rng.randint(0, size, (n_stones, 2)).tolist()))
+        for i, (r, c) in enumerate(sorted(cells)):
+            b[i & 1, r, c] = 1.0
+        m = len(game.valid_cells(b))
+        if m in want and per_count.get(m, 0) < 3:
+            per_count[m] = per_count.get(m, 0) + 1
+            boards.append(b)
+    missing = sorted(m for m in want if per_count.get(m, 0) == 0)
+    assert not missing, missing
+    boards = np.stack(boards)
+    moves, counts = azk.rules_legal_moves("gomoku", torch.from_numpy(boards).to(dev()), size)
+    moves, counts = moves.cpu().numpy(), counts.cpu().numpy()
+    for i in range(len(boards)):
+        assert moves[i, :counts[i]].tolist() == game.valid_cells(boards[i]).tolist(), (i, int(counts[i]))
+
+
 @pytest.mark.parametrize("size,plies,n_sims", [(19, 0, 40), (19, 30, 120), (20, 90, 80), (11, 14, 150)])
 def test_large_and_odd_gomoku_boards_vs_oracle(azk, ao, size, plies, n_sims):
     """Boards beyond 256 cells (19x19, 20x20: seven cells per lane, the 2048-slot set tables) and an odd mid size: legal-move
