@@ -214,10 +214,8 @@ struct MoveScratch {
     uint32_t *bits;              // [ceil(rc*8/32)] first-adder key bitmap
     uint16_t *pref;              // [ceil(rc*8/32)] exclusive popcount prefix
     int16_t *ord;                // [rc] candidate cells in first-insertion order
-    unsigned long long *chash;   // [rc] tuple hash per cell
     uint16_t *tabA, *tabB;       // [table_size] emulated set tables (cell+1, 0 = empty)
     uint32_t *claim;             // [table_size] per-slot lowest claiming lane of the current round (0xffffffff = none)
-    uint32_t *rows;              // [64] row bitmasks: [0,32) stones, [32,64) occupied (bit c+1 of word r+1)
     int table_size;
 };
 
@@ -585,14 +583,13 @@ __device__ __forceinline__ double azk_exp_det64(double x) {
 __device__ __forceinline__ float azk_exp_det(float x) { return (float)azk_exp_det64((double)x); }
 
 // numpy's float32 pairwise summation (numpy/core/src/umath/loops_utils.h.src), n <= 512.
-// a[] in LDS (racc is no longer used).  All lanes call; returns the sum on every lane.
+// a[] in LDS.  All lanes call; returns the sum on every lane.
 // Recursion: n <= 128 -> one 8-accumulator block; else split at n2 = n/2 - (n/2)%8 and recurse: at most four leaf blocks.
 // Lanes 8q .. 8q+7 own block q: lane j runs accumulator r[j] (a[j] + a[j+8] + ... in index order), the combine
 // ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) is three DPP exchanges inside the group of eight (float addition commutes, so either side of a
 // pair computes the same bits), the block's last len % 8 elements are added in order, and the block sums meet through v_readlane.
 // No LDS writes and no single-lane epilogue.
-__device__ float azk_pairwise_sum(const float *a, int n, float *racc) {
-    (void)racc;
+__device__ float azk_pairwise_sum(const float *a, int n) {
     const int lane = azk_lane();
     // leaf blocks (start, len); a block with len 0 does not exist
     int s0 = 0, l0 = n, s1 = 0, l1 = 0, s2 = 0, l2 = 0, s3 = 0, l3 = 0;

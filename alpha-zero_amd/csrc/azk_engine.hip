@@ -80,7 +80,6 @@ struct LdsView {
     int *path;
     int16_t *moves;
     float *e;
-    float *racc;
     int *cnt;
     double *cdf;
     MoveScratch ms;
@@ -89,49 +88,43 @@ struct LdsView {
 __host__ __device__ inline int up16(int x) { return (x + 15) & ~15; }
 
 __host__ __device__ inline int lds_layout(const GameDesc &g, int path_cap, int table_size, int *off) {
-    // offsets (bytes) of: board, path, moves, e, racc, cnt, cdf, bits, pref, ord, chash, tabA, tabB, claim, rows
+    // offsets (bytes) of: board, path, moves, e, cnt, cdf, bits, pref, ord, tabA, tabB, claim
     int o = 0;
     off[0] = o; o += up16(g.rc);
     off[1] = o; o += up16(path_cap * 4);
     off[2] = o; o += up16(g.rc * 2);
     int ea = g.action_dim > g.rc ? g.action_dim : g.rc;
     off[3] = o; o += up16(ea * 4);
-    off[4] = o; o += 128;
-    off[5] = o; o += up16(ea * 4);
-    off[6] = o; o += up16(ea * 8);
+    off[4] = o; o += up16(ea * 4);
+    off[5] = o; o += up16(ea * 8);
     int nwords = (g.rc * 8 + 31) >> 5;
-    off[7] = o; o += up16((nwords > (table_size >> 5) + 2 ? nwords : (table_size >> 5) + 2) * 4);   // key bitmap, later the set table's occupancy bitmap
-    off[8] = o; o += up16(nwords * 2);
-    off[9] = o; o += up16(g.rc * 2);
-    off[10] = o; o += up16(g.rc * 8);
-    off[11] = o; o += up16(table_size * 2);
-    off[12] = o; o += up16(table_size * 2);
-    off[13] = o; o += up16(table_size * 4);
-    off[14] = o; o += 256;
+    off[6] = o; o += up16((nwords > (table_size >> 5) + 2 ? nwords : (table_size >> 5) + 2) * 4);   // key bitmap, later the set table's occupancy bitmap
+    off[7] = o; o += up16(nwords * 2);
+    off[8] = o; o += up16(g.rc * 2);
+    off[9] = o; o += up16(table_size * 2);
+    off[10] = o; o += up16(table_size * 2);
+    off[11] = o; o += up16(table_size * 4);
     return o;
 }
 
 extern __shared__ __attribute__((aligned(16))) unsigned char azk_smem[];
 
 __device__ __forceinline__ LdsView carve(const GameDesc &g, int path_cap, int table_size) {
-    int off[15];
+    int off[12];
     lds_layout(g, path_cap, table_size, off);
     LdsView L;
     L.board = azk_smem + off[0];
     L.path = (int *)(azk_smem + off[1]);
     L.moves = (int16_t *)(azk_smem + off[2]);
     L.e = (float *)(azk_smem + off[3]);
-    L.racc = (float *)(azk_smem + off[4]);
-    L.cnt = (int *)(azk_smem + off[5]);
-    L.cdf = (double *)(azk_smem + off[6]);
-    L.ms.bits = (uint32_t *)(azk_smem + off[7]);
-    L.ms.pref = (uint16_t *)(azk_smem + off[8]);
-    L.ms.ord = (int16_t *)(azk_smem + off[9]);
-    L.ms.chash = (unsigned long long *)(azk_smem + off[10]);
-    L.ms.tabA = (uint16_t *)(azk_smem + off[11]);
-    L.ms.tabB = (uint16_t *)(azk_smem + off[12]);
-    L.ms.claim = (uint32_t *)(azk_smem + off[13]);
-    L.ms.rows = (uint32_t *)(azk_smem + off[14]);
+    L.cnt = (int *)(azk_smem + off[4]);
+    L.cdf = (double *)(azk_smem + off[5]);
+    L.ms.bits = (uint32_t *)(azk_smem + off[6]);
+    L.ms.pref = (uint16_t *)(azk_smem + off[7]);
+    L.ms.ord = (int16_t *)(azk_smem + off[8]);
+    L.ms.tabA = (uint16_t *)(azk_smem + off[9]);
+    L.ms.tabB = (uint16_t *)(azk_smem + off[10]);
+    L.ms.claim = (uint32_t *)(azk_smem + off[11]);
     L.ms.table_size = table_size;
     return L;
 }
@@ -356,7 +349,7 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev dd, const float *__restri
                 if (lane == 0) d.cache_value[crow] = vraw;
             }
             if (xst) x2 = clock64();
-            const float s = azk_pairwise_sum(L.e, A, L.racc);
+            const float s = azk_pairwise_sum(L.e, A);
             if (xst) x3 = clock64();
             const int fc = uniform_i32(e_top);
             const bool fits = fc + nv <= d.cap;
@@ -1528,10 +1521,9 @@ __global__ __launch_bounds__(AZK_WAVE) void k_rules(RuleArgs a) {
 __global__ __launch_bounds__(AZK_WAVE) void k_softmax_rows(const float *logits, int A, float *out) {
     const int b = blockIdx.x, lane = azk_lane();
     float *e = (float *)azk_smem;
-    float *racc = e + ((A + 31) & ~31);
     for (int i = lane; i < A; i += AZK_WAVE) e[i] = azk_exp_det(logits[(size_t)b * A + i]);
     __syncthreads();
-    const float s = azk_pairwise_sum(e, A, racc);
+    const float s = azk_pairwise_sum(e, A);
     for (int i = lane; i < A; i += AZK_WAVE) out[(size_t)b * A + i] = e[i] / s;
 }
 
