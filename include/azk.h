@@ -51,7 +51,7 @@ typedef struct azk_engine azk_engine;
 
 typedef struct {
     int32_t game;          /* AZK_* */
-    int32_t rows, cols;    /* Gomoku only (reference ships 7x7, gomoku.py:10; 15x15 by attribute override) */
+    int32_t rows, cols;    /* Gomoku only (reference ships 7x7, gomoku.py:10; 15x15 by attribute override); 1..400 cells, at most 30 columns */
     int32_t n_games;       /* G: games resident on this GPU */
     int32_t max_sims;      /* largest mcts_iterations a search will run (arena sizing) */
     int32_t leaf_dtype;    /* AZK_LEAF_F32 | AZK_LEAF_BF16 */
