@@ -251,20 +251,6 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev dd, const float *__restri
 #pragma unroll
         for (int k4 = 0; k4 < KSL; k4++) s_cells[k4] = d.cells[(size_t)g * d.rc_pad + min(lane + AZK_WAVE * k4, rc - 1)];
     }
-    // The walk's first level, fetched on speculation with the entry loads: an expanded root's children sit at arena index 1 (k_begin_search
-    // leaves arena_top = 1), so their address depends on the game index alone.  The previous leaf's backup, applied below, changes one of
-    // them (the root child on its path): that lane's copy is patched in registers with the very values the backup stores.  One dependent
-    // memory round trip less per simulation; any case outside the common one (root expanded in this launch, > 64 root children, a path
-    // of 64+ nodes, the budget-stepping instantiation) falls back to the loads in the walk.
-    constexpr bool PRE = ONE_LOAD;
-    NodeH pre_h = NodeH{0, 0.f, 0u, -1};
-    double pre_w = 0.0, pre_p64 = 0.0;
-    bool pre_ok = false;
-    if (PRE) {
-        const size_t pi = base + (size_t)min(1 + lane, d.cap - 1);
-        pre_h = d.H[pi]; pre_w = d.W[pi];
-        pre_p64 = d.rootP[(size_t)g * rc + min(lane, rc - 1)];
-    }
     if (ONE_LOAD) {                                          // (behind the loads that do not depend on them)
         e_node = __builtin_amdgcn_readlane(uw, 0); e_slot = __builtin_amdgcn_readlane(uw, 1); e_depth = __builtin_amdgcn_readlane(uw, 2);
         e_nv = __builtin_amdgcn_readlane(uw, 3); e_top = __builtin_amdgcn_readlane(uw, 4);
@@ -273,7 +259,6 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev dd, const float *__restri
         s_done = __builtin_amdgcn_readlane(uw, 7); s_player = __builtin_amdgcn_readlane(uw, 8); s_mc = __builtin_amdgcn_readlane(uw, 9);
         s_rootf64 = __builtin_amdgcn_readlane(uw, 10); r_fc = __builtin_amdgcn_readlane(uw, 11); r_N = __builtin_amdgcn_readlane(uw, 12);
         r_meta = (uint32_t)__builtin_amdgcn_readlane(uw, 13);
-        pre_ok = r_fc == 1;
     }
 
     if (EXPAND) {
@@ -385,21 +370,8 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev dd, const float *__restri
                     d.H[base + e_path].N = nN;
                     d.W[base + e_path] = nW;
                 }
-                if (PRE && pre_ok) {
-                    if (node == 0) pre_ok = false;                    // the root's children were written a few lines up
-                    else {                                            // depth >= 1: trace node 1 is a root child - lane 1 holds its new visit count and value
-                        const int pl = __builtin_amdgcn_readlane(e_path, 1) - 1;
-                        const int pN = __builtin_amdgcn_readlane(nN, 1);
-                        const double pW = __longlong_as_double((long long)azk_readlane_u64((unsigned long long)__double_as_longlong(nW), 1));
-                        if (lane == pl) {
-                            pre_h.N = pN; pre_w = pW;
-                            if (depth == 1 && fits) { pre_h.fc = fc; pre_h.meta = (node_meta & 0xffff0000u) | (uint32_t)nv; }   // ... and it is the node expanded above
-                        }
-                    }
-                }
             } else {
                 backup_path(d, base, d.path + (size_t)vi * d.path_cap, depth, v, vl);
-                pre_ok = false;
             }
             if (!vl) r_N += 1;                                        // the root is trace node 0 of every simulation
             if (xst && lane == 0) {
@@ -453,17 +425,14 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev dd, const float *__restri
                 // argmax as a DPP maximum + ballot - "first maximum wins" (node.py:47) is the lowest lane holding the maximum
                 const bool valid = lane < nch;
                 const size_t ci = base + fc + (valid ? lane : 0);
-                const bool use_pre = PRE && node == 0 && pre_ok;     // (wave-uniform) the root's children came with the entry loads
-                NodeH hc;                                             // one 16-byte load: N, P, meta, first_child
-                double Wc;
-                if (use_pre) { hc = pre_h; Wc = pre_w; }
-                else { hc = d.H[ci]; Wc = d.W[ci]; }
+                const NodeH hc = d.H[ci];                             // one 16-byte load: N, P, meta, first_child
+                const double Wc = d.W[ci];
                 const int Nc = hc.N, fcc = hc.fc;
                 const uint32_t mc = hc.meta;
                 const float P32 = hc.P;
                 unsigned long long winners;
                 if (f64) {                                            // root after Dirichlet mixing: float64 priors => float64 UCB
-                    const double P64 = use_pre ? pre_p64 : d.rootP[(size_t)g * rc + (valid ? lane : 0)];
+                    const double P64 = d.rootP[(size_t)g * rc + (valid ? lane : 0)];
                     const double s = sqrt((double)Np);
                     const double u0 = P64 * s / (double)(Nc + 1);
                     const double q = Wc / (double)Nc;                 // N = 0: inf/nan, discarded by the select

@@ -690,6 +690,18 @@ class KernelTimer:
             return None
         return sum(a.elapsed_time(b) for a, b in self.pairs) / len(self.pairs)
 
+    def robust_mean_ms(self):
+        """Mean of the samples that are not host stalls: a pair brackets an EAGER launch, and a host hiccup between its two event records
+        (garbage collection, another process tearing down) adds milliseconds to a ~10 us sample - a handful of those moves the mean of a
+        few hundred samples by tens of percent.  Samples above three times the median are dropped; returns (mean_ms, dropped, total)."""
+        self.torch.cuda.synchronize()
+        if not self.pairs:
+            return None, 0, 0
+        t = sorted(a.elapsed_time(b) for a, b in self.pairs)
+        med = t[len(t) // 2]
+        kept = [x for x in t if x <= 3.0 * med]
+        return sum(kept) / len(kept), len(t) - len(kept), len(t)
+
     def spread_us(self):
         """(median, max) of the samples in microseconds: a mean that sits far above the median is a few stalled samples, not the kernel."""
         self.torch.cuda.synchronize()

@@ -514,7 +514,13 @@ def main():
             if world > 1:
                 dist.destroy_process_group()
             return 0
-        tree_ms = kt.mean_ms()
+        ev_dropped = [0, 0]                       # HIP-event samples dropped as host stalls / taken (KernelTimer.robust_mean_ms)
+
+        def rmean(t_):
+            m_, d_, n_ = t_.robust_mean_ms()
+            ev_dropped[0] += d_; ev_dropped[1] += n_
+            return m_
+        tree_ms = rmean(kt)
         launches = max(1, (getattr(runner, "launches", 0) - launches0)) * runner.n_split      # k_tree launches in the window (one per game group and step)
         alg_bytes = algorithmic_bytes(c, A) / launches                         # this build's layout
         sv_bytes = survey_bytes(c, cfg.channels, cfg.rows, cfg.cols, A) / launches  # SURVEY 8(d)'s formula: what `frac` is priced on
@@ -535,10 +541,10 @@ def main():
         ev_us = {"tree": (tree_ms or 0.0) * 1e3}
         for nm_ in ("k_embed", "k_cls_pool", "k_embed_pool"):
             ch_ = kt.children.get(nm_)
-            ev_us[nm_] = (ch_.mean_ms() or 0.0) * 1e3 if ch_ else 0.0
+            ev_us[nm_] = (rmean(ch_) or 0.0) * 1e3 if ch_ else 0.0
         ch_ = kt.children.get("k_tail")
         tail_launches = 5 if (args.nn_path == "clsfold" and (args.nn_dtype == "fp32" or args.tail == "chain")) else 1
-        ev_us["k_tail"] = (ch_.mean_ms() or 0.0) * 1e3 * tail_launches if ch_ else 0.0
+        ev_us["k_tail"] = (rmean(ch_) or 0.0) * 1e3 * tail_launches if ch_ else 0.0
         step_us = dt * 1e6 / max(1, launches / runner.n_split)
         ev_sum = sum(ev_us.values())
         ev_pairs = {k_: (tail_launches if k_ == "k_tail" else 1) for k_, v_ in ev_us.items() if v_ > 0}
@@ -548,6 +554,7 @@ def main():
             return max(ms_ * 0.5, ms_ - pairs_ * ev_over * 1e-3)
         dur_note = (f"HIP-event samples of eagerly launched steps inside the timed window, each reduced by {ev_over:.2f} us per event pair = (sum of the raw samples "
                     f"{ev_sum:.1f} us - measured step time {step_us:.1f} us [window / {launches // runner.n_split} simulation steps]) / {sum(ev_pairs.values())} pairs per step; "
+                    f"{ev_dropped[0]} of {ev_dropped[1]} samples above 3x their kernel's median (host stalls between eager launches) dropped; "
                     "rocprofv3 --kernel-trace --stats of the same command is under profiles/")
         if tree_ms:
             t_us = ev_fix(tree_ms) * 1e3
@@ -570,7 +577,7 @@ def main():
         for name, per_board in (("k_embed", T_tok * Dm * 2 + cfg.num_heads * 4 * ((T_tok + 15) // 16 * 16) + 2 * cfg.rows * cfg.cols * 2),
                                 ("k_cls_pool", T_tok * Dm * 2 + cfg.num_heads * Dm * 2 + cfg.num_heads * 4 * ((T_tok + 15) // 16 * 16))):
             ch = kt.children.get(name)
-            ms = ch.mean_ms() if ch else None
+            ms = ch.robust_mean_ms()[0] if ch else None
             if ms:
                 by = per_board * live
                 kernels.append({"kernel": name, "bound": "hbm", "achieved": by / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -578,7 +585,7 @@ def main():
                                 "traffic": None, "event_samples": len(ch.pairs),
                                 "note": f"{per_board} B per live board x {live:.0f} live boards per launch (device-side count)"})
         ch = kt.children.get("k_embed_pool")            # fused embedding + cls pooling: on-chip, priced against the dense bf16 MFMA peak
-        ms = ch.mean_ms() if ch else None
+        ms = ch.robust_mean_ms()[0] if ch else None
         if ms:
             kreal = cfg.channels * cfg.patch_size ** 2
             per_board = 2 * (T_tok - 1) * Dm * kreal + 2 * T_tok * 16 * kreal + 2 * T_tok * cfg.num_heads * Dm
@@ -622,7 +629,7 @@ def main():
                                      "rest as precomputed constants (executed_share_of_algorithmic_flops: MFMA work actually issued); HBM traffic is "
                                      "~9 KB per board (board in, z out): bound by VALU/MFMA issue and LDS, not HBM")})
         ch = kt.children.get("k_tail")                  # the cls-row tail (five k_tail_gemm launches, or the library GEMMs): MFMA-bound
-        ms = ch.mean_ms() if ch else None
+        ms = ch.robust_mean_ms()[0] if ch else None
         ms_raw = None
         if ms and args.nn_path == "clsfold" and (exact or args.tail == "chain"):
             ms *= 5                                     # the timer holds one event pair per launch of the five-launch chain: their sum per step
