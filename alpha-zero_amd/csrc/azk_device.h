@@ -472,27 +472,37 @@ __device__ int azk_valid_moves_gomoku(const uint8_t *b, const GameDesc &g, int16
             const bool have = idx < count;
             const unsigned keyv = have ? (unsigned)list[idx] : 1u;   // cell + 1
             const unsigned long long h = hash_cell1((int)keyv);
+            // the first window of the probe sequence is the same in every round (slots i0 .. i0+9, or i0 alone near the table's end):
+            // its address, shift and width are fixed per key, and the round reads it straight-line
+            const unsigned i0 = (unsigned)h & msk, w0 = i0 >> 5, sh0 = i0 & 31u;
+            const unsigned win0 = (i0 + 9u <= msk) ? 0x3ffu : 1u;
             bool placed = !have;
             while (__ballot(!placed) != 0ull) {
-                unsigned slot = 0;
-                if (!placed) {
-                    unsigned long long perturb = h;
-                    unsigned i = (unsigned)h & msk;
-                    for (;;) {
-                        if (i + 9 <= msk) {
-                            // the ten-slot window from the occupancy bitmap: two words cover bits i .. i+9
-                            const unsigned w = i >> 5, sh = i & 31u;
-                            const unsigned long long both = ((unsigned long long)occ[w + 1] << 32) | (unsigned long long)occ[w];
-                            const unsigned z = (unsigned)((~both) >> sh) & 0x3ffu;
-                            if (z) { slot = i + (unsigned)__ffs((int)z) - 1u; break; }
-                        } else if (((occ[i >> 5] >> (i & 31u)) & 1u) == 0u) { slot = i; break; }
-                        perturb >>= 5;
-                        i = (unsigned)((unsigned long long)i * 5 + 1 + perturb) & msk;
+                // the ten-slot window from the occupancy bitmap: two words cover bits i .. i+9
+                const unsigned long long both0 = ((unsigned long long)occ[w0 + 1] << 32) | (unsigned long long)occ[w0];
+                const unsigned z0 = (unsigned)((~both0) >> sh0) & win0;
+                unsigned slot = i0 + (unsigned)__ffs((int)z0) - 1u;
+                const bool deeper = !placed && z0 == 0u;              // the whole first window is taken: the perturbed sequence (rare)
+                if (__ballot(deeper) != 0ull) {
+                    if (deeper) {
+                        unsigned long long perturb = h;
+                        unsigned i = i0;
+                        for (;;) {
+                            perturb >>= 5;
+                            i = (unsigned)((unsigned long long)i * 5 + 1 + perturb) & msk;
+                            if (i + 9 <= msk) {
+                                const unsigned w = i >> 5, sh = i & 31u;
+                                const unsigned long long both = ((unsigned long long)occ[w + 1] << 32) | (unsigned long long)occ[w];
+                                const unsigned z = (unsigned)((~both) >> sh) & 0x3ffu;
+                                if (z) { slot = i + (unsigned)__ffs((int)z) - 1u; break; }
+                            } else if (((occ[i >> 5] >> (i & 31u)) & 1u) == 0u) { slot = i; break; }
+                        }
                     }
-                    atomicMin(&ms.claim[slot], (stamp << 6) | (unsigned)lane);
                 }
+                const unsigned mine = (stamp << 6) | (unsigned)lane;
+                if (!placed) atomicMin(&ms.claim[slot], mine);
                 azk_wave_sync();                                      // the claims are applied before the read below (issue order)
-                const bool conflict = !placed && ms.claim[slot] != ((stamp << 6) | (unsigned)lane);
+                const bool conflict = !placed && ms.claim[placed ? 0u : slot] != mine;
                 const unsigned long long cb = __ballot(conflict);
                 const int first_bad = cb ? __ffsll((long long)cb) - 1 : AZK_WAVE;
                 if (!placed && lane < first_bad) { tb[slot] = (uint16_t)keyv; atomicOr(&occ[slot >> 5], 1u << (slot & 31u)); placed = true; }
