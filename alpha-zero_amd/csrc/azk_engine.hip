@@ -25,6 +25,7 @@ struct __attribute__((aligned(16))) NodeH { int N; float P; uint32_t meta; int f
 struct Dev {               // device view of the engine, passed to kernels by value
     GameDesc g;
     int G, cap, path_cap, rc_pad, leaf_dtype, table_size, lds_bytes;
+    int lds_off[12];       // lds_layout()'s offsets, computed once on the host (k_tree reads them instead of redoing the arithmetic in every wave)
     int K;                 // leaves in flight per game (virtual-loss mode, opt-in; 1 = the reference's sequential search).  Every
                            // pending-leaf array below is [G * K], slot v = g * K + k
     // game state
@@ -109,6 +110,24 @@ __host__ __device__ inline int lds_layout(const GameDesc &g, int path_cap, int t
 
 extern __shared__ __attribute__((aligned(16))) unsigned char azk_smem[];
 
+__device__ __forceinline__ LdsView carve_at(const int *off, int table_size) {
+    LdsView L;
+    L.board = azk_smem + off[0];
+    L.path = (int *)(azk_smem + off[1]);
+    L.moves = (int16_t *)(azk_smem + off[2]);
+    L.e = (float *)(azk_smem + off[3]);
+    L.cnt = (int *)(azk_smem + off[4]);
+    L.cdf = (double *)(azk_smem + off[5]);
+    L.ms.bits = (uint32_t *)(azk_smem + off[6]);
+    L.ms.pref = (uint16_t *)(azk_smem + off[7]);
+    L.ms.ord = (int16_t *)(azk_smem + off[8]);
+    L.ms.tabA = (uint16_t *)(azk_smem + off[9]);
+    L.ms.tabB = (uint16_t *)(azk_smem + off[10]);
+    L.ms.claim = (uint32_t *)(azk_smem + off[11]);
+    L.ms.table_size = table_size;
+    return L;
+}
+
 __device__ __forceinline__ LdsView carve(const GameDesc &g, int path_cap, int table_size) {
     int off[12];
     lds_layout(g, path_cap, table_size, off);
@@ -171,7 +190,7 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev dd, const float *__restri
     const GameDesc &gd = d.g;
     const int A = gd.action_dim, rc = gd.rc;
     const size_t base = (size_t)g * (size_t)d.cap;
-    LdsView L = carve(gd, d.path_cap, d.table_size);
+    LdsView L = carve_at(d.lds_off, d.table_size);
     const bool wrec = DBG && (ablate & 8192) != 0;      // debug only: ONE record per wave and launch (overwritten), for the distribution of wave times
     const bool stamp = (ablate & 16) != 0 || wrec;
     long long t0 = stamp ? clock64() : 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
@@ -1594,6 +1613,7 @@ int32_t azk_create(const azk_config *cfg, azk_engine **out) {
     { const char *ab = getenv("AZK_TREE_ABLATE"); d.ablate = ab ? atoi(ab) : 0; }
     int off[15];
     d.lds_bytes = lds_layout(g, d.path_cap, d.table_size, off);
+    for (int i = 0; i < 12; i++) d.lds_off[i] = off[i];
     const size_t G = d.G, nodes = G * (size_t)d.cap;
     hipError_t s = hipSuccess;
 #define DA(ptr, count) if (s == hipSuccess) s = dalloc(e, &ptr, (count))
