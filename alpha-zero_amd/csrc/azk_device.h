@@ -255,7 +255,7 @@ __device__ __forceinline__ int azk_valid_moves_small(const uint8_t *b, const Gam
 
 // Gomoku.  `mid` is called exactly once, by all lanes, after the first-adder keys - a few thousand cycles into the function:
 // k_tree looks at its eval-cache probe there, whose loads it issued before the call.
-template <typename Mid = AzkNoHook>
+template <int KMAX = 7, typename Mid = AzkNoHook>                    // KMAX: cell groups of 64 the function is unrolled for (rc <= 64 KMAX)
 __device__ int azk_valid_moves_gomoku(const uint8_t *b, const GameDesc &g, int16_t *moves, const MoveScratch &ms, bool skip_set = false,
                                       long long *dbgv = nullptr, Mid &&mid = Mid()) {
     const int lane = azk_lane();
@@ -265,7 +265,6 @@ __device__ int azk_valid_moves_gomoku(const uint8_t *b, const GameDesc &g, int16
     // needs no wait between them, only a compiler-level fence (azk_wave_sync).  Every wait in this function is a data wait.
     const int R = g.rows, C = g.cols, rc = g.rc;
     const int nwords = (rc * 8 + 31) >> 5;
-    constexpr int KMAX = 7;                                       // cells per lane: rc <= 448
     long long s0 = dbgv ? clock64() : 0, s1 = 0, s2 = 0, s3 = 0;
     // this lane's cells (lane + 64 k): board codes and columns once, straight-line (no load sits behind a branch);
     // e / C by multiplication: exact for e < 65536 / C

@@ -181,7 +181,10 @@ __device__ __forceinline__ void backup_path(const Dev &d, size_t base, const int
 // budget[1] simulations.  The order of a game's simulations is untouched (they are sequential inside one wave), so every tree
 // is bit-identical to one-simulation-per-launch stepping; what changes is that ~55 % of the simulations no longer wait for a
 // kernel boundary and every launch hands the evaluator a (nearly) full batch.
-template <bool EXPAND, bool SELECT, bool DBG, bool MULTI = false>
+// KSL: cells (and actions) per lane the kernel is compiled for - 4 covers boards of up to 256 cells (every shipped game), 7 the rest
+// (make_game allows 400).  A compile-time bound: the per-lane load sequences, their registers and the move generator's cell groups are
+// unrolled to it, and a 15 x 15 board does not pay for three empty groups in each of them.
+template <bool EXPAND, bool SELECT, bool DBG, bool MULTI = false, int KSL = 7>
 __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev dd, const float *__restrict__ logits, const float *__restrict__ values) {
     const Dev &d = dd;
     const int ablate = DBG ? dd.ablate : 0;
@@ -259,13 +262,12 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev dd, const float *__restri
     //  is compiled as a branch around the load plus a wait for its result right behind it, and the eighteen loads of this entry
     //  sequence then cost one memory round trip EACH instead of one together)
     const int e_path = EXPAND ? d.path[(size_t)vi * d.path_cap + min(lane, d.path_cap - 1)] : 0;     // trace nodes 0..63 (deeper ones: below)
-    constexpr int KSL = 7;                                  // cells per lane: rc <= 448 (make_game allows 400)
-    int e_mv[KSL] = {0, 0, 0, 0, 0, 0, 0};
+    int e_mv[KSL] = {};
     if (EXPAND) {
 #pragma unroll
         for (int k4 = 0; k4 < KSL; k4++) e_mv[k4] = d.leaf_moves[(size_t)vi * rc + min(lane + AZK_WAVE * k4, rc - 1)];
     }
-    int s_cells[KSL] = {0, 0, 0, 0, 0, 0, 0};               // (one register each: byte-sized destinations are packed, and every packed load waits for the one before)
+    int s_cells[KSL] = {};                                  // (one register each: byte-sized destinations are packed, and every packed load waits for the one before)
     if (SELECT) {
 #pragma unroll
         for (int k4 = 0; k4 < KSL; k4++) s_cells[k4] = d.cells[(size_t)g * d.rc_pad + min(lane + AZK_WAVE * k4, rc - 1)];
@@ -314,7 +316,7 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev dd, const float *__restri
             const float vraw = hit ? (shared ? d.hit_value[vi] : d.cache_value[crow]) : values[slot];
             const uint32_t node_meta = d.H[base + node].meta;
             const bool mix = depth == 0 && d.noise != nullptr;        // mcts.py:42-43,52-53
-            double nzv[KSL] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            double nzv[KSL] = {};
             if (mix) {
                 // asynchronous moves keep two rows per game - the current search's and the next one's, generated a whole search ahead
                 // (k_noise_ahead) - and the slot's move counter says which is which
@@ -629,7 +631,7 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev dd, const float *__restri
         int entry = 0;
         unsigned long long mykey = 0ull, kw = 0ull;
         unsigned c1v = 0u, c2v = 0u;
-        float row[KSL] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, vv = 0.f;
+        float row[KSL] = {}, vv = 0.f;
         bool maybe_hit = false;                                       // shared table: key and claim word say "hit" - the second claim read decides
         const int KW = d.key_words;
         if (d.cache_entries) {
@@ -676,7 +678,7 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev dd, const float *__restri
         unsigned c2 = 0u;
         if (ablate & 4) { nv = 1; if (lane == 0) L.moves[0] = (int16_t)(gd.rc / 2); __syncthreads(); probe_mid(); c2 = (unsigned)uniform_i32((int)c2v); }
         else if (gd.kind == AZK_KIND_GOMOKU) {                         // mcts.py:34
-            nv = azk_valid_moves_gomoku(L.board, gd, L.moves, L.ms, (ablate & 8) != 0, (ablate & 32) ? d.dbg + (size_t)g * 8 : nullptr, probe_mid);
+            nv = azk_valid_moves_gomoku<KSL>(L.board, gd, L.moves, L.ms, (ablate & 8) != 0, (ablate & 32) ? d.dbg + (size_t)g * 8 : nullptr, probe_mid);
             c2 = (unsigned)uniform_i32((int)c2v);
         } else { probe_mid(); c2 = (unsigned)uniform_i32((int)c2v); nv = azk_valid_moves_small(L.board, gd, L.moves); }
         if (stamp) t4 = clock64();
@@ -736,6 +738,11 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev dd, const float *__restri
         }
     }
 }
+
+// launch: the instantiation compiled for this engine's cells-per-lane bound
+#define AZK_LAUNCH_TREE(E_, S_, D_, M_, ARGS_) do { \
+        if (d.g.rc <= 4 * AZK_WAVE && d.g.action_dim <= 4 * AZK_WAVE) k_tree<E_, S_, D_, M_, 4><<<d.G, AZK_WAVE, d.lds_bytes, st>>> ARGS_; \
+        else k_tree<E_, S_, D_, M_, 7><<<d.G, AZK_WAVE, d.lds_bytes, st>>> ARGS_; } while (0)
 
 // Leaf compaction: slot = number of leaf games with a lower index (deterministic order); writes the
 // canonical board (gomoku.py:34-40; 3-plane: mcts.py:126-137) of each leaf into the evaluator batch.
@@ -1793,7 +1800,7 @@ int32_t azk_async_step(azk_engine *e, const float *logits_dev, const float *valu
     if (!e || !e->async_on) { if (e) e->err = "azk_async_step: call azk_async_begin first"; return AZK_ERR_STATE; }
     const Dev &d = e->d;
     hipStream_t st = (hipStream_t)stream;
-    if (phases & 1) k_tree<true, true, false, true><<<d.G, AZK_WAVE, d.lds_bytes, st>>>(d, logits_dev, values_dev);
+    if (phases & 1) AZK_LAUNCH_TREE(true, true, false, true, (d, logits_dev, values_dev));
     if (phases & 2) k_move_async<<<d.G, AZK_WAVE, d.lds_bytes, st>>>(d, e->ad);
     HIPCHK(e, hipGetLastError());
     return AZK_OK;
@@ -1858,16 +1865,16 @@ static int32_t launch_tree(azk_engine *e, bool expand, bool select, const float 
     if (expand && (!logits || !values)) { e->err = "expand needs logits_dev and values_dev"; return AZK_ERR_ARG; }
     if (select && (!leaf_boards || !n_leaf)) { e->err = "select needs leaf_boards_dev and n_leaf_dev"; return AZK_ERR_ARG; }
     if (d.ablate) {
-        if (expand && select) k_tree<true, true, true><<<d.G, AZK_WAVE, d.lds_bytes, st>>>(d, logits, values);
-        else if (expand) k_tree<true, false, true><<<d.G, AZK_WAVE, d.lds_bytes, st>>>(d, logits, values);
-        else k_tree<false, true, true><<<d.G, AZK_WAVE, d.lds_bytes, st>>>(d, logits, values);
+        if (expand && select) AZK_LAUNCH_TREE(true, true, true, false, (d, logits, values));
+        else if (expand) AZK_LAUNCH_TREE(true, false, true, false, (d, logits, values));
+        else AZK_LAUNCH_TREE(false, true, true, false, (d, logits, values));
     } else if (e->multi && select) {
         // budget stepping always carries the expansion code: a leaf served by the cache is expanded inside the launch (logits may
         // be null when no game has a pending evaluation, e.g. in a search's first launch)
-        k_tree<true, true, false, true><<<d.G, AZK_WAVE, d.lds_bytes, st>>>(d, logits, values);
-    } else if (expand && select) k_tree<true, true, false><<<d.G, AZK_WAVE, d.lds_bytes, st>>>(d, logits, values);
-    else if (expand) k_tree<true, false, false><<<d.G, AZK_WAVE, d.lds_bytes, st>>>(d, logits, values);
-    else k_tree<false, true, false><<<d.G, AZK_WAVE, d.lds_bytes, st>>>(d, logits, values);
+        AZK_LAUNCH_TREE(true, true, false, true, (d, logits, values));
+    } else if (expand && select) AZK_LAUNCH_TREE(true, true, false, false, (d, logits, values));
+    else if (expand) AZK_LAUNCH_TREE(true, false, false, false, (d, logits, values));
+    else AZK_LAUNCH_TREE(false, true, false, false, (d, logits, values));
     HIPCHK(e, hipGetLastError());
     if (select) {
         k_gather<<<d.G * d.K, AZK_WAVE, 0, st>>>(d, leaf_boards, n_leaf);
@@ -1898,12 +1905,12 @@ int32_t azk_step_tree(azk_engine *e, const float *logits_dev, const float *value
     hipStream_t st = (hipStream_t)stream;
     if (logits_dev && !values_dev) { e->err = "values_dev missing"; return AZK_ERR_ARG; }
     if (d.ablate) {
-        if (logits_dev) k_tree<true, true, true><<<d.G, AZK_WAVE, d.lds_bytes, st>>>(d, logits_dev, values_dev);
-        else k_tree<false, true, true><<<d.G, AZK_WAVE, d.lds_bytes, st>>>(d, nullptr, nullptr);
+        if (logits_dev) AZK_LAUNCH_TREE(true, true, true, false, (d, logits_dev, values_dev));
+        else AZK_LAUNCH_TREE(false, true, true, false, (d, nullptr, nullptr));
     } else if (e->multi) {
-        k_tree<true, true, false, true><<<d.G, AZK_WAVE, d.lds_bytes, st>>>(d, logits_dev, values_dev);
-    } else if (logits_dev) k_tree<true, true, false><<<d.G, AZK_WAVE, d.lds_bytes, st>>>(d, logits_dev, values_dev);
-    else k_tree<false, true, false><<<d.G, AZK_WAVE, d.lds_bytes, st>>>(d, nullptr, nullptr);
+        AZK_LAUNCH_TREE(true, true, false, true, (d, logits_dev, values_dev));
+    } else if (logits_dev) AZK_LAUNCH_TREE(true, true, false, false, (d, logits_dev, values_dev));
+    else AZK_LAUNCH_TREE(false, true, false, false, (d, nullptr, nullptr));
     HIPCHK(e, hipGetLastError());
     return AZK_OK;
 }
