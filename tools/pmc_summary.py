@@ -7,7 +7,7 @@ import json
 import re
 import sys
 
-KEYS = ("k_tree<true, true, false, false>", "k_tree<true, true, false, true>", "k_embed_fold", "k_embed_pool_c", "k_embed_pool_x", "k_gemm_x", "k_tail_gemm", "k_tail_lds", "k_move_async")
+KEYS = ("k_tree<true, true, false, false", "k_tree<true, true, false, true", "k_embed_fold", "k_embed_pool_c", "k_embed_pool_x", "k_gemm_x", "k_tail_gemm", "k_tail_lds", "k_move_async")
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for d in sys.argv[1:]:
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):

@@ -15,7 +15,7 @@ mkdir -p $O
 ( while sleep 45; do echo "[heartbeat $(date +%T)]"; done ) &
 HB=$!
 B="python3 bench.py --steps 1 --warmup 1 --preroll-cheap 32 --preroll-full 2 --cpu-seconds 0 --fp32-steps 0 $*"
-for RX in k_tree k_embed_fold k_tail_lds k_tail_gemm; do
+for RX in ${PMC_FAMILIES:-k_tree k_embed_fold k_tail_lds k_tail_gemm}; do        # (PMC_FAMILIES="k_tree": one family again, e.g. after a rename)
 for pass in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_INSTS_MFMA SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_SCA"; do
   tag=${RX}_$(echo $pass | cut -d' ' -f1)
   t0=$(date +%s)
