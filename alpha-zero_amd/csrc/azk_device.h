@@ -545,6 +545,15 @@ __device__ int azk_valid_moves_gomoku(const uint8_t *b, const GameDesc &g, int16
     }
     if (dbgv) s3 = clock64();
     // 5. list(set): table order
+    if (mask == 127u) {                                               // the common table: both halves' reads in flight together
+        const uint16_t k0 = tab[lane], k1 = tab[AZK_WAVE + lane];
+        const unsigned long long b0 = __ballot(k0 != 0), b1 = __ballot(k1 != 0);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        const int n0 = __popcll(b0);
+        if (k0) moves[__popcll(b0 & below)] = (int16_t)(k0 - 1);
+        if (k1) moves[n0 + __popcll(b1 & below)] = (int16_t)(k1 - 1);
+        n = n0 + __popcll(b1);
+    } else
     for (unsigned base = 0; base <= mask; base += AZK_WAVE) {
         const unsigned i = base + lane;
         const uint16_t kv = i <= mask ? tab[i] : (uint16_t)0;

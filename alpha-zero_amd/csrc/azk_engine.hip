@@ -267,10 +267,15 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev dd, const float *__restri
 #pragma unroll
         for (int k4 = 0; k4 < KSL; k4++) e_mv[k4] = d.leaf_moves[(size_t)vi * rc + min(lane + AZK_WAVE * k4, rc - 1)];
     }
-    int s_cells[KSL] = {};                                  // (one register each: byte-sized destinations are packed, and every packed load waits for the one before)
+    // the game's cell codes, four to a register: a row of `cells` is rc_pad bytes (a multiple of 16, zeros past rc), so the board comes in as
+    // NCW dword loads per lane instead of KSL byte loads, and goes to LDS - and later out to leaf_cells - the same way
+    constexpr int NCW = (KSL * AZK_WAVE / 4 + AZK_WAVE - 1) / AZK_WAVE;
+    const int ncw = d.rc_pad >> 2;
+    uint32_t s_cw[NCW] = {};
     if (SELECT) {
+        const uint32_t *cw = (const uint32_t *)(d.cells + (size_t)g * d.rc_pad);
 #pragma unroll
-        for (int k4 = 0; k4 < KSL; k4++) s_cells[k4] = d.cells[(size_t)g * d.rc_pad + min(lane + AZK_WAVE * k4, rc - 1)];
+        for (int q = 0; q < NCW; q++) s_cw[q] = cw[min(lane + AZK_WAVE * q, ncw - 1)];
     }
     if (ONE_LOAD) {                                          // (behind the loads that do not depend on them)
         e_node = __builtin_amdgcn_readlane(uw, 0); e_slot = __builtin_amdgcn_readlane(uw, 1); e_depth = __builtin_amdgcn_readlane(uw, 2);
@@ -418,7 +423,7 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev dd, const float *__restri
         done_sims++;
         if (stamp) t1 = clock64();
 #pragma unroll
-        for (int k4 = 0; k4 < KSL; k4++) { const int i = lane + AZK_WAVE * k4; if (i < rc) L.board[i] = s_cells[k4]; }
+        for (int q = 0; q < NCW; q++) { const int i = lane + AZK_WAVE * q; if (i < ncw) ((uint32_t *)L.board)[i] = s_cw[q]; }
         const int root_player = uniform_i32(s_player);
         const int root_mc = uniform_i32(s_mc);
         if (lane == 0) L.path[0] = 0;
@@ -700,7 +705,11 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev dd, const float *__restri
             if (lane == 0) d.leaf_cache[vi] = cached ? entry : -(entry + 1);
         }
         for (int i = lane; i < nv; i += AZK_WAVE) d.leaf_moves[(size_t)vi * rc + i] = L.moves[i];
-        for (int i = lane; i < rc; i += AZK_WAVE) d.leaf_cells[(size_t)vi * d.rc_pad + i] = L.board[i];
+        {
+            uint32_t *lw = (uint32_t *)(d.leaf_cells + (size_t)vi * d.rc_pad);
+#pragma unroll
+            for (int q = 0; q < NCW; q++) { const int i = lane + AZK_WAVE * q; if (i < ncw) lw[i] = ((const uint32_t *)L.board)[i]; }
+        }
         for (int i = lane; i <= depth; i += AZK_WAVE) d.path[(size_t)vi * d.path_cap + i] = L.path[i];
         if (vl) {                                                     // virtual loss: the path counts a visit now and a lost game until its value arrives
             for (int i = lane; i <= depth; i += AZK_WAVE) { const int nd = L.path[i]; d.H[base + nd].N += 1; d.W[base + nd] -= 1.0; }
