@@ -21,6 +21,7 @@ namespace {
 enum { CNT_SIMS = 0, CNT_SCANNED, CNT_TRACE, CNT_CREATED, CNT_LEAVES, CNT_TERMINAL, CNT_MOVES, CNT_CACHE_HITS, CNT_N };
 
 struct __attribute__((aligned(16))) NodeH { int N; float P; uint32_t meta; int fc; };
+typedef float f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));   // four consecutive floats of a row that is only 4-byte aligned (A = 225: 900-byte rows)
 
 struct Dev {               // device view of the engine, passed to kernels by value
     GameDesc g;
@@ -315,9 +316,19 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev dd, const float *__restri
             const int bN = d.H[base + bnode].N;
             const double bW = d.W[base + bnode];
             // second (and last) round trip of the expansion, all straight-line: logits, value, the node's header, root noise
-            float lgv[KSL];
+            // a lane takes FOUR consecutive logits per load (actions 4 lane .. 4 lane + 3 of each block of 256; the lane at the row's end
+            // takes the row's last four, overlapping its neighbour - the same values twice): one 16-byte load instead of four 4-byte ones,
+            // here and for the eval-cache row's stores and loads below
+            constexpr int NV4 = (KSL * AZK_WAVE + 255) / 256;
+            int la[NV4];                                              // first action of the lane's group
+            bool lact[NV4];
+            f32x4_a4 lgv[NV4];
 #pragma unroll
-            for (int k4 = 0; k4 < KSL; k4++) { const int i = lane + AZK_WAVE * k4; lgv[k4] = lg[i < A ? i : A - 1]; }
+            for (int q = 0; q < NV4; q++) {
+                lact[q] = 256 * q + 4 * lane < A;
+                la[q] = min(256 * q + 4 * lane, A - 4);
+                lgv[q] = *(const f32x4_a4 *)(lg + la[q]);
+            }
             const float vraw = hit ? (shared ? d.hit_value[vi] : d.cache_value[crow]) : values[slot];
             const uint32_t node_meta = d.H[base + node].meta;
             const bool mix = depth == 0 && d.noise != nullptr;        // mcts.py:42-43,52-53
@@ -345,18 +356,20 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev dd, const float *__restri
             if (xst) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); x1 = clock64(); }
             // float32 softmax, no max subtraction (mcts.py:48-49)
 #pragma unroll
-            for (int k4 = 0; k4 < KSL; k4++) {
-                if (AZK_WAVE * k4 >= A) break;
-                const int i = lane + AZK_WAVE * k4;
-                const float ev = (ablate & 1) ? 1.0f : azk_exp_det(lgv[k4]);
-                if (i < A) L.e[i] = ev;
+            for (int q = 0; q < NV4; q++) {
+                if (256 * q >= A) break;
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const float ev = (ablate & 1) ? 1.0f : azk_exp_det(lgv[q][c]);
+                    if (lact[q]) L.e[la[q] + c] = ev;
+                }
             }
             azk_wave_sync();
             if (cache_write) {
                 // (behind the exponentials: by now every logit is in its register, and the stores go out back to back - placed
                 //  right behind the loads, each store waited for the one before it, one write round trip per 64 actions)
 #pragma unroll
-                for (int k4 = 0; k4 < KSL; k4++) { const int i = lane + AZK_WAVE * k4; if (i < A) d.cache_logits[crow * A + i] = lgv[k4]; }
+                for (int q = 0; q < NV4; q++) if (lact[q]) *(f32x4_a4 *)(d.cache_logits + crow * A + la[q]) = lgv[q];
                 if (lane == 0) d.cache_value[crow] = vraw;
             }
             if (xst) x2 = clock64();
@@ -636,7 +649,9 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev dd, const float *__restri
         int entry = 0;
         unsigned long long mykey = 0ull, kw = 0ull;
         unsigned c1v = 0u, c2v = 0u;
-        float row[KSL] = {}, vv = 0.f;
+        constexpr int NV4P = (KSL * AZK_WAVE + 255) / 256;           // the cached row, four consecutive logits per lane and load (as at the expansion)
+        f32x4_a4 row[NV4P] = {};
+        float vv = 0.f;
         bool maybe_hit = false;                                       // shared table: key and claim word say "hit" - the second claim read decides
         const int KW = d.key_words;
         if (d.cache_entries) {
@@ -659,7 +674,7 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev dd, const float *__restri
                 c1v = __hip_atomic_load(d.cache_claim + entry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 kw = d.cache_key[(size_t)entry * KW + min(lane, KW - 1)];
 #pragma unroll
-                for (int k4 = 0; k4 < KSL; k4++) { const int i = lane + AZK_WAVE * k4; row[k4] = d.cache_logits[(size_t)entry * A + (i < A ? i : A - 1)]; }
+                for (int q = 0; q < NV4P; q++) row[q] = *(const f32x4_a4 *)(d.cache_logits + (size_t)entry * A + min(256 * q + 4 * lane, A - 4));
                 vv = d.cache_value[entry];
             } else {
                 entry = (int)(h & (unsigned long long)(d.cache_entries - 1));
@@ -692,7 +707,7 @@ __global__ __launch_bounds__(AZK_WAVE) void k_tree(Dev dd, const float *__restri
                 if (maybe_hit && c2 == (unsigned)uniform_i32((int)c1v)) {   // nobody started rewriting the entry meanwhile: the copy is whole
                     cached = true;
 #pragma unroll
-                    for (int k4 = 0; k4 < KSL; k4++) { const int i = lane + AZK_WAVE * k4; if (i < A) d.hit_logits[(size_t)vi * A + i] = row[k4]; }
+                    for (int q = 0; q < NV4P; q++) if (256 * q + 4 * lane < A) *(f32x4_a4 *)(d.hit_logits + (size_t)vi * A + min(256 * q + 4 * lane, A - 4)) = row[q];
                     if (lane == 0) d.hit_value[vi] = vv;
                 }
                 if (!cached && lane < KW) d.leaf_key[(size_t)vi * KW + lane] = mykey;      // written into the table at expansion
